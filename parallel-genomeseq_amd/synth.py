@@ -1,0 +1,113 @@
+"""Deterministic synthetic inputs: SplitMix64-seeded DNA / protein sequences
+and reads in the shapes the reference's drivers consume (src/sw_solve_big.cpp:30-37,69:
+single-line reference, reads = CSV column 2; py/ompfg_data_prep.py:92-116)."""
+import numpy as np
+
+_G = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def splitmix64(seed, count, start=0):
+    """Outputs start+1 .. start+count of SplitMix64(seed) as a uint64 array (vectorised:
+    the k-th output depends only on seed + k*gamma)."""
+    with np.errstate(over="ignore"):
+        k = np.arange(start + 1, start + count + 1, dtype=np.uint64)
+        z = np.uint64(seed) + k * _G
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+_DNA = np.frombuffer(b"ACGT", dtype=np.uint8)
+# 20 amino acids, rough UniProt background frequencies (per mille)
+_AA = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+_AA_W = np.array([83, 14, 55, 68, 39, 71, 23, 59, 58, 97, 24, 41, 47, 39, 55, 66, 54, 69, 11, 29], dtype=np.float64)
+
+
+def dna(seed, length, chunk=1 << 24):
+    """Uniform ACGT: base = "ACGT"[x >> 62]."""
+    out = np.empty(length, dtype=np.uint8)
+    for s in range(0, length, chunk):
+        n = min(chunk, length - s)
+        out[s:s + n] = _DNA[(splitmix64(seed, n, s) >> np.uint64(62)).astype(np.intp)]
+    return out
+
+
+def protein(seed, length):
+    cdf = np.cumsum(_AA_W) / _AA_W.sum()
+    u = (splitmix64(seed, length) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    return _AA[np.minimum(np.searchsorted(cdf, u, side="right"), 19)]
+
+
+def read_from_ref(ref, seed, length, sub_rate=0.01, indel_rate=0.001):
+    """One read: substring of `ref` at a PRNG offset with substitutions and single-base indels
+    so the traceback sees gaps.  Returns (read uint8 array, 0-based offset)."""
+    r = splitmix64(seed, 4 * length + 8)
+    n = len(ref)
+    span = length + 16
+    off = int(r[0] % np.uint64(max(1, n - span)))
+    src = ref[off:off + span]
+    out = []
+    k = 0
+    i = 0
+    while len(out) < length and i < len(src):
+        u = float(r[1 + k] >> np.uint64(11)) / float(1 << 53)
+        v = int(r[2 + k] >> np.uint64(62))
+        k += 2
+        if u < indel_rate / 2:            # deletion from the read
+            i += 1
+            continue
+        if u < indel_rate:                # insertion into the read
+            out.append(int(_DNA[v]))
+            continue
+        b = int(src[i])
+        if u < indel_rate + sub_rate:
+            b = int(_DNA[(int(np.searchsorted(_DNA, b)) + 1 + v % 3) % 4]) if b in _DNA else int(_DNA[v])
+        out.append(b)
+        i += 1
+    while len(out) < length:
+        out.append(int(_DNA[0]))
+    return np.array(out[:length], dtype=np.uint8), off
+
+
+def reads_from_ref(ref, seed, count, length, sub_rate=0.01, indel_rate=0.001):
+    """`count` reads; read k uses seed (seed + 0x1000003 * k)."""
+    reads = np.empty((count, length), dtype=np.uint8)
+    offs = np.empty(count, dtype=np.int64)
+    for k in range(count):
+        reads[k], offs[k] = read_from_ref(ref, seed + 0x1000003 * k, length, sub_rate, indel_rate)
+    return reads, offs
+
+
+def fast_reads_from_ref(ref, seed, count, length, sub_rate=0.01):
+    """Vectorised variant for large batches (substitutions only)."""
+    n = len(ref)
+    offs = (splitmix64(seed, count) % np.uint64(max(1, n - length))).astype(np.int64)
+    idx = offs[:, None] + np.arange(length, dtype=np.int64)[None, :]
+    reads = ref[idx]
+    r = splitmix64(seed ^ 0x5DEECE66D, count * length).reshape(count, length)
+    u = (r >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    sub = u < sub_rate
+    repl = _DNA[(r & np.uint64(3)).astype(np.intp)]
+    return np.where(sub, repl, reads).astype(np.uint8), offs
+
+
+def make_lut(seed, scale=1.0):
+    """256x256 float32 scoring table: diagonal in [1,6]*scale, off-diagonal in [-5,5]*scale.
+    The same construction is used by oracle/ref_driver.cpp's `alignlut` so that fixtures made
+    with the real reference can be replayed."""
+    r = splitmix64(seed, 65536).reshape(256, 256)
+    off = (r % np.uint64(11)).astype(np.int64) - 5
+    dia = 1 + (r % np.uint64(6)).astype(np.int64)
+    lut = np.where(np.eye(256, dtype=bool), dia, off).astype(np.float32) * np.float32(scale)
+    return np.ascontiguousarray(lut)
+
+
+def lognormal_lengths(seed, count, median=290.0, sigma=0.66, lo=2, hi=35000):
+    """UniProt-like sequence length distribution (SURVEY.md §8d cfg 4)."""
+    r = splitmix64(seed, 2 * count)
+    u1 = ((r[:count] >> np.uint64(11)).astype(np.float64) + 1.0) / float((1 << 53) + 1)
+    u2 = (r[count:] >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+    return np.clip(np.rint(median * np.exp(sigma * z)), lo, hi).astype(np.int64)

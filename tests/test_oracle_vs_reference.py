@@ -1,0 +1,45 @@
+"""Live differential: C restatement vs the real reference (oracle/_ref/ref_driver).  Runs only
+where the reference build exists (this container); skipped on the GPU box."""
+import random
+
+import pytest
+
+from oracle import refproc as rp
+
+pytestmark = pytest.mark.skipif(not rp.available(), reason="oracle/_ref not built (no /root/reference)")
+
+
+def _rs(rng, n, alpha="ACGT"):
+    return "".join(rng.choice(alpha) for _ in range(n))
+
+
+def test_random_differential(oracle):
+    rng = random.Random(7)
+    cases = []
+    for t in range(600):
+        m = rng.choice([1, 2, 7, 31, 32, 33, 64, 96, 127, 128, 150])
+        n = rng.choice([1, 2, 7, 31, 32, 33, 64, 96, 127, 128, 150, 400])
+        if t % 5 == 0:
+            n = max(1, m + rng.choice([-1, 0, 1]))
+        y = _rs(rng, n)
+        x = y[:m] if (t % 3 == 0 and n >= m) else _rs(rng, m)
+        x = x + "A" * (m - len(x))
+        cases.append((x, y, t % 2, rng.choice([(3.0, -3.0, 2.0), (2.0, -1.0, 1.0), (7.0, -5.0, 3.0)])))
+
+    def go(idx):
+        try:
+            outs = rp.run([rp.align_cmd(cases[i][0], cases[i][1], cases[i][2], *cases[i][3]) for i in idx])
+        except RuntimeError:
+            if len(idx) == 1:       # reference aborts only on an all-zero matrix
+                x, y, sem, sc = cases[idx[0]]
+                assert oracle.align(x, y, sem, *sc)["score"] == 0
+                return
+            h = len(idx) // 2
+            go(idx[:h]); go(idx[h:])
+            return
+        for i, o in zip(idx, outs):
+            x, y, sem, sc = cases[i]
+            exp = rp.parse_align(o)
+            got = oracle.align(x, y, sem, *sc)
+            assert {k: got[k] for k in exp} == exp, (x, y, sem, sc)
+    go(list(range(len(cases))))
