@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the Smith-Waterman hot path on MI355X.
+
+Metric (BASELINE.json): GCUPS = sum |x_k|*|y| / t * 1e-9 for 150 bp synthetic reads against a 50 Mbp
+synthetic reference (configs[2], "100k x 150 bp vs 50 Mbp"), whole job: score pass + argmax +
+traceback + results on the host, inputs resident in HBM when the timed region starts.
+
+One "step" = one pass of the hot path over one batch of --reads reads per GPU (default 2048; the
+full 100 000-read set is 49 such batches — 7.5e14 cells — and the per-batch rate is size-normalised).
+Multi-GPU: one process per GPU (torch.distributed / RCCL), reads sharded across ranks, reference
+replicated, no data-path collective; one 8-byte all-reduce per step merges the per-rank best
+(score, read) — weak scaling.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (packed op = 1 lane-op)
+OPS_PER_CELL = {0: 2.4, 1: 2.9}  # VALU instructions per cell of sw_score_kernel<10,*>
+
+
+def load_package():
+    name = "parallel_genomeseq_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    path = os.path.join(ROOT, "parallel-genomeseq_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location(name, path, submodule_search_locations=[os.path.dirname(path)])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def cpu_baseline(pgs, ref, read_len, seconds_hint=20.0):
+    """The reference's own OpenMP path (oracle/_ref/ref_driver_omp = unmodified reference sources
+    behind our driver, src/sw_solve_big.cpp:78-92 loop) on this box's host cores, bounded sample.
+    Falls back to the oracle's scalar port when the reference build did not travel."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    sys.path.insert(0, ROOT)
+    from oracle import refproc
+    sub_len = min(len(ref), 5_000_000)
+    nreads = 48
+    sub = ref[:sub_len]
+    reads, _ = pgs.synth.fast_reads_from_ref(sub, 77, nreads, read_len)
+    if os.access(refproc.DRIVER_OMP, os.X_OK):
+        with tempfile.NamedTemporaryFile("wb", suffix=".txt", delete=False) as f:
+            f.write(sub.tobytes() + b"\n")
+            for r in reads:
+                f.write(r.tobytes() + b"\n")
+            path = f.name
+        env = dict(os.environ, OMP_PLACES="cores", OMP_PROC_BIND="close", OMP_DYNAMIC="false")
+        try:
+            t0 = time.time()
+            out = refproc.run(["bench %s %d 1" % (path, 2 * cores)], omp=True, env=env, timeout=600)[0].split()
+            wall = time.time() - t0
+        finally:
+            os.unlink(path)
+        kv = dict(zip(out[0::2], out[1::2]))
+        return {"value": float(kv["gcups_iterate"]), "unit": "GCUPS", "cores": cores, "kind": "reference",
+                "sample": "%d reads x %d bp vs first %d bp of the reference; OMPParallelLocalAligner<Skewed,SWAligner<Skewed>> "
+                          "with %d pieces, overlap 2.0, OMP_PLACES=cores OMP_PROC_BIND=close; value = reference's own metric "
+                          "(iterate() time only, sw_solve_big.cpp:92-99); end-to-end incl. matrix alloc/zero + winner re-run = %.3f GCUPS; %.1f s wall"
+                          % (nreads, read_len, sub_len, 2 * cores, float(kv["gcups_wall"]), wall)}
+    from oracle import binding as ob
+    n = min(len(ref), 2_000_000)
+    t0 = time.time()
+    for r in reads[:4]:
+        ob.score_only(r.tobytes(), ref[:n].tobytes(), ob.U8SAT)
+    dt = time.time() - t0
+    return {"value": 4 * read_len * n / dt * 1e-9, "unit": "GCUPS", "cores": 1, "kind": "port",
+            "sample": "4 reads x %d bp vs first %d bp, scalar uint8 score-only port (oracle/sw_oracle.c)" % (read_len, n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=2048, help="reads per GPU per step")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--ref-len", type=int, default=50_000_000)
+    ap.add_argument("--semantics", choices=["f32", "u8"], default="f32")
+    ap.add_argument("--score-only", action="store_true", help="skip the traceback (diagnostic; not the headline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    pgs = load_package()
+    sem = pgs.F32 if args.semantics == "f32" else pgs.U8SAT
+    ctx = pgs.Context(local_rank)
+    ref = pgs.synth.dna(3, args.ref_len)                                   # seed 3 (SURVEY §8d cfg 3)
+    reads, _ = pgs.synth.fast_reads_from_ref(ref, 4 + 7919 * rank, args.reads, args.read_len)
+    ctx.set_reference(ref)
+    ctx.batch_upload([r.tobytes() for r in reads])
+    flags = pgs.capi.SCORE_ONLY if args.score_only else 0
+    cells_per_step = float(args.reads) * args.read_len * args.ref_len
+
+    def step():
+        out = ctx.batch_run(semantics=sem, flags=flags, raw=True)
+        best = int(out["score"].max()) << 32 | (0xFFFFFFFF - (int(out["score"].argmax()) + rank * args.reads))
+        if dist is not None:
+            t = torch.tensor([best], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)                      # per-rank best (score, read) over xGMI
+            best = int(t.item())
+        return out, best
+
+    for _ in range(args.warmup):
+        step()
+    kern_us, kern_launches, locate_us, trace_us = 0.0, 0, 0.0, 0.0
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, best = step()
+        tm = ctx.last_timings()
+        kern_us += tm["score_us"]; kern_launches += tm["score_launches"]
+        locate_us += tm["locate_us"]; trace_us += tm["trace_us"]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_cells = cells_per_step * args.steps * world
+        gcups = total_cells / dt * 1e-9
+        avg_launch_s = kern_us / max(1, kern_launches) * 1e-6
+        alg_bytes = float(args.reads) * (args.read_len + args.ref_len + 16)   # |x|+|y|+16 per alignment
+        achieved = alg_bytes / avg_launch_s * 1e-9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("reads") == args.reads and rec.get("ref_len") == args.ref_len and rec.get("semantics") == args.semantics:
+                    traffic = rec["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        kern_cells_per_s = cells_per_step / avg_launch_s
+        line = {
+            "metric": "GCUPS (cell updates/s), 150 bp reads vs 50 Mbp reference, whole job (score + argmax + traceback)",
+            "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i16 (packed 2x16-bit cells; exact for the float32 engine's integer scores)" if sem == pgs.F32 else "u8 (saturating, held in packed 16-bit lanes)",
+            "data": "synthetic",
+            "config": {"workload": "configs[2]: %d x %d bp reads per GPU per step vs %d bp reference (one batch of the 100k-read set)"
+                                   % (args.reads, args.read_len, args.ref_len),
+                       "semantics": "Similarity_Matrix (float32)" if sem == pgs.F32 else "Similarity_Matrix_Skewed (uint8 saturating)",
+                       "reads_per_gpu_per_step": args.reads, "read_len": args.read_len, "ref_len": args.ref_len,
+                       "parallelism": "reads sharded x%d, reference replicated" % world, "score_only": bool(args.score_only)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "sw_score_kernel<R=%d>" % next(r for r in (2, 4, 6, 8, 10, 12, 16, 20, 24, 32) if r >= (args.read_len + 15) // 16),
+                         "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "scalar recurrence: VALU-bound, not HBM-bound (DESIGN.md §5); see valu"},
+            "valu": {"kernel_gcups": kern_cells_per_s * 1e-9, "lane_ops_per_cell": OPS_PER_CELL[sem],
+                     "achieved_lane_ops_per_s": kern_cells_per_s * OPS_PER_CELL[sem],
+                     "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                     "frac": kern_cells_per_s * OPS_PER_CELL[sem] / VALU_PEAK_LANE_OPS},
+            "phases_ms_per_step": {"score_kernel": kern_us / args.steps * 1e-3, "locate": locate_us / args.steps * 1e-3,
+                                   "traceback": trace_us / args.steps * 1e-3},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(pgs, ref, args.read_len)
+            except Exception as e:  # the baseline is reported, never required
+                line["cpu_baseline"] = {"value": None, "unit": "GCUPS", "cores": 0, "kind": "reference", "sample": "failed: %r" % (e,)}
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,140 @@
+/*
+ * mi355_sw.h — C-ABI of the MI355X (gfx950) Smith-Waterman engine.
+ *
+ * This is the drop-in boundary for the reference's hot path (kosta777/parallel-genomeseq):
+ * the entry points are what a binding of `SWAligner<SMT>::calculateScore()` and
+ * `OMPParallelLocalAligner<SMT,LAT>::calculateScore()` needs, with plain pointers and sizes.
+ * Reference interfaces replaced (paths relative to the reference root):
+ *
+ *   mi355_sw_align        SWAligner<SMT>::calculateScore + getScore/getPos/getConsensus_x/_y
+ *                         (src/aligner/smithwaterman.h:11-58, smithwaterman.cpp:80-108)
+ *   mi355_sw_align_batch  the loop of independent alignments in src/sw_solve_small.cpp:82-93,
+ *                         src/sw_solve_big.cpp:78-92, src/mpi_sw_solve_uniprot.cpp:95-138
+ *   mi355_sw_align_split  OMPParallelLocalAligner<SMT,LAT>::calculateScore
+ *                         (src/aligner/plocalaligner.h:6-33, plocalaligner.cpp:105-143)
+ *   mi355_sw_make_string_range   _make_string_range (plocalaligner.cpp:44-67)
+ *   mi355_sw_fill_matrix  Abstract_Similarity_Matrix::iterate + operator()(row,col)
+ *                         (src/aligner/similaritymatrix.h:13-24,45,76-79)
+ *   mi355_sw_argmax       Abstract_Similarity_Matrix::find_index_of_maximum
+ *                         (similaritymatrix.cpp:21-28, :291-299)
+ *
+ * Semantics: MI355_SW_F32 follows Similarity_Matrix (float cells, linear gap), MI355_SW_U8SAT
+ * follows Similarity_Matrix_Skewed (uint8 saturating cells; only f('A','A'), f('A','T') and the
+ * gap are used, similaritymatrix.cpp:389-392).  Argmax tie-breaks, the greedy traceback and the
+ * reversed consensus strings are those of the reference.
+ *
+ * Deliberate divergence: an all-zero matrix (no positive cell) is undefined behaviour in the
+ * reference (smithwaterman.cpp:46-48); here it yields score 0, pos 0, empty consensus.
+ *
+ * Ownership: inputs are caller-owned and only read during the call.  Output strings are
+ * library-owned (malloc) and released with mi355_sw_free_result(s).  One context per host
+ * thread / per GPU; a context is not thread-safe.  All functions return 0 on success or a
+ * negative MI355_SW_E* code; mi355_sw_last_error() gives the message.  There is NO CPU
+ * fallback: without a usable HIP device every compute entry point fails with MI355_SW_ENODEV.
+ */
+#ifndef MI355_SW_H_
+#define MI355_SW_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MI355_SW_F32 = 0, MI355_SW_U8SAT = 1 };
+
+enum {
+  MI355_SW_OK = 0,
+  MI355_SW_EINVAL = -22,   /* bad argument */
+  MI355_SW_ENOMEM = -12,   /* host or device allocation failed */
+  MI355_SW_ENODEV = -19,   /* no usable HIP device / HIP call failed */
+  MI355_SW_ENOTSUP = -95,  /* input outside what this build's kernels cover (message says what) */
+  MI355_SW_ERANGE = -34    /* the reference's own asserts would fire (plocalaligner.cpp:52,63,65) */
+};
+
+/* flags for mi355_sw_align_batch / mi355_sw_batch_run */
+enum {
+  MI355_SW_SCORE_ONLY = 1  /* score + argmax cell only: pos = 0, empty consensus */
+};
+
+typedef struct mi355_sw_ctx mi355_sw_ctx;
+
+typedef struct {
+  const float *lut;  /* 256x256 table, lut[(uint8)a*256 + (uint8)b] = f(a,b) with a from x, b from y;
+                        NULL => f(a,b) = (a == b ? match : mismatch)  (smithwaterman.cpp:8) */
+  float match;       /* reference default  3 */
+  float mismatch;    /* reference default -3 */
+  float gap;         /* gap_penalty, reference default 2 */
+  int semantics;     /* MI355_SW_F32 | MI355_SW_U8SAT */
+} mi355_sw_params;
+
+typedef struct {
+  float score;          /* getScore(): maximum cell value */
+  uint32_t pos;         /* getPos(): 1-based column of y where the traceback stopped */
+  int64_t end_x;        /* argmax row    (1-based index into x), 0 when score == 0 */
+  int64_t end_y;        /* argmax column (1-based index into y), 0 when score == 0 */
+  char *cons_x;         /* getConsensus_x(): reversed, '-' for gaps, NUL terminated */
+  char *cons_y;         /* getConsensus_y() */
+  size_t cons_len;
+  float timings_us[2];  /* getTimings(): [0] DP-fill device time of the call that produced this
+                           result (shared by all results of one batch), [1] sum over pieces */
+} mi355_sw_result;
+
+int mi355_sw_create(mi355_sw_ctx **ctx, int device);
+void mi355_sw_destroy(mi355_sw_ctx *ctx);
+const char *mi355_sw_last_error(const mi355_sw_ctx *ctx);
+void mi355_sw_default_params(mi355_sw_params *p); /* 3 / -3 / 2, F32, no table */
+
+/* One alignment of x (rows) against y (columns). */
+int mi355_sw_align(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, size_t ny,
+                   const mi355_sw_params *params, mi355_sw_result *out);
+
+/* Make y resident in HBM for subsequent batch calls (copied; caller may free y). */
+int mi355_sw_set_reference(mi355_sw_ctx *ctx, const char *y, size_t ny);
+
+/* n independent alignments of xs[k] (length nxs[k]) against the resident reference. */
+int mi355_sw_align_batch(mi355_sw_ctx *ctx, size_t n, const char *const *xs, const size_t *nxs,
+                         const mi355_sw_params *params, int flags, mi355_sw_result *outs);
+
+/* Same, with the queries made resident first so that a timed region can start with all inputs
+ * in HBM (bench.py).  mi355_sw_batch_run may be called repeatedly. */
+int mi355_sw_batch_upload(mi355_sw_ctx *ctx, size_t n, const char *const *xs, const size_t *nxs);
+int mi355_sw_batch_run(mi355_sw_ctx *ctx, const mi355_sw_params *params, int flags,
+                       mi355_sw_result *outs);
+
+/* OMPParallelLocalAligner: split y into npiece overlapping pieces, pick the first piece with the
+ * strictly greatest maximum under (params, sm_semantics), re-align it under la_semantics with
+ * DEFAULT scoring (plocalaligner.cpp:135), pos += left.  winning_piece may be NULL. */
+int mi355_sw_align_split(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, size_t ny,
+                         const mi355_sw_params *params, int sm_semantics, int la_semantics,
+                         int npiece, float overlap_ratio, mi355_sw_result *out, int *winning_piece);
+
+/* Host-only helper: piece ranges [left,right). Returns MI355_SW_ERANGE where the reference asserts. */
+int mi355_sw_make_string_range(int npiece, int64_t shortlen, int64_t longlen, float overlap_ratio,
+                               int64_t *lefts, int64_t *rights);
+
+/* Full matrix on the device, copied out as float, column-major over y:
+ * H[j*(nx+1) + i] = matrix(i, j), i = 0..nx, j = 0..ny.  For small problems (tests, operator()). */
+int mi355_sw_fill_matrix(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, size_t ny,
+                         const mi355_sw_params *params, float *H);
+
+/* find_index_of_maximum(): first maximum in the reference's storage order. */
+int mi355_sw_argmax(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, size_t ny,
+                    const mi355_sw_params *params, int64_t *index_x, int64_t *index_y, float *max);
+
+/* Device timings of the last batch/align call, microseconds (HIP events on the library's stream):
+ * [0] score kernel(s), [1] argmax rescan, [2] traceback window + walk, [3] whole call (device),
+ * [4] number of score-kernel launches, [5] cells swept by the score kernel(s). */
+int mi355_sw_last_timings(const mi355_sw_ctx *ctx, double out[6]);
+
+void mi355_sw_free_result(mi355_sw_result *r);
+void mi355_sw_free_results(mi355_sw_result *r, size_t n);
+
+/* Build information: "gfx950;..." */
+const char *mi355_sw_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_SW_H_ */

@@ -1,0 +1,198 @@
+"""ctypes binding of libmi355_sw.so (include/mi355_sw.h).  There is no CPU fallback: if the HIP
+library is missing, or no MI355X is visible, every compute call raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355_sw.so")
+
+F32, U8SAT = 0, 1
+SCORE_ONLY = 1
+
+EXPORTS = [
+    "mi355_sw_create", "mi355_sw_destroy", "mi355_sw_last_error", "mi355_sw_default_params",
+    "mi355_sw_align", "mi355_sw_set_reference", "mi355_sw_align_batch", "mi355_sw_batch_upload",
+    "mi355_sw_batch_run", "mi355_sw_align_split", "mi355_sw_make_string_range", "mi355_sw_fill_matrix",
+    "mi355_sw_argmax", "mi355_sw_last_timings", "mi355_sw_free_result", "mi355_sw_free_results",
+    "mi355_sw_build_info",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("lut", C.POINTER(C.c_float)), ("match", C.c_float), ("mismatch", C.c_float),
+                ("gap", C.c_float), ("semantics", C.c_int)]
+
+
+class Result(C.Structure):
+    _fields_ = [("score", C.c_float), ("pos", C.c_uint32), ("end_x", C.c_int64), ("end_y", C.c_int64),
+                ("cons_x", C.c_void_p), ("cons_y", C.c_void_p), ("cons_len", C.c_size_t),
+                ("timings_us", C.c_float * 2)]
+
+
+class MI355Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mi355_sw error %d: %s" % (code, msg))
+        self.code = code
+
+
+_LIB = None
+
+
+def lib():
+    """Load the HIP library; fail loudly when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libmi355_sw.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C parallel-genomeseq_amd/csrc`")
+        L = C.CDLL(LIB_PATH)
+        L.mi355_sw_last_error.restype = C.c_char_p
+        L.mi355_sw_build_info.restype = C.c_char_p
+        for name in EXPORTS:
+            getattr(L, name)
+        _LIB = L
+    return _LIB
+
+
+def make_params(semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None):
+    p = Params()
+    keep = None
+    if lut is not None:
+        keep = np.ascontiguousarray(lut, dtype=np.float32).reshape(65536)
+        p.lut = keep.ctypes.data_as(C.POINTER(C.c_float))
+    p.match, p.mismatch, p.gap, p.semantics = match, mismatch, gap, semantics
+    return p, keep
+
+
+def _bytes(s):
+    if isinstance(s, (bytes, bytearray)):
+        return bytes(s)
+    if isinstance(s, np.ndarray):
+        return s.astype(np.uint8).tobytes()
+    return s.encode("latin-1")
+
+
+def _take(r):
+    cx = C.string_at(r.cons_x, r.cons_len).decode("latin-1") if r.cons_len else ""
+    cy = C.string_at(r.cons_y, r.cons_len).decode("latin-1") if r.cons_len else ""
+    return dict(score=float(r.score), pos=int(r.pos), end_x=int(r.end_x), end_y=int(r.end_y),
+                cons_x=cx, cons_y=cy, timings_us=(float(r.timings_us[0]), float(r.timings_us[1])))
+
+
+class Context:
+    """One engine context = one GPU (mi355_sw_create)."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        self._ctx = C.c_void_p()
+        rc = self._L.mi355_sw_create(C.byref(self._ctx), C.c_int(device))
+        if rc:
+            raise MI355Error(rc, "mi355_sw_create failed (no usable HIP device %d?)" % device)
+        self.device = device
+
+    def close(self):
+        if self._ctx:
+            self._L.mi355_sw_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise MI355Error(rc, (self._L.mi355_sw_last_error(self._ctx) or b"").decode())
+
+    # -- single alignment ---------------------------------------------------------------------
+    def align(self, x, y, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None):
+        x, y = _bytes(x), _bytes(y)
+        p, keep = make_params(semantics, match, mismatch, gap, lut)
+        r = Result()
+        self._chk(self._L.mi355_sw_align(self._ctx, x, C.c_size_t(len(x)), y, C.c_size_t(len(y)), C.byref(p), C.byref(r)))
+        out = _take(r)
+        self._L.mi355_sw_free_result(C.byref(r))
+        return out
+
+    def argmax(self, x, y, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None):
+        x, y = _bytes(x), _bytes(y)
+        p, keep = make_params(semantics, match, mismatch, gap, lut)
+        ix, iy, mx = C.c_int64(), C.c_int64(), C.c_float()
+        self._chk(self._L.mi355_sw_argmax(self._ctx, x, C.c_size_t(len(x)), y, C.c_size_t(len(y)), C.byref(p),
+                                          C.byref(ix), C.byref(iy), C.byref(mx)))
+        return ix.value, iy.value, mx.value
+
+    def fill_matrix(self, x, y, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None):
+        x, y = _bytes(x), _bytes(y)
+        p, keep = make_params(semantics, match, mismatch, gap, lut)
+        H = np.zeros((len(y) + 1, len(x) + 1), dtype=np.float32)
+        self._chk(self._L.mi355_sw_fill_matrix(self._ctx, x, C.c_size_t(len(x)), y, C.c_size_t(len(y)), C.byref(p),
+                                               H.ctypes.data_as(C.POINTER(C.c_float))))
+        return H.T
+
+    def align_split(self, x, y, npiece, overlap_ratio, sm_semantics=F32, la_semantics=F32, match=3.0,
+                    mismatch=-3.0, gap=2.0, lut=None):
+        x, y = _bytes(x), _bytes(y)
+        p, keep = make_params(sm_semantics, match, mismatch, gap, lut)
+        r = Result()
+        piece = C.c_int(0)
+        self._chk(self._L.mi355_sw_align_split(self._ctx, x, C.c_size_t(len(x)), y, C.c_size_t(len(y)), C.byref(p),
+                                               C.c_int(sm_semantics), C.c_int(la_semantics), C.c_int(npiece),
+                                               C.c_float(overlap_ratio), C.byref(r), C.byref(piece)))
+        out = _take(r)
+        out["piece"] = piece.value
+        self._L.mi355_sw_free_result(C.byref(r))
+        return out
+
+    # -- batches ------------------------------------------------------------------------------
+    def set_reference(self, y):
+        y = _bytes(y)
+        self._chk(self._L.mi355_sw_set_reference(self._ctx, y, C.c_size_t(len(y))))
+        self._ref_len = len(y)
+
+    def batch_upload(self, xs):
+        xs = [_bytes(x) for x in xs]
+        n = len(xs)
+        arr = (C.c_char_p * n)(*xs)
+        lens = (C.c_size_t * n)(*[len(x) for x in xs])
+        self._chk(self._L.mi355_sw_batch_upload(self._ctx, C.c_size_t(n), arr, lens))
+        self._nbatch = n
+
+    def batch_run(self, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None, flags=0, raw=False):
+        p, keep = make_params(semantics, match, mismatch, gap, lut)
+        n = self._nbatch
+        res = (Result * n)()
+        self._chk(self._L.mi355_sw_batch_run(self._ctx, C.byref(p), C.c_int(flags), res))
+        if raw:
+            out = dict(score=np.array([r.score for r in res], dtype=np.float32),
+                       pos=np.array([r.pos for r in res], dtype=np.int64),
+                       end_x=np.array([r.end_x for r in res], dtype=np.int64),
+                       end_y=np.array([r.end_y for r in res], dtype=np.int64))
+        else:
+            out = [_take(r) for r in res]
+        self._L.mi355_sw_free_results(res, C.c_size_t(n))
+        return out
+
+    def align_batch(self, xs, y=None, **kw):
+        if y is not None:
+            self.set_reference(y)
+        self.batch_upload(xs)
+        return self.batch_run(**kw)
+
+    def last_timings(self):
+        t = (C.c_double * 6)()
+        self._L.mi355_sw_last_timings(self._ctx, t)
+        return dict(score_us=t[0], locate_us=t[1], trace_us=t[2], total_us=t[3], score_launches=int(t[4]), cells=t[5])
+
+
+def make_string_range(npiece, shortlen, longlen, ratio):
+    lefts = (C.c_int64 * max(1, npiece))()
+    rights = (C.c_int64 * max(1, npiece))()
+    rc = lib().mi355_sw_make_string_range(C.c_int(npiece), C.c_int64(shortlen), C.c_int64(longlen), C.c_float(ratio),
+                                          lefts, rights)
+    if rc:
+        return None
+    return [(int(lefts[k]), int(rights[k])) for k in range(npiece)]

@@ -1,0 +1,958 @@
+// mi355_sw.hip — host side of the C-ABI in include/mi355_sw.h (gfx950 only, no CPU fallback).
+//
+// Pipeline for every alignment:
+//   1. score pass      sw_score_kernel  — packed 16-bit wavefront sweep over (query pair x chunk)
+//                                         tiles, per-query (max, first chunk) by 64-bit atomicMax
+//   2. locate          sw_exact_kernel  — the tile(s) that can hold the first maximum in the
+//                                         reference's storage order -> argmax cell
+//   3. traceback       sw_exact_kernel  — window left of the argmax -> greedy decisions,
+//                      sw_walk_kernel   — the walk itself (smithwaterman.cpp:40-78)
+// Problems the score kernel does not cover (see fast_eligible) run 2+3 on the whole matrix.
+#include "../../include/mi355_sw.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sw_exact_kernel.h"
+#include "sw_score_kernel.h"
+
+using namespace mi355sw;
+
+namespace {
+
+constexpr int kMaxCodes = 48;                 // LDS profile budget: codes incl. pad
+constexpr int kMaxRowsFast = 512;             // 16 lanes x R <= 32 rows
+constexpr size_t kDirsBudget = 3ull << 30;    // bytes of traceback decisions per exact launch
+constexpr size_t kExactLdsMax = 160 * 1024;
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct RefData {
+  DevBuf bytes, codes;
+  size_t n = 0;
+  int ncodes = 0;                 // incl. pad
+  int code_of[256];
+  uint8_t byte_of[256];
+};
+
+struct QueryBatch {
+  DevBuf bytes, lens;
+  std::vector<int32_t> len;
+  std::vector<uint8_t> host;      // [nq][stride]
+  size_t nq = 0;
+  int stride = 0;
+  int maxlen = 0;
+};
+
+struct Range { int64_t lo, hi; };
+
+// One alignment's intermediate state on the host
+struct Located {
+  float score = 0;
+  int64_t ix = 0, iy = 0;         // argmax, iy relative to the range start (1-based)
+};
+
+}  // namespace
+
+struct mi355_sw_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {};
+  std::string err;
+  RefData ref;                    // resident reference (set_reference)
+  QueryBatch batch;               // resident queries (batch_upload)
+  // scratch
+  DevBuf keys, ranges, stab, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat;
+  double timings[6] = {0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                  \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+      return MI355_SW_ENODEV;                                                              \
+    }                                                                                      \
+  } while (0)
+
+int fail(mi355_sw_ctx *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+inline float lut_or(const mi355_sw_params &p, uint8_t a, uint8_t b) {
+  if (p.lut) return p.lut[(size_t)a * 256 + b];
+  return a == b ? p.match : p.mismatch;
+}
+
+// similaritymatrix.cpp:376-384
+inline int sat8(float a) { return a < 0 ? 0 : (a > 255 ? 255 : (int)(uint8_t)a); }
+
+struct U8Params { int M, X, G; };
+U8Params u8_params(const mi355_sw_params &p) {
+  return {sat8(lut_or(p, 'A', 'A')), sat8(-lut_or(p, 'A', 'T')), sat8(p.gap)};   // :389-392
+}
+
+// host twin of order_key<> (sw_exact_kernel.h)
+unsigned long long host_order_key(int sem, int64_t i, int64_t j, int64_t m, int64_t n) {
+  if (sem == MI355_SW_F32) return ((unsigned long long)j << 32) | (unsigned long long)i;
+  const int64_t len_x = n + 1, len_y = m + 1;
+  const int64_t nrows = std::min(len_x, len_y), ncols = std::max(len_x, len_y);
+  const int64_t ti = j, tj = i;
+  int64_t ri, rj;
+  if (ti + tj < nrows - 1) { ri = ti; rj = ti + tj; }
+  else if (ti + tj > ncols - 1) { ri = ti - ncols + len_y; rj = ti + tj - (ncols - 1) - 1; }
+  else { ri = (len_x <= len_y) ? ti : len_y - 1 - tj; rj = ti + tj; }
+  return ((unsigned long long)rj << 32) | (unsigned long long)ri;
+}
+
+int upload_reference(mi355_sw_ctx *ctx, RefData &r, const char *y, size_t ny) {
+  bool present[256] = {false};
+  const uint8_t *u = reinterpret_cast<const uint8_t *>(y);
+  for (size_t k = 0; k < ny; ++k) present[u[k]] = true;
+  int nc = 0;
+  for (int b = 0; b < 256; ++b) {
+    r.code_of[b] = -1;
+    if (present[b]) { r.code_of[b] = nc; r.byte_of[nc] = (uint8_t)b; ++nc; }
+  }
+  r.ncodes = nc + 1;   // + pad
+  r.n = ny;
+  if (r.bytes.ensure(ny + 64) || r.codes.ensure(ny + 64)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(reference) failed");
+  std::vector<uint8_t> codes(ny);
+  for (size_t k = 0; k < ny; ++k) codes[k] = (uint8_t)r.code_of[u[k]];
+  HIPCHK(ctx, hipMemcpyAsync(r.bytes.p, y, ny, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(r.codes.p, codes.data(), ny, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int upload_queries(mi355_sw_ctx *ctx, QueryBatch &q, size_t n, const char *const *xs, const size_t *nxs) {
+  q.nq = n;
+  q.len.resize(n);
+  size_t mx = 0;
+  for (size_t k = 0; k < n; ++k) {
+    if (nxs[k] > 0x3fffffff) return fail(ctx, MI355_SW_EINVAL, "query too long");
+    q.len[k] = (int32_t)nxs[k];
+    mx = std::max(mx, nxs[k]);
+  }
+  q.maxlen = (int)mx;
+  q.stride = (int)((mx + 15) / 16 * 16);
+  if (q.stride == 0) q.stride = 16;
+  q.host.assign((size_t)q.stride * n, 0);
+  for (size_t k = 0; k < n; ++k) memcpy(&q.host[(size_t)q.stride * k], xs[k], nxs[k]);
+  if (q.bytes.ensure(q.host.size() + 16) || q.lens.ensure(n * 4 + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(queries) failed");
+  HIPCHK(ctx, hipMemcpyAsync(q.bytes.p, q.host.data(), q.host.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(q.lens.p, q.len.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// ---- what the packed 16-bit score kernel covers --------------------------------------------
+struct FastPlan {
+  bool ok = false;
+  std::string why;
+  int R = 0;
+  int64_t warm = 0;          // exactness margin in columns
+  int gap = 0, smax = 0;
+  std::vector<int16_t> stab; // [256][ncodes]
+};
+
+int pick_R(int maxlen) {
+  static const int rs[] = {2, 4, 6, 8, 10, 12, 16, 20, 24, 32};
+  const int need = (maxlen + 15) / 16;
+  for (int r : rs) if (r >= need) return r;
+  return 0;
+}
+
+FastPlan plan_fast(const RefData &ref, const QueryBatch &q, const mi355_sw_params &p, int64_t max_range_len) {
+  FastPlan f;
+  if (ref.ncodes > kMaxCodes) { f.why = "reference alphabet larger than the LDS profile budget"; return f; }
+  if (q.maxlen > kMaxRowsFast || q.maxlen < 1) { f.why = "query longer than 512 rows (strip-mined kernel not built yet)"; return f; }
+  f.R = pick_R(q.maxlen);
+  const int nc = ref.ncodes;
+  f.stab.assign((size_t)256 * nc, (int16_t)kPadScore);
+  if (p.semantics == MI355_SW_U8SAT) {
+    const U8Params u = u8_params(p);
+    if (u.G < 1) { f.why = "gap penalty saturates to 0: no finite warm-up margin"; return f; }
+    for (int a = 0; a < 256; ++a)
+      for (int c = 0; c < nc - 1; ++c) f.stab[(size_t)a * nc + c] = (int16_t)((uint8_t)a == ref.byte_of[c] ? u.M : -u.X);
+    f.gap = u.G; f.smax = u.M;
+  } else {
+    const float g = p.gap;
+    if (!(g >= 1.0f) || g != std::floor(g) || g > 8000) { f.why = "gap penalty is not an integer >= 1"; return f; }
+    int smax = 0;
+    for (int a = 0; a < 256; ++a)
+      for (int c = 0; c < nc - 1; ++c) {
+        const float s = lut_or(p, (uint8_t)a, ref.byte_of[c]);
+        if (s != std::floor(s) || std::fabs(s) > 8000) { f.why = "substitution scores are not small integers"; return f; }
+        f.stab[(size_t)a * nc + c] = (int16_t)s;
+        // only bytes that occur in some query matter for the bound, but 256 x nc is cheap
+        smax = std::max(smax, (int)s);
+      }
+    f.gap = (int)g; f.smax = smax;
+    const int64_t rows = q.maxlen;
+    const int64_t bound = (int64_t)smax * std::min<int64_t>(rows, std::max<int64_t>(max_range_len, 1));
+    if (bound + smax > 32000) { f.why = "score bound exceeds the 16-bit cell range"; return f; }
+  }
+  if (f.smax <= 0) { f.warm = 0; }
+  else {
+    // any positive-scoring path ending in a column spans < m + smax*m/gap columns
+    const int64_t m = q.maxlen;
+    f.warm = m + ((int64_t)f.smax * m + f.gap - 1) / f.gap;
+  }
+  f.warm = (f.warm + 3) / 4 * 4;
+  f.ok = true;
+  return f;
+}
+
+template <int SEM>
+int launch_score_R(int R, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
+  switch (R) {
+#define CASE_R(r) case r: hipLaunchKernelGGL((sw_score_kernel<r, SEM>), grid, dim3(256), shmem, st, a); return 0;
+    CASE_R(2) CASE_R(4) CASE_R(6) CASE_R(8) CASE_R(10) CASE_R(12) CASE_R(16) CASE_R(20) CASE_R(24) CASE_R(32)
+#undef CASE_R
+  }
+  return -1;
+}
+
+int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm) {
+  int64_t cl = 16384;
+  // fill the chip: 256 CUs x 32 waves x 4 slots; shrink tiles while they stay >> warm-up
+  while (cl > 2048 && cl / 2 >= 4 * warm &&
+         (double)npairs * (double)((max_range_len + cl - 1) / cl) < 65536.0) cl /= 2;
+  return cl;
+}
+
+struct ScoreOut {
+  std::vector<unsigned long long> keys;   // [nranges][nq]
+  int64_t chunk_len = 0;
+  int64_t warm = 0;
+};
+
+// Score pass over all (query, range) pairs.  Device time is added to ctx->timings[0].
+int score_pass(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const std::vector<Range> &ranges,
+               const mi355_sw_params &p, const FastPlan &plan, ScoreOut &out) {
+  const size_t nq = q.nq, nr = ranges.size();
+  int64_t maxlen = 0;
+  for (auto &r : ranges) maxlen = std::max(maxlen, r.hi - r.lo);
+  const size_t npairs = (nq + 1) / 2;
+  out.warm = plan.warm;
+  out.chunk_len = pick_chunk_len(maxlen, npairs * nr, plan.warm);
+  const int64_t cpr = (maxlen + out.chunk_len - 1) / out.chunk_len;
+  const int64_t cgroups = (cpr + 15) / 16;
+  if ((double)npairs * (double)cgroups > 2.0e9 || nr > 65535) return fail(ctx, MI355_SW_ENOTSUP, "grid too large");
+
+  std::vector<int64_t> rl(2 * nr);
+  for (size_t k = 0; k < nr; ++k) { rl[k] = ranges[k].lo; rl[nr + k] = ranges[k].hi; }
+  if (ctx->ranges.ensure(rl.size() * 8) || ctx->keys.ensure(nq * nr * 8) || ctx->stab.ensure(plan.stab.size() * 2))
+    return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
+  HIPCHK(ctx, hipMemcpyAsync(ctx->ranges.p, rl.data(), rl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->stab.p, plan.stab.data(), plan.stab.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, nq * nr * 8, ctx->stream));
+
+  ScoreArgs a;
+  a.refcodes = ref.codes.as<uint8_t>();
+  a.ref_len = (int64_t)ref.n;
+  a.range_lo = ctx->ranges.as<int64_t>();
+  a.range_hi = ctx->ranges.as<int64_t>() + nr;
+  a.chunk_len = out.chunk_len;
+  a.warm = plan.warm;
+  a.chunks_per_range = (int)cpr;
+  a.qbytes = q.bytes.as<uint8_t>();
+  a.qlen = q.lens.as<int32_t>();
+  a.qstride = q.stride;
+  a.nq = (int)nq;
+  a.stab = ctx->stab.as<int16_t>();
+  a.ncodes = ref.ncodes;
+  a.gap2 = (uint32_t)plan.gap * 0x00010001u;
+  a.clamp2 = 255u * 0x00010001u;
+  a.keys = ctx->keys.as<unsigned long long>();
+
+  const int LS = lane_stride(plan.R);
+  const size_t shmem = (size_t)ref.ncodes * kSlotLanes * LS * 4 + 16 * kCodeBuf;
+  dim3 grid((unsigned)(npairs * cgroups), (unsigned)nr);
+  HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  int rc = (p.semantics == MI355_SW_U8SAT) ? launch_score_R<kSemU8>(plan.R, grid, shmem, ctx->stream, a)
+                                           : launch_score_R<kSemI16>(plan.R, grid, shmem, ctx->stream, a);
+  if (rc) return fail(ctx, MI355_SW_ENOTSUP, "no score kernel instance for this R");
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  out.keys.resize(nq * nr);
+  HIPCHK(ctx, hipMemcpyAsync(out.keys.data(), ctx->keys.p, nq * nr * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+  ctx->timings[0] += (double)ms * 1000.0;
+  ctx->timings[4] += 1;
+  double cells = 0;
+  for (size_t k = 0; k < nq; ++k)
+    for (auto &r : ranges) cells += (double)q.len[k] * (double)(r.hi - r.lo);
+  ctx->timings[5] += cells;
+  return 0;
+}
+
+// ---- exact kernel launches ------------------------------------------------------------------
+struct ExactJob {
+  int q;                 // query index in the batch
+  int64_t ylo;           // window start (absolute reference index of local column 1)
+  int32_t nw;
+  int64_t col_offset;    // true (range-relative) column = col_offset + jl
+  int64_t full_n;
+  int32_t own_lo;
+  int32_t quirk;
+  float target;
+  bool want_dirs;
+  // results
+  float best = -1;
+  int64_t ci = 0, cj = 0;
+  size_t dirs_off = 0;
+};
+
+size_t exact_lds_bytes(int m, int nw) { return (size_t)3 * (std::min(m, nw) + 2) * 4 + (size_t)m + 16; }
+
+ExactScoring make_scoring(mi355_sw_ctx *ctx, const mi355_sw_params &p, bool &lut_uploaded, int &rc) {
+  ExactScoring s;
+  rc = 0;
+  s.lut = nullptr;
+  if (p.lut && p.semantics == MI355_SW_F32) {
+    if (!lut_uploaded) {
+      if (ctx->lut.ensure(65536 * 4)) { rc = MI355_SW_ENOMEM; return s; }
+      if (hipMemcpyAsync(ctx->lut.p, p.lut, 65536 * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = MI355_SW_ENODEV; return s; }
+      lut_uploaded = true;
+    }
+    s.lut = ctx->lut.as<float>();
+  }
+  s.match = p.match; s.mismatch = p.mismatch; s.gap = p.gap;
+  const U8Params u = u8_params(p);
+  s.u8M = u.M; s.u8X = u.X; s.u8G = u.G;
+  return s;
+}
+
+// Runs jobs[lo,hi) in one launch.  Decisions (if wanted) land in ctx->dirs at job.dirs_off.
+int run_exact(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const mi355_sw_params &p,
+              std::vector<ExactJob> &jobs, size_t lo, size_t hi, float *hout /* device or null, single job */) {
+  const size_t n = hi - lo;
+  if (n == 0) return 0;
+  size_t dirs_total = 0, lds = 0;
+  for (size_t k = lo; k < hi; ++k) {
+    ExactJob &j = jobs[k];
+    lds = std::max(lds, exact_lds_bytes(q.len[j.q], j.nw));
+    if (j.want_dirs) { j.dirs_off = dirs_total; dirs_total += ((size_t)j.nw + 1) * ((size_t)q.len[j.q] + 1); dirs_total = (dirs_total + 15) & ~(size_t)15; }
+  }
+  if (lds > kExactLdsMax) return fail(ctx, MI355_SW_ENOTSUP, "anti-diagonal longer than the exact kernel's LDS window");
+  if (ctx->probs.ensure(n * sizeof(ExactProblem)) || ctx->outs_f.ensure(n * 4) || ctx->outs_i.ensure(n * 16) ||
+      (dirs_total && ctx->dirs.ensure(dirs_total)))
+    return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(exact scratch) failed");
+  std::vector<ExactProblem> pr(n);
+  for (size_t k = 0; k < n; ++k) {
+    const ExactJob &j = jobs[lo + k];
+    ExactProblem &e = pr[k];
+    e.x = q.bytes.as<uint8_t>() + (size_t)j.q * q.stride;
+    e.y = ref.bytes.as<uint8_t>() + j.ylo;
+    e.m = q.len[j.q];
+    e.nw = j.nw;
+    e.col_offset = j.col_offset;
+    e.full_n = j.full_n;
+    e.own_lo = j.own_lo;
+    e.square_quirk = j.quirk;
+    e.target = j.target;
+    e.dirs = j.want_dirs ? ctx->dirs.as<uint8_t>() + j.dirs_off : nullptr;
+    e.hout = hout;
+    e.best = ctx->outs_f.as<float>() + k;
+    e.cell = ctx->outs_i.as<int64_t>() + 2 * k;
+  }
+  HIPCHK(ctx, hipMemcpyAsync(ctx->probs.p, pr.data(), n * sizeof(ExactProblem), hipMemcpyHostToDevice, ctx->stream));
+  bool lut_up = false;
+  int rc = 0;
+  const ExactScoring sc = make_scoring(ctx, p, lut_up, rc);
+  if (rc) return fail(ctx, rc, "scoring table upload failed");
+  if (p.semantics == MI355_SW_U8SAT)
+    hipLaunchKernelGGL((sw_exact_kernel<1>), dim3((unsigned)n), dim3(64), lds, ctx->stream, ctx->probs.as<ExactProblem>(), sc);
+  else
+    hipLaunchKernelGGL((sw_exact_kernel<0>), dim3((unsigned)n), dim3(64), lds, ctx->stream, ctx->probs.as<ExactProblem>(), sc);
+  HIPCHK(ctx, hipGetLastError());
+  std::vector<float> bf(n);
+  std::vector<int64_t> ci(2 * n);
+  HIPCHK(ctx, hipMemcpyAsync(bf.data(), ctx->outs_f.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ci.data(), ctx->outs_i.p, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t k = 0; k < n; ++k) { jobs[lo + k].best = bf[k]; jobs[lo + k].ci = ci[2 * k]; jobs[lo + k].cj = ci[2 * k + 1]; }
+  return 0;
+}
+
+struct TraceOut {
+  std::string cx, cy;
+  uint32_t pos = 0;
+};
+
+// Walk over decisions of jobs[lo,hi) (all with want_dirs), starting at (start_i, local nw...).
+int run_walk(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const std::vector<ExactJob> &jobs,
+             size_t lo, size_t hi, const std::vector<std::pair<int32_t, int32_t>> &starts,
+             const std::vector<int32_t> &exact_lo, std::vector<TraceOut> &outs, std::vector<int> &status) {
+  const size_t n = hi - lo;
+  if (n == 0) return 0;
+  std::vector<WalkProblem> wp(n);
+  std::vector<size_t> coff(n);
+  size_t ctot = 0;
+  for (size_t k = 0; k < n; ++k) {
+    const ExactJob &j = jobs[lo + k];
+    const int cap = q.len[j.q] + j.nw + 2;
+    coff[k] = ctot;
+    ctot += 2 * (size_t)cap;
+  }
+  if (ctx->cons.ensure(ctot + 16) || ctx->walkp.ensure(n * sizeof(WalkProblem) + n * 24))
+    return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(walk scratch) failed");
+  int64_t *wout = reinterpret_cast<int64_t *>(ctx->walkp.as<uint8_t>() + n * sizeof(WalkProblem));
+  for (size_t k = 0; k < n; ++k) {
+    const ExactJob &j = jobs[lo + k];
+    WalkProblem &w = wp[k];
+    const int cap = q.len[j.q] + j.nw + 2;
+    w.x = q.bytes.as<uint8_t>() + (size_t)j.q * q.stride;
+    w.y = ref.bytes.as<uint8_t>() + j.ylo;
+    w.dirs = ctx->dirs.as<uint8_t>() + j.dirs_off;
+    w.m = q.len[j.q]; w.nw = j.nw;
+    w.start_i = starts[k].first; w.start_jl = starts[k].second;
+    w.exact_lo = exact_lo[k];
+    w.col_offset = j.col_offset;
+    w.cons_x = ctx->cons.as<char>() + coff[k];
+    w.cons_y = w.cons_x + cap;
+    w.cap = cap;
+    w.out = wout + 3 * k;
+  }
+  HIPCHK(ctx, hipMemcpyAsync(ctx->walkp.p, wp.data(), n * sizeof(WalkProblem), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(sw_walk_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, ctx->walkp.as<WalkProblem>(), (int)n);
+  HIPCHK(ctx, hipGetLastError());
+  std::vector<int64_t> wo(3 * n);
+  std::vector<char> cons(ctot);
+  HIPCHK(ctx, hipMemcpyAsync(wo.data(), wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(cons.data(), ctx->cons.p, ctot, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  outs.resize(n); status.resize(n);
+  for (size_t k = 0; k < n; ++k) {
+    const ExactJob &j = jobs[lo + k];
+    const int cap = q.len[j.q] + j.nw + 2;
+    status[k] = (int)wo[3 * k + 2];
+    const size_t len = (size_t)wo[3 * k];
+    outs[k].cx.assign(cons.data() + coff[k], len);
+    outs[k].cy.assign(cons.data() + coff[k] + cap, len);
+    outs[k].pos = (uint32_t)wo[3 * k + 1];
+  }
+  return 0;
+}
+
+void set_result(mi355_sw_result &r, float score, int64_t ix, int64_t iy, const TraceOut *t) {
+  r.score = score;
+  r.end_x = score > 0 ? ix : 0;
+  r.end_y = score > 0 ? iy : 0;
+  r.pos = t ? t->pos : 0;
+  const std::string empty;
+  const std::string &cx = t ? t->cx : empty, &cy = t ? t->cy : empty;
+  r.cons_len = cx.size();
+  r.cons_x = (char *)malloc(cx.size() + 1);
+  r.cons_y = (char *)malloc(cy.size() + 1);
+  memcpy(r.cons_x, cx.data(), cx.size()); r.cons_x[cx.size()] = 0;
+  memcpy(r.cons_y, cy.data(), cy.size()); r.cons_y[cy.size()] = 0;
+}
+
+// Traceback for located alignments of one range: windows left of the argmax, grown on demand.
+int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
+                  const mi355_sw_params &p, int64_t warm, bool whole_matrix_ok,
+                  const std::vector<int> &qidx, const std::vector<Located> &loc, std::vector<TraceOut> &tout) {
+  tout.assign(qidx.size(), TraceOut());
+  std::vector<size_t> todo;
+  for (size_t k = 0; k < qidx.size(); ++k) if (loc[k].score > 0) todo.push_back(k);
+  std::vector<int64_t> budget(qidx.size());
+  for (size_t k : todo) budget[k] = 2 * (int64_t)q.len[qidx[k]] + 64;
+  (void)whole_matrix_ok;
+  while (!todo.empty()) {
+    // build jobs in memory-bounded groups
+    std::vector<size_t> next;
+    size_t pos = 0;
+    while (pos < todo.size()) {
+      std::vector<ExactJob> jobs;
+      std::vector<size_t> owner;
+      std::vector<std::pair<int32_t, int32_t>> starts;
+      std::vector<int32_t> exlo;
+      size_t bytes = 0;
+      while (pos < todo.size()) {
+        const size_t k = todo[pos];
+        const int qi = qidx[k];
+        const int64_t iy = loc[k].iy;
+        int64_t wl = iy - (budget[k] + warm);           // range-relative 0-based start of window
+        if (wl < 0) wl = 0;
+        const int64_t nw = iy - wl;
+        const size_t need = ((size_t)nw + 1) * ((size_t)q.len[qi] + 1) + 16;
+        if (need > kDirsBudget) return fail(ctx, MI355_SW_ENOTSUP, "traceback window exceeds the device scratch budget");
+        if (!jobs.empty() && bytes + need > kDirsBudget) break;
+        ExactJob j;
+        j.q = qi; j.ylo = rg.lo + wl; j.nw = (int32_t)nw; j.col_offset = wl; j.full_n = rg.hi - rg.lo;
+        j.own_lo = (int32_t)(nw + 1);                   // nothing competes: decisions only
+        j.quirk = 0;                                    // |x| == |y| never reaches the score path (range_fast_ok)
+        j.target = 1e30f; j.want_dirs = true;
+        jobs.push_back(j); owner.push_back(k);
+        starts.emplace_back((int32_t)loc[k].ix, (int32_t)nw);
+        exlo.push_back(wl == 0 ? 0 : (int32_t)warm);
+        bytes += need;
+        ++pos;
+      }
+      int rc = run_exact(ctx, ref, q, p, jobs, 0, jobs.size(), nullptr);
+      if (rc) return rc;
+      std::vector<TraceOut> outs;
+      std::vector<int> st;
+      rc = run_walk(ctx, ref, q, jobs, 0, jobs.size(), starts, exlo, outs, st);
+      if (rc) return rc;
+      for (size_t t = 0; t < jobs.size(); ++t) {
+        const size_t k = owner[t];
+        if (st[t] == 0) tout[k] = outs[t];
+        else if (st[t] == 1) { budget[k] *= 4; next.push_back(k); }
+        else return fail(ctx, MI355_SW_ENOTSUP, "consensus longer than |x| + window");
+      }
+    }
+    todo.swap(next);
+  }
+  return 0;
+}
+
+// Whole-matrix path (exact kernel only) for the listed queries over one range.
+int exact_full(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
+               const mi355_sw_params &p, const std::vector<int> &qidx, bool want_trace,
+               std::vector<Located> &loc, std::vector<TraceOut> &tout) {
+  const int64_t n = rg.hi - rg.lo;
+  loc.assign(qidx.size(), Located());
+  tout.assign(qidx.size(), TraceOut());
+  size_t pos = 0;
+  while (pos < qidx.size()) {
+    std::vector<ExactJob> jobs;
+    std::vector<size_t> owner;
+    size_t bytes = 0;
+    while (pos < qidx.size()) {
+      const int qi = qidx[pos];
+      const size_t need = ((size_t)n + 1) * ((size_t)q.len[qi] + 1) + 16;
+      if (want_trace && need > kDirsBudget) return fail(ctx, MI355_SW_ENOTSUP, "problem needs the score kernel but is outside its coverage");
+      if (!jobs.empty() && want_trace && bytes + need > kDirsBudget) break;
+      if (jobs.size() >= 65536) break;
+      ExactJob j;
+      j.q = qi; j.ylo = rg.lo; j.nw = (int32_t)n; j.col_offset = 0; j.full_n = n; j.own_lo = 1;
+      j.quirk = (p.semantics == MI355_SW_U8SAT && q.len[qi] == n) ? 1 : 0;
+      j.target = -1.0f; j.want_dirs = want_trace;
+      jobs.push_back(j); owner.push_back(pos);
+      bytes += need;
+      ++pos;
+    }
+    int rc = run_exact(ctx, ref, q, p, jobs, 0, jobs.size(), nullptr);
+    if (rc) return rc;
+    std::vector<std::pair<int32_t, int32_t>> starts;
+    std::vector<int32_t> exlo(jobs.size(), 0);
+    for (size_t t = 0; t < jobs.size(); ++t) {
+      Located &L = loc[owner[t]];
+      L.score = jobs[t].best > 0 ? jobs[t].best : 0;
+      L.ix = jobs[t].ci; L.iy = jobs[t].cj;
+      starts.emplace_back(L.score > 0 ? (int32_t)L.ix : 0, L.score > 0 ? (int32_t)L.iy : 0);
+    }
+    if (want_trace) {
+      std::vector<TraceOut> outs;
+      std::vector<int> st;
+      rc = run_walk(ctx, ref, q, jobs, 0, jobs.size(), starts, exlo, outs, st);
+      if (rc) return rc;
+      for (size_t t = 0; t < jobs.size(); ++t) {
+        if (st[t] != 0) return fail(ctx, MI355_SW_ENOTSUP, "traceback walk failed on a whole-matrix window");
+        tout[owner[t]] = outs[t];
+      }
+    }
+  }
+  return 0;
+}
+
+bool range_fast_ok(const FastPlan &plan, const QueryBatch &q, const Range &rg, const mi355_sw_params &p) {
+  if (!plan.ok) return false;
+  const int64_t n = rg.hi - rg.lo;
+  if (n < 1) return false;
+  // the uint8 engine's storage order is only bounded to a few tiles when the reference is the
+  // longer side; shorter references take the whole-matrix path (which also holds the |x|==|y| quirk)
+  if (p.semantics == MI355_SW_U8SAT && n <= (int64_t)q.maxlen + 1) return false;
+  return true;
+}
+
+// Argmax cells for every query of the batch over one range, from the score pass' keys.
+int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
+                const mi355_sw_params &p, const ScoreOut &so, const unsigned long long *keys,
+                std::vector<Located> &loc) {
+  const size_t nq = q.nq;
+  const int64_t n = rg.hi - rg.lo;
+  const int64_t nchunks = (n + so.chunk_len - 1) / so.chunk_len;
+  loc.assign(nq, Located());
+  std::vector<ExactJob> jobs;
+  for (size_t k = 0; k < nq; ++k) {
+    const unsigned long long key = keys[k];
+    const int score = (int)(key >> 32);
+    if (score <= 0) continue;
+    const int64_t first = (int64_t)(0xFFFFFFFFull - (key & 0xFFFFFFFFull));
+    loc[k].score = (float)score;
+    int64_t cand[5];
+    int nc = 0;
+    cand[nc++] = first;
+    if (p.semantics == MI355_SW_U8SAT) {
+      // storage order = anti-diagonal (mod ncols): the first maximum lies in the first tile that
+      // reached the maximum or the next one, or in the corner triangles (first / last two tiles)
+      const int64_t extra[4] = {first + 1, 0, nchunks - 2, nchunks - 1};
+      for (int64_t c : extra) {
+        if (c < 0 || c >= nchunks) continue;
+        bool dup = false;
+        for (int t = 0; t < nc; ++t) dup |= cand[t] == c;
+        if (!dup) cand[nc++] = c;
+      }
+    }
+    for (int t = 0; t < nc; ++t) {
+      const int64_t own_lo = cand[t] * so.chunk_len;               // range-relative, 0-based
+      const int64_t own_hi = std::min(own_lo + so.chunk_len, n);
+      const int64_t wl = std::max<int64_t>(0, own_lo - so.warm);
+      ExactJob j;
+      j.q = (int)k; j.ylo = rg.lo + wl; j.nw = (int32_t)(own_hi - wl); j.col_offset = wl; j.full_n = n;
+      j.own_lo = (int32_t)(own_lo - wl + 1); j.quirk = 0; j.target = (float)score; j.want_dirs = false;
+      jobs.push_back(j);
+    }
+  }
+  for (size_t lo = 0; lo < jobs.size(); lo += 65536) {
+    int rc = run_exact(ctx, ref, q, p, jobs, lo, std::min(jobs.size(), lo + 65536), nullptr);
+    if (rc) return rc;
+  }
+  std::vector<unsigned long long> bestkey(nq, ~0ull);
+  for (const ExactJob &j : jobs) {
+    if (j.best != j.target) continue;
+    const unsigned long long kk = host_order_key(p.semantics, j.ci, j.cj, q.len[j.q], n);
+    if (kk < bestkey[j.q]) { bestkey[j.q] = kk; loc[j.q].ix = j.ci; loc[j.q].iy = j.cj; }
+  }
+  for (size_t k = 0; k < nq; ++k)
+    if (loc[k].score > 0 && bestkey[k] == ~0ull)
+      return fail(ctx, MI355_SW_ENODEV, "internal: maximum of the score pass not found again by the exact kernel");
+  return 0;
+}
+
+// All queries of `q` against one range of the reference.
+int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
+                const mi355_sw_params &p, int flags, mi355_sw_result *outs) {
+  const bool want_trace = !(flags & MI355_SW_SCORE_ONLY);
+  const size_t nq = q.nq;
+  HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  std::vector<Located> loc;
+  std::vector<TraceOut> tout;
+  FastPlan plan = plan_fast(ref, q, p, rg.hi - rg.lo);
+  std::vector<int> all(nq);
+  for (size_t k = 0; k < nq; ++k) all[k] = (int)k;
+  if (rg.hi - rg.lo < 1) {
+    loc.assign(nq, Located()); tout.assign(nq, TraceOut());
+  } else if (range_fast_ok(plan, q, rg, p)) {
+    ScoreOut so;
+    int rc = score_pass(ctx, ref, q, std::vector<Range>{rg}, p, plan, so);
+    if (rc) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    rc = locate_fast(ctx, ref, q, rg, p, so, so.keys.data(), loc);
+    if (rc) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev[3]));
+    float ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+    ctx->timings[1] += (double)ms * 1000.0;
+    if (want_trace) {
+      HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+      rc = trace_located(ctx, ref, q, rg, p, so.warm, true, all, loc, tout);
+      if (rc) return rc;
+      HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+      HIPCHK(ctx, hipEventSynchronize(ctx->ev[3]));
+      HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+      ctx->timings[2] += (double)ms * 1000.0;
+    } else tout.assign(nq, TraceOut());
+  } else {
+    HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    int rc = exact_full(ctx, ref, q, rg, p, all, want_trace, loc, tout);
+    if (rc) { if (!plan.ok && ctx->err.find("outside its coverage") != std::string::npos) ctx->err += " (" + plan.why + ")"; return rc; }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev[3]));
+    float ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+    ctx->timings[2] += (double)ms * 1000.0;
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+  HIPCHK(ctx, hipEventSynchronize(ctx->ev[5]));
+  float ms = 0;
+  HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
+  ctx->timings[3] += (double)ms * 1000.0;
+  for (size_t k = 0; k < nq; ++k) {
+    set_result(outs[k], loc[k].score, loc[k].ix, loc[k].iy, (want_trace && loc[k].score > 0) ? &tout[k] : nullptr);
+    outs[k].timings_us[0] = (float)(ctx->timings[0] > 0 ? ctx->timings[0] : ctx->timings[3]);
+    outs[k].timings_us[1] = 0;
+  }
+  return 0;
+}
+
+int check_params(mi355_sw_ctx *ctx, const mi355_sw_params *p) {
+  if (!ctx) return MI355_SW_EINVAL;
+  if (!p) return fail(ctx, MI355_SW_EINVAL, "params is NULL");
+  if (p->semantics != MI355_SW_F32 && p->semantics != MI355_SW_U8SAT) return fail(ctx, MI355_SW_EINVAL, "unknown semantics");
+  return 0;
+}
+
+void reset_timings(mi355_sw_ctx *ctx) { for (double &t : ctx->timings) t = 0; }
+
+}  // namespace
+
+// ================================= C-ABI ======================================================
+extern "C" {
+
+const char *mi355_sw_build_info(void) { return "mi355_sw gfx950 hip; score kernel R={2,4,6,8,10,12,16,20,24,32} x {i16,u8sat}"; }
+
+void mi355_sw_default_params(mi355_sw_params *p) {
+  if (!p) return;
+  p->lut = nullptr; p->match = 3.0f; p->mismatch = -3.0f; p->gap = 2.0f; p->semantics = MI355_SW_F32;
+}
+
+int mi355_sw_create(mi355_sw_ctx **out, int device) {
+  if (!out) return MI355_SW_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return MI355_SW_ENODEV;
+  if (hipSetDevice(device) != hipSuccess) return MI355_SW_ENODEV;
+  mi355_sw_ctx *c = new (std::nothrow) mi355_sw_ctx();
+  if (!c) return MI355_SW_ENOMEM;
+  c->device = device;
+  if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return MI355_SW_ENODEV; }
+  for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return MI355_SW_ENODEV; }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_exact_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kExactLdsMax);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_exact_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kExactLdsMax);
+  *out = c;
+  return 0;
+}
+
+void mi355_sw_destroy(mi355_sw_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  DevBuf *bufs[] = {&c->ref.bytes, &c->ref.codes, &c->batch.bytes, &c->batch.lens, &c->keys, &c->ranges, &c->stab,
+                    &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat};
+  for (DevBuf *b : bufs) b->release();
+  for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *mi355_sw_last_error(const mi355_sw_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int mi355_sw_set_reference(mi355_sw_ctx *ctx, const char *y, size_t ny) {
+  if (!ctx || (!y && ny)) return MI355_SW_EINVAL;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return upload_reference(ctx, ctx->ref, y, ny);
+}
+
+int mi355_sw_batch_upload(mi355_sw_ctx *ctx, size_t n, const char *const *xs, const size_t *nxs) {
+  if (!ctx || !xs || !nxs) return MI355_SW_EINVAL;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return upload_queries(ctx, ctx->batch, n, xs, nxs);
+}
+
+int mi355_sw_batch_run(mi355_sw_ctx *ctx, const mi355_sw_params *params, int flags, mi355_sw_result *outs) {
+  int rc = check_params(ctx, params);
+  if (rc) return rc;
+  if (!outs) return fail(ctx, MI355_SW_EINVAL, "outs is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  reset_timings(ctx);
+  if (ctx->batch.nq == 0) return 0;
+  return align_range(ctx, ctx->ref, ctx->batch, Range{0, (int64_t)ctx->ref.n}, *params, flags, outs);
+}
+
+int mi355_sw_align_batch(mi355_sw_ctx *ctx, size_t n, const char *const *xs, const size_t *nxs,
+                         const mi355_sw_params *params, int flags, mi355_sw_result *outs) {
+  int rc = check_params(ctx, params);
+  if (rc) return rc;
+  rc = mi355_sw_batch_upload(ctx, n, xs, nxs);
+  if (rc) return rc;
+  return mi355_sw_batch_run(ctx, params, flags, outs);
+}
+
+int mi355_sw_align(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, size_t ny,
+                   const mi355_sw_params *params, mi355_sw_result *out) {
+  int rc = check_params(ctx, params);
+  if (rc) return rc;
+  if (!out || (!x && nx) || (!y && ny)) return fail(ctx, MI355_SW_EINVAL, "null argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  reset_timings(ctx);
+  RefData ref;
+  QueryBatch q;
+  rc = upload_reference(ctx, ref, y, ny);
+  if (!rc) rc = upload_queries(ctx, q, 1, &x, &nx);
+  if (!rc) rc = align_range(ctx, ref, q, Range{0, (int64_t)ny}, *params, 0, out);
+  ref.bytes.release(); ref.codes.release(); q.bytes.release(); q.lens.release();
+  return rc;
+}
+
+int mi355_sw_argmax(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, size_t ny,
+                    const mi355_sw_params *params, int64_t *index_x, int64_t *index_y, float *mx) {
+  int rc = check_params(ctx, params);
+  if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  reset_timings(ctx);
+  RefData ref;
+  QueryBatch q;
+  mi355_sw_result r;
+  memset(&r, 0, sizeof r);
+  rc = upload_reference(ctx, ref, y, ny);
+  if (!rc) rc = upload_queries(ctx, q, 1, &x, &nx);
+  if (!rc) rc = align_range(ctx, ref, q, Range{0, (int64_t)ny}, *params, MI355_SW_SCORE_ONLY, &r);
+  ref.bytes.release(); ref.codes.release(); q.bytes.release(); q.lens.release();
+  if (rc) return rc;
+  if (index_x) *index_x = r.end_x;
+  if (index_y) *index_y = r.end_y;
+  if (mx) *mx = r.score;
+  mi355_sw_free_result(&r);
+  return 0;
+}
+
+int mi355_sw_make_string_range(int npiece, int64_t shortlen, int64_t longlen, float overlap_ratio,
+                               int64_t *lefts, int64_t *rights) {
+  // plocalaligner.cpp:44-67
+  if (npiece < 1 || !lefts || !rights) return MI355_SW_EINVAL;
+  const int64_t overlap = (int64_t)((float)shortlen * overlap_ratio);
+  if (npiece == 1) { lefts[0] = 0; rights[0] = longlen; return 0; }
+  const int64_t piecelen = (longlen + (int64_t)(npiece - 1) * overlap) / npiece;
+  if (!(overlap <= piecelen)) return MI355_SW_ERANGE;
+  int64_t left = 0, right = piecelen;
+  int k = 0;
+  lefts[k] = left; rights[k] = right; ++k;
+  while (k < npiece - 1) {
+    left = std::max<int64_t>(0, right - overlap);
+    right = std::min(left + piecelen, longlen);
+    lefts[k] = left; rights[k] = right; ++k;
+  }
+  if (!(right < longlen)) return MI355_SW_ERANGE;
+  lefts[k] = std::max<int64_t>(0, right - overlap); rights[k] = longlen;
+  return 0;
+}
+
+int mi355_sw_align_split(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, size_t ny,
+                         const mi355_sw_params *params, int sm_semantics, int la_semantics,
+                         int npiece, float overlap_ratio, mi355_sw_result *out, int *winning_piece) {
+  int rc = check_params(ctx, params);
+  if (rc) return rc;
+  if (!out || npiece < 1) return fail(ctx, MI355_SW_EINVAL, "bad argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  reset_timings(ctx);
+  std::vector<int64_t> lefts(npiece), rights(npiece);
+  rc = mi355_sw_make_string_range(npiece, (int64_t)nx, (int64_t)ny, overlap_ratio, lefts.data(), rights.data());
+  if (rc) return fail(ctx, rc, "_make_string_range: the reference's asserts would fire for these arguments");
+  RefData ref;
+  QueryBatch q;
+  rc = upload_reference(ctx, ref, y, ny);
+  if (!rc) rc = upload_queries(ctx, q, 1, &x, &nx);
+  int bp = 0;
+  if (!rc) {
+    mi355_sw_params ps = *params;
+    ps.semantics = sm_semantics;
+    std::vector<Range> ranges(npiece);
+    int64_t maxlen = 0;
+    for (int k = 0; k < npiece; ++k) { ranges[k] = Range{lefts[k], rights[k]}; maxlen = std::max(maxlen, rights[k] - lefts[k]); }
+    FastPlan plan = plan_fast(ref, q, ps, maxlen);
+    bool all_fast = plan.ok;
+    for (auto &r : ranges) all_fast = all_fast && range_fast_ok(plan, q, r, ps);
+    std::vector<float> pmax(npiece, 0.0f);
+    if (all_fast) {
+      ScoreOut so;
+      rc = score_pass(ctx, ref, q, ranges, ps, plan, so);
+      if (!rc) for (int k = 0; k < npiece; ++k) pmax[k] = (float)(so.keys[k] >> 32);
+    } else {
+      for (int k = 0; k < npiece && !rc; ++k) {
+        std::vector<Located> loc;
+        std::vector<TraceOut> t;
+        rc = exact_full(ctx, ref, q, ranges[k], ps, std::vector<int>{0}, false, loc, t);
+        if (!rc) pmax[k] = loc[0].score;
+      }
+    }
+    if (!rc) {
+      float best = -1.0f;                                  // plocalaligner.cpp:106,122-129
+      for (int k = 0; k < npiece; ++k) if (pmax[k] > best) { best = pmax[k]; bp = k; }
+      mi355_sw_params pd;
+      mi355_sw_default_params(&pd);                        // LAT(x, piece): default scoring (:135)
+      pd.semantics = la_semantics;
+      const double t_score = ctx->timings[0];
+      rc = align_range(ctx, ref, q, ranges[bp], pd, 0, out);
+      if (!rc) {
+        if (out->score > 0) { out->pos += (uint32_t)lefts[bp]; out->end_y += lefts[bp]; }
+        else out->pos = (uint32_t)lefts[bp];
+        out->timings_us[0] = (float)t_score;
+        out->timings_us[1] = (float)t_score;
+      }
+    }
+  }
+  if (winning_piece) *winning_piece = bp;
+  ref.bytes.release(); ref.codes.release(); q.bytes.release(); q.lens.release();
+  return rc;
+}
+
+int mi355_sw_fill_matrix(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, size_t ny,
+                         const mi355_sw_params *params, float *H) {
+  int rc = check_params(ctx, params);
+  if (rc) return rc;
+  if (!H) return fail(ctx, MI355_SW_EINVAL, "H is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t cells = (nx + 1) * (ny + 1);
+  if (cells * 4 > (size_t)8 << 30) return fail(ctx, MI355_SW_ENOTSUP, "matrix larger than 8 GiB");
+  if (nx == 0 || ny == 0) { memset(H, 0, cells * 4); return 0; }
+  RefData ref;
+  QueryBatch q;
+  rc = upload_reference(ctx, ref, y, ny);
+  if (!rc) rc = upload_queries(ctx, q, 1, &x, &nx);
+  if (!rc && ctx->hmat.ensure(cells * 4)) rc = fail(ctx, MI355_SW_ENOMEM, "hipMalloc(matrix) failed");
+  if (!rc) {
+    if (hipMemsetAsync(ctx->hmat.p, 0, cells * 4, ctx->stream) != hipSuccess) rc = fail(ctx, MI355_SW_ENODEV, "hipMemsetAsync failed");
+  }
+  if (!rc) {
+    std::vector<ExactJob> jobs(1);
+    ExactJob &j = jobs[0];
+    j.q = 0; j.ylo = 0; j.nw = (int32_t)ny; j.col_offset = 0; j.full_n = (int64_t)ny; j.own_lo = 1;
+    j.quirk = (params->semantics == MI355_SW_U8SAT && nx == ny) ? 1 : 0;
+    j.target = -1.0f; j.want_dirs = false;
+    rc = run_exact(ctx, ref, q, *params, jobs, 0, 1, ctx->hmat.as<float>());
+  }
+  if (!rc && hipMemcpy(H, ctx->hmat.p, cells * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, MI355_SW_ENODEV, "hipMemcpy(matrix) failed");
+  ref.bytes.release(); ref.codes.release(); q.bytes.release(); q.lens.release();
+  return rc;
+}
+
+int mi355_sw_last_timings(const mi355_sw_ctx *ctx, double out[6]) {
+  if (!ctx || !out) return MI355_SW_EINVAL;
+  for (int k = 0; k < 6; ++k) out[k] = ctx->timings[k];
+  return 0;
+}
+
+void mi355_sw_free_result(mi355_sw_result *r) {
+  if (!r) return;
+  free(r->cons_x); free(r->cons_y);
+  r->cons_x = r->cons_y = nullptr; r->cons_len = 0;
+}
+
+void mi355_sw_free_results(mi355_sw_result *r, size_t n) {
+  if (!r) return;
+  for (size_t k = 0; k < n; ++k) mi355_sw_free_result(r + k);
+}
+
+}  // extern "C"

@@ -1,0 +1,214 @@
+// sw_score_kernel.h — score-only Smith-Waterman sweep for gfx950 (MI355X), hand-written HIP.
+//
+// Replaces, for the score pass, Similarity_Matrix::iterate / Similarity_Matrix_Skewed::iterate
+// plus the value half of find_index_of_maximum (reference src/aligner/similaritymatrix.cpp:99-264,
+// :386-561, :21-28, :291-299).  The argmax POSITION and the traceback are recovered afterwards by
+// sw_exact_kernel.h on the one or two tiles that hold the maximum.
+//
+// Layout:
+//   * a tile = (query pair, reference chunk).  16 lanes of a wavefront (one DPP row) own one tile;
+//     lane l owns R consecutive query rows, so a 16-lane slot covers 16*R rows.  A wavefront runs
+//     4 tiles (4 chunks of the same query pair), a 256-thread workgroup 16.
+//   * every VGPR holds TWO cells: low half = query A, high half = query B, same reference column.
+//     All arithmetic is packed 16-bit (v_pk_add_i16 / v_pk_max_i16 / v_pk_sub_u16 clamp).
+//   * cells of one anti-diagonal live in the 16 lanes: at step t lane l is at column t - l.  The
+//     only cross-lane traffic is ONE v_mov_b32_dpp row_shr:1 per step (last row of the lane above).
+//   * the substitution scores come from a per-workgroup query profile in LDS,
+//     prof[ref code][lane][row] (packed A|B), read with ds_read_b128; the reference chunk is
+//     streamed through a small per-slot LDS byte window (coalesced global loads, once per 64 steps).
+//   * the running maximum is folded into t = max(W, N), which the recurrence needs anyway, on odd
+//     rows only: t_r covers cell (r, j-1) and cell (r-1, j), so R/2 extra ops per step suffice.
+//
+// Per pair of cells: add, max, sub(clamp), max  (+ min for U8SAT)  + 1/2 max  => 2.25 (2.75)
+// lane-ops per cell, against 157 T lane-ops/s/2 of the chip (MI355X_MICROARCH.md).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi355sw {
+
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kSlotLanes = 16;
+constexpr int kSeg = 64;               // steps between two refills of the code window
+constexpr int kHist = 16;              // bytes of history kept in front of a segment
+constexpr int kCodeBuf = kHist + kSeg; // bytes per slot
+constexpr int kPadScore = -16384;      // substitution score of padding rows / columns
+constexpr int kSemI16 = 0;             // Similarity_Matrix semantics on integer scores
+constexpr int kSemU8 = 1;              // Similarity_Matrix_Skewed semantics (saturate at 255)
+
+// LDS stride (dwords) between the profile rows of two adjacent lanes: a multiple of 4 (b128
+// alignment) that is ≡ 4 (mod 8), so that the sixteen 16-byte windows of a ds_read_b128 lane
+// group fall on disjoint banks whatever reference code each lane looks up (16*LS ≡ 0 mod 64).
+__host__ __device__ constexpr int lane_stride(int R) {
+  int rp = (R + 3) / 4 * 4;
+  return (rp % 8 == 0) ? rp + 4 : rp;
+}
+
+struct ScoreArgs {
+  const uint8_t *refcodes;   // [ref_len] reference as dense codes 0..ncodes-2
+  int64_t ref_len;
+  const int64_t *range_lo;   // [nranges] sub-problems (pieces) of the reference, [lo,hi)
+  const int64_t *range_hi;
+  int64_t chunk_len;         // own columns per tile
+  int64_t warm;              // warm-up columns recomputed in front of a tile
+  int chunks_per_range;      // max over ranges
+  const uint8_t *qbytes;     // [nq][qstride] raw query bytes
+  const int32_t *qlen;       // [nq]
+  int qstride;
+  int nq;
+  const int16_t *stab;       // [256][ncodes] score(query byte, reference code); column ncodes-1 = pad
+  int ncodes;
+  uint32_t gap2;             // gap penalty in both halves
+  uint32_t clamp2;           // 255 in both halves (U8SAT)
+  unsigned long long *keys;  // [nranges][nq]  (max << 32) | (0xFFFFFFFF - chunk)
+};
+
+__device__ __forceinline__ uint32_t as_u32(i16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ i16x2 as_i16x2(uint32_t v) { return __builtin_bit_cast(i16x2, v); }
+__device__ __forceinline__ u16x2 as_u16x2(i16x2 v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ i16x2 to_i16x2(u16x2 v) { return __builtin_bit_cast(i16x2, v); }
+
+// value of the lane above inside the 16-lane DPP row, 0 for the first lane (row H(0,.) = 0)
+__device__ __forceinline__ uint32_t row_shr1(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+}
+
+template <int R, int SEM>
+__global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
+  static_assert(R % 2 == 0, "running max is folded on odd rows: R must be even");
+  constexpr int LS = lane_stride(R);
+  constexpr int NQ4 = (R + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t *prof = smem;                                           // [ncodes][16][LS]
+  uint8_t *codebuf = reinterpret_cast<uint8_t *>(smem + a.ncodes * kSlotLanes * LS);
+
+  const int tid = threadIdx.x;
+  const int l16 = tid & 15;
+  const int slot = tid >> 4;                                       // 0..15 within the workgroup
+  const int cgroups = (a.chunks_per_range + 15) >> 4;
+  const int pair = blockIdx.x / cgroups;
+  const int cg = blockIdx.x - pair * cgroups;
+  const int range = blockIdx.y;
+  const int qA = 2 * pair;
+  const bool hasB = (qA + 1) < a.nq;
+  const int qB = hasB ? qA + 1 : qA;
+
+  // ---- query profile for this workgroup's pair -------------------------------------------
+  {
+    const int mA = a.qlen[qA], mB = a.qlen[qB];
+    const uint8_t *xA = a.qbytes + (size_t)qA * a.qstride;
+    const uint8_t *xB = a.qbytes + (size_t)qB * a.qstride;
+    const int per_code = kSlotLanes * R;
+    for (int e = tid; e < a.ncodes * per_code; e += 256) {
+      const int c = e / per_code;
+      const int rem = e - c * per_code;
+      const int ll = rem / R, r = rem - ll * R;
+      const int i = ll * R + r;
+      const int sa = (i < mA) ? a.stab[(int)xA[i] * a.ncodes + c] : kPadScore;
+      const int sb = (i < mB) ? a.stab[(int)xB[i] * a.ncodes + c] : kPadScore;
+      prof[(c * kSlotLanes + ll) * LS + r] = (uint32_t)(uint16_t)sa | ((uint32_t)(uint16_t)sb << 16);
+    }
+  }
+
+  // ---- this slot's tile -------------------------------------------------------------------
+  const int64_t rlo = a.range_lo[range], rhi = a.range_hi[range];
+  const int64_t nchunks = (rhi - rlo + a.chunk_len - 1) / a.chunk_len;
+  const int64_t chunk = (int64_t)cg * 16 + slot;
+  const bool active = chunk < nchunks;
+  const int64_t own_lo = rlo + chunk * a.chunk_len;
+  const int64_t own_hi = (own_lo + a.chunk_len < rhi) ? own_lo + a.chunk_len : rhi;
+  const int64_t s0 = own_lo - a.warm;                 // reference index of stream position 0
+  const uint32_t pad = (uint32_t)(a.ncodes - 1);
+  const uint32_t pad4 = pad * 0x01010101u;
+
+  // codes of stream positions seg*64 + 4*l16 .. +3 (pad outside [rlo, own_hi))
+  auto stage_load = [&](int seg) -> uint32_t {
+    const int64_t c0 = s0 + (int64_t)seg * kSeg + 4 * l16;
+    uint32_t w = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int64_t col = c0 + b;
+      const bool ok = active && col >= rlo && col < own_hi;
+      const uint32_t code = ok ? (uint32_t)a.refcodes[col] : pad;
+      w |= code << (8 * b);
+    }
+    return w;
+  };
+
+  uint8_t *buf = codebuf + slot * kCodeBuf;
+  uint32_t *buf32 = reinterpret_cast<uint32_t *>(buf);
+  const uint8_t *buf_lane = buf + kHist - l16;                     // + k = code of step k
+  const uint32_t *prof_lane = prof + l16 * LS;
+
+  const int64_t total_steps = a.warm + a.chunk_len + kSlotLanes;   // +15 skew, +1 max-fold drain
+  const int nseg = (int)((total_steps + kSeg - 1) / kSeg);
+
+  uint32_t nextcodes = stage_load(0);
+  if (l16 < kHist / 4) buf32[l16] = pad4;
+  buf32[kHist / 4 + l16] = nextcodes;
+  nextcodes = stage_load(1);
+  __syncthreads();                                                 // profile + first window ready
+
+  i16x2 H[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) H[r] = as_i16x2(0u);
+  i16x2 mx = as_i16x2(0u);
+  uint32_t up_prev = 0;
+  const u16x2 gap = __builtin_bit_cast(u16x2, a.gap2);
+  const i16x2 clampv = as_i16x2(a.clamp2);
+  const int code_stride = kSlotLanes * LS;                         // dwords per reference code
+
+  for (int seg = 0; seg < nseg; ++seg) {
+#pragma unroll 8
+    for (int k = 0; k < kSeg; ++k) {
+      const uint32_t c = buf_lane[k];
+      const uint4 *pp = reinterpret_cast<const uint4 *>(prof_lane + c * code_stride);
+      uint32_t p[NQ4 * 4];
+#pragma unroll
+      for (int q = 0; q < NQ4; ++q) {
+        const uint4 v = pp[q];
+        p[4 * q + 0] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+      }
+      const uint32_t up = row_shr1(as_u32(H[R - 1]));              // H(i0-1, j) of the lane above
+      i16x2 diag = as_i16x2(up_prev);                              // H(i0-1, j-1)
+      i16x2 north = as_i16x2(up);
+      up_prev = up;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const i16x2 w = H[r];
+        i16x2 x = diag + as_i16x2(p[r]);
+        if (SEM == kSemU8) x = __builtin_elementwise_min(x, clampv);
+        const i16x2 t = __builtin_elementwise_max(w, north);
+        if (r & 1) mx = __builtin_elementwise_max(mx, t);
+        const i16x2 y = to_i16x2(__builtin_elementwise_sub_sat(as_u16x2(t), gap));
+        const i16x2 h = __builtin_elementwise_max(x, y);
+        diag = w;
+        H[r] = h;
+        north = h;
+      }
+    }
+    // slide the code window: keep the last 16 bytes as history, append the prefetched segment
+    const uint32_t hist = buf32[kSeg / 4 + (l16 & 3)];
+    if (l16 < kHist / 4) buf32[l16] = hist;
+    buf32[kHist / 4 + l16] = nextcodes;
+    nextcodes = stage_load(seg + 2);
+  }
+
+  // ---- per-tile maximum -> per-query key -------------------------------------------------
+  uint32_t m32 = as_u32(mx);
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)m32, off, 16);
+    m32 = as_u32(__builtin_elementwise_max(as_i16x2(m32), as_i16x2(o)));
+  }
+  if (l16 == 0 && active) {
+    const unsigned long long tag = 0xFFFFFFFFull - (unsigned long long)chunk;
+    unsigned long long *k = a.keys + (size_t)range * a.nq;
+    atomicMax(k + qA, ((unsigned long long)(m32 & 0xFFFFu) << 32) | tag);
+    if (hasB) atomicMax(k + qB, ((unsigned long long)(m32 >> 16) << 32) | tag);
+  }
+}
+
+}  // namespace mi355sw

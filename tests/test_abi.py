@@ -1,0 +1,48 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/mi355_sw.h declares, and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "mi355_sw.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi355_sw_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(pgs):
+    L = pgs.capi.lib()
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), "symbol %s declared in include/mi355_sw.h is not exported" % n
+    assert sorted(pgs.capi.EXPORTS) == names
+    assert b"gfx950" in L.mi355_sw_build_info()
+
+
+def test_make_string_range_host_helper(pgs, golden):
+    for c in golden["range"]:
+        assert pgs.capi.make_string_range(c["npiece"], c["short"], c["long"], c["ratio"]) == [tuple(r) for r in c["ranges"]]
+    assert pgs.capi.make_string_range(4, 100, 120, 2.0) is None     # assert overlap <= piecelen would fire
+
+
+def test_no_cpu_fallback(pgs):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pgs.MI355Error):
+        pgs.Context(0)
+    with pytest.raises(pgs.MI355Error):
+        pgs.SWAligner("GGTTGACTA", "TGTTACGG").calculateScore()
+
+
+def test_aligner_mirror_defaults(pgs):
+    la = pgs.SWAligner("GGTTGACTA", "TGTTACGG")
+    assert la.getScore() == -1.0 and la.getPos() == 0 and la.getConsensus_x() == ""   # smithwaterman.cpp:27-33
+    with pytest.raises(AssertionError):
+        pgs.OMPParallelLocalAligner("A" * 100, "C" * 120, 4, 2.0)                     # plocalaligner.cpp:52

@@ -1,0 +1,147 @@
+"""GPU parity: the HIP path (through the C-ABI) against the golden fixtures made with the real
+reference, and against the CPU oracle on seeded inputs.  Integer outputs (pos, argmax, consensus)
+bit-exact; scores are small integers held in float -> tolerance 0 (north_star allows 1e-5)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 0.0
+
+
+@pytest.fixture(scope="module")
+def ctx(pgs):
+    c = pgs.Context(0)
+    yield c
+    c.close()
+
+
+def _cmp(got, exp, what):
+    assert abs(got["score"] - exp["score"]) <= SCORE_TOL, "%s: score %r != %r" % (what, got["score"], exp["score"])
+    for k in ("pos", "end_x", "end_y", "cons_x", "cons_y"):
+        if k in exp and exp[k] != -1:
+            assert got[k] == exp[k], "%s: %s differs: got %r expected %r" % (what, k, got[k], exp[k])
+
+
+def test_reference_gtest_cases(pgs, ctx):
+    # test/test_localaligner.cpp:24-27, :53-58 through the mirrored class
+    la = pgs.SWAligner("GGTTGACTA", "TGTTACGG", matrix=pgs.Similarity_Matrix_Skewed, context=ctx)
+    la.calculateScore()
+    assert la.getScore() == 13 and la.getPos() == 2
+    assert la.getConsensus_x() == "CAGTTG" and la.getConsensus_y() == "CA-TTG"
+
+
+def test_kat(ctx, golden):
+    for c in golden["kat"]:
+        _cmp(ctx.align(c["x"], c["y"], c["sem"], c["match"], c["mismatch"], c["gap"]), c["expect"], c["name"])
+
+
+def test_matrices_and_skewed_equals_normal(ctx, golden):
+    # test/test_skewedmatrix.cpp:39-66 + commented matrix test_localaligner.cpp:33-42 + square quirk
+    for c in golden["matrix"]:
+        H = ctx.fill_matrix(c["x"], c["y"], c["sem"], c["match"], c["mismatch"], c["gap"])
+        exp = np.array(c["cells"], dtype=np.float32).reshape(len(c["x"]) + 1, len(c["y"]) + 1)
+        assert np.array_equal(H, exp), (c["x"], c["y"], c["sem"])
+
+
+def test_align_cases(ctx, golden):
+    for k, c in enumerate(golden["align"]):
+        _cmp(ctx.align(c["x"], c["y"], c["sem"], c["match"], c["mismatch"], c["gap"]), c["expect"], "align[%d]" % k)
+
+
+def test_alignlut_cases(ctx, golden, pgs):
+    for k, c in enumerate(golden["alignlut"]):
+        lut = pgs.synth.make_lut(c["seed"], c["scale"])
+        _cmp(ctx.align(c["x"], c["y"], c["sem"], gap=c["gap"], lut=lut), c["expect"], "alignlut[%d]" % k)
+
+
+def test_split_cases(ctx, golden):
+    for k, c in enumerate(golden["split"]):
+        got = ctx.align_split(c["x"], c["y"], c["npiece"], c["ratio"], c["sm"], c["la"], c["match"], c["mismatch"], c["gap"])
+        _cmp(got, c["expect"], "split[%d]" % k)
+
+
+def test_no_match_defined(ctx):
+    r = ctx.align("AAAA", "CCCCCC")
+    assert r["score"] == 0 and r["pos"] == 0 and r["cons_x"] == "" and r["end_x"] == 0
+
+
+def test_empty_inputs(ctx):
+    assert ctx.align("", "ACGT")["score"] == 0
+    assert ctx.align("ACGT", "")["score"] == 0
+
+
+@pytest.mark.parametrize("sem,name", [(0, "f32"), (1, "u8")])
+def test_data_small_digest(ctx, data_small, sem, name):
+    """Config 1 (sw_solve_small) at full size through the batched path."""
+    res = ctx.align_batch(data_small["reads"], data_small["ref"], semantics=sem)
+    lines = ["%d,%g,%d,%s,%s\n" % (k, r["score"], r["pos"], r["cons_x"], r["cons_y"]) for k, r in enumerate(res)]
+    for k, exp in enumerate(data_small["first"][name]):
+        _cmp(res[k], exp, "data_small[%s][%d]" % (name, k))
+    assert hashlib.sha256("".join(lines).encode()).hexdigest() == data_small["digests"][name]
+
+
+def test_data_small_split_digest(ctx, data_small):
+    lines = []
+    for k, read in enumerate(data_small["reads"]):
+        r = ctx.align_split(read, data_small["ref"], 17, 2.0, 1, 1)
+        lines.append("%d,%g,%d,%s,%s\n" % (k, r["score"], r["pos"], r["cons_x"], r["cons_y"]))
+    assert hashlib.sha256("".join(lines).encode()).hexdigest() == data_small["digests"]["u8_npiece17"]
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+def test_config2_single_read_vs_1mbp(ctx, oracle, pgs, sem):
+    """Config 2: one 150 bp synthetic read vs a 1 Mbp synthetic reference, bit-match vs the oracle."""
+    ref = pgs.synth.dna(1, 1_000_000)
+    read, off = pgs.synth.read_from_ref(ref, 2, 150)
+    exp = oracle.align(read.tobytes(), ref.tobytes(), sem)
+    got = ctx.align(read, ref, sem)
+    _cmp(got, exp, "cfg2 sem=%d" % sem)
+    assert abs(got["pos"] - (off + 1)) < 40
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+def test_batch_vs_oracle(ctx, oracle, pgs, sem):
+    """Ragged batch (lengths 20..250) against a 300 kbp reference, incl. reads that match nowhere."""
+    ref = pgs.synth.dna(11, 300_000)
+    reads = []
+    for k in range(48):
+        ln = [20, 33, 64, 100, 125, 150, 151, 200, 250][k % 9]
+        r, _ = pgs.synth.read_from_ref(ref, 100 + k, ln, sub_rate=0.03, indel_rate=0.01)
+        reads.append(r.tobytes())
+    reads.append(pgs.synth.dna(999, 150).tobytes())          # unrelated read
+    reads.append(b"N" * 40)                                   # matches nothing
+    res = ctx.align_batch(reads, ref, semantics=sem)
+    for k, (q, got) in enumerate(zip(reads, res)):
+        _cmp(got, oracle.align(q, ref.tobytes(), sem), "batch[%d] sem=%d" % (k, sem))
+
+
+def test_ties_and_repeats(ctx, oracle):
+    unit = "ACGTTGCA"
+    for sem in (0, 1):
+        for x, y in [(unit * 4, unit * 5000), ("A" * 120, "A" * 30000), (unit * 12, ("T" * 50 + unit * 12) * 300)]:
+            _cmp(ctx.align(x, y, sem), oracle.align(x, y, sem), "repeat sem=%d |y|=%d" % (sem, len(y)))
+
+
+def test_full_size_planted_reads(ctx, pgs):
+    """Config-3 shape at full reference size (50 Mbp): exact substrings must be found where they were
+    cut (size-independent property; the oracle cannot hold a 150 x 50M matrix in a few seconds)."""
+    ref = pgs.synth.dna(3, 50_000_000)
+    offs = (pgs.synth.splitmix64(4, 64) % np.uint64(len(ref) - 150)).astype(np.int64)
+    offs[0], offs[1] = 0, len(ref) - 150                       # both ends of the reference
+    reads = [ref[o:o + 150].tobytes() for o in offs]
+    ctx.set_reference(ref)
+    ctx.batch_upload(reads)
+    for sem in (0, 1):
+        res = ctx.batch_run(semantics=sem)
+        for o, r in zip(offs, res):
+            if sem == 0:
+                assert r["score"] == 450 and r["end_x"] == 150 and r["end_y"] == o + 150
+                # consensus is stored end -> start; the greedy walk may overshoot the true start
+                rev = ref[o:o + 150].tobytes()[::-1].decode()
+                assert r["cons_x"][:150] == rev and r["cons_y"][:150] == rev
+                assert r["pos"] <= o + 1
+            else:
+                assert r["score"] == 255 and r["end_x"] == 85 and r["end_y"] == o + 85
