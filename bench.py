@@ -42,15 +42,33 @@ def load_package():
     return mod
 
 
+def host_cores():
+    """Host cores this job may use: the cgroup CPU quota when there is one, otherwise the affinity
+    mask capped at the GPU box's per-GPU CPU share (16 per visible GPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    try:
+        import torch
+        share = 16 * max(1, torch.cuda.device_count())
+    except Exception:
+        share = 16
+    return max(1, min(n, share))
+
+
 def cpu_baseline(pgs, ref, read_len, seconds_hint=20.0):
     """The reference's own OpenMP path (oracle/_ref/ref_driver_omp = unmodified reference sources
     behind our driver, src/sw_solve_big.cpp:78-92 loop) on this box's host cores, bounded sample.
     Falls back to the oracle's scalar port when the reference build did not travel."""
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     sys.path.insert(0, ROOT)
     from oracle import refproc
     sub_len = min(len(ref), 5_000_000)
-    nreads = 48
+    nreads = 96
     sub = ref[:sub_len]
     reads, _ = pgs.synth.fast_reads_from_ref(sub, 77, nreads, read_len)
     if os.access(refproc.DRIVER_OMP, os.X_OK):
@@ -59,7 +77,8 @@ def cpu_baseline(pgs, ref, read_len, seconds_hint=20.0):
             for r in reads:
                 f.write(r.tobytes() + b"\n")
             path = f.name
-        env = dict(os.environ, OMP_PLACES="cores", OMP_PROC_BIND="close", OMP_DYNAMIC="false")
+        env = dict(os.environ, OMP_PLACES="cores", OMP_PROC_BIND="close", OMP_DYNAMIC="false",
+                   OMP_THREAD_LIMIT=str(cores))
         try:
             t0 = time.time()
             out = refproc.run(["bench %s %d 1" % (path, 2 * cores)], omp=True, env=env, timeout=600)[0].split()
