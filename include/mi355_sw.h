@@ -110,6 +110,13 @@ int mi355_sw_align_split(mi355_sw_ctx *ctx, const char *x, size_t nx, const char
                          const mi355_sw_params *params, int sm_semantics, int la_semantics,
                          int npiece, float overlap_ratio, mi355_sw_result *out, int *winning_piece);
 
+/* Maximum cell value of every resident query over each sub-range [lefts[k], rights[k]) of the resident
+ * reference, each range an independent problem with a zero left border (what
+ * OMPParallelLocalAligner's per-piece iterate + find_index_of_maximum produce, plocalaligner.cpp:110-129).
+ * maxima[k * n_queries + q].  Used by multi-GPU reference sharding: every rank sweeps its own pieces. */
+int mi355_sw_score_ranges(mi355_sw_ctx *ctx, size_t nranges, const int64_t *lefts, const int64_t *rights,
+                          const mi355_sw_params *params, float *maxima);
+
 /* Host-only helper: piece ranges [left,right). Returns MI355_SW_ERANGE where the reference asserts. */
 int mi355_sw_make_string_range(int npiece, int64_t shortlen, int64_t longlen, float overlap_ratio,
                                int64_t *lefts, int64_t *rights);

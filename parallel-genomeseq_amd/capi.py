@@ -14,7 +14,7 @@ SCORE_ONLY = 1
 EXPORTS = [
     "mi355_sw_create", "mi355_sw_destroy", "mi355_sw_last_error", "mi355_sw_default_params",
     "mi355_sw_align", "mi355_sw_set_reference", "mi355_sw_align_batch", "mi355_sw_batch_upload",
-    "mi355_sw_batch_run", "mi355_sw_align_split", "mi355_sw_make_string_range", "mi355_sw_fill_matrix",
+    "mi355_sw_batch_run", "mi355_sw_score_ranges", "mi355_sw_align_split", "mi355_sw_make_string_range", "mi355_sw_fill_matrix",
     "mi355_sw_argmax", "mi355_sw_last_timings", "mi355_sw_free_result", "mi355_sw_free_results",
     "mi355_sw_build_info",
 ]
@@ -174,6 +174,17 @@ class Context:
         else:
             out = [_take(r) for r in res]
         self._L.mi355_sw_free_results(res, C.c_size_t(n))
+        return out
+
+    def score_ranges(self, ranges, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None):
+        """Per-range maxima of every resident query: array [len(ranges), n_queries]."""
+        p, keep = make_params(semantics, match, mismatch, gap, lut)
+        n = len(ranges)
+        lefts = (C.c_int64 * n)(*[r[0] for r in ranges])
+        rights = (C.c_int64 * n)(*[r[1] for r in ranges])
+        out = np.zeros((n, self._nbatch), dtype=np.float32)
+        self._chk(self._L.mi355_sw_score_ranges(self._ctx, C.c_size_t(n), lefts, rights, C.byref(p),
+                                                out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
     def align_batch(self, xs, y=None, **kw):

@@ -908,6 +908,47 @@ int mi355_sw_align_split(mi355_sw_ctx *ctx, const char *x, size_t nx, const char
   return rc;
 }
 
+int mi355_sw_score_ranges(mi355_sw_ctx *ctx, size_t nranges, const int64_t *lefts, const int64_t *rights,
+                          const mi355_sw_params *params, float *maxima) {
+  int rc = check_params(ctx, params);
+  if (rc) return rc;
+  if (!lefts || !rights || !maxima) return fail(ctx, MI355_SW_EINVAL, "null argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  reset_timings(ctx);
+  const QueryBatch &q = ctx->batch;
+  if (q.nq == 0 || nranges == 0) return 0;
+  std::vector<Range> ranges(nranges);
+  int64_t maxlen = 0;
+  for (size_t k = 0; k < nranges; ++k) {
+    if (lefts[k] < 0 || rights[k] < lefts[k] || rights[k] > (int64_t)ctx->ref.n) return fail(ctx, MI355_SW_EINVAL, "range outside the resident reference");
+    ranges[k] = Range{lefts[k], rights[k]};
+    maxlen = std::max(maxlen, rights[k] - lefts[k]);
+  }
+  FastPlan plan = plan_fast(ctx->ref, q, *params, maxlen);
+  bool all_fast = plan.ok;
+  for (auto &r : ranges) all_fast = all_fast && range_fast_ok(plan, q, r, *params);
+  if (all_fast) {
+    for (size_t lo = 0; lo < nranges; lo += 32768) {          // grid.y limit
+      const size_t hi = std::min(nranges, lo + 32768);
+      ScoreOut so;
+      rc = score_pass(ctx, ctx->ref, q, std::vector<Range>(ranges.begin() + lo, ranges.begin() + hi), *params, plan, so);
+      if (rc) return rc;
+      for (size_t k = 0; k < (hi - lo) * q.nq; ++k) maxima[lo * q.nq + k] = (float)(so.keys[k] >> 32);
+    }
+    return 0;
+  }
+  std::vector<int> all(q.nq);
+  for (size_t k = 0; k < q.nq; ++k) all[k] = (int)k;
+  for (size_t k = 0; k < nranges; ++k) {
+    std::vector<Located> loc;
+    std::vector<TraceOut> t;
+    rc = exact_full(ctx, ctx->ref, q, ranges[k], *params, all, false, loc, t);
+    if (rc) return rc;
+    for (size_t i = 0; i < q.nq; ++i) maxima[k * q.nq + i] = loc[i].score;
+  }
+  return 0;
+}
+
 int mi355_sw_fill_matrix(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, size_t ny,
                          const mi355_sw_params *params, float *H) {
   int rc = check_params(ctx, params);

@@ -1,0 +1,125 @@
+"""Multi-GPU sharding of the alignment path: one process per GPU,
+torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+
+* query sharding  — the shape of src/mpi_sw_solve_uniprot.cpp:95-138 (independent alignments farmed to
+  ranks) without its MPI_Send/MPI_Recv writer rank: reads are block- or LPT-partitioned, the reference is
+  replicated, there is no exchange during compute; results stay rank-local or are all-gathered (16 B per
+  alignment); "best over the batch" is ONE 8-byte all-reduce(MAX) of a packed (score, ~index) key.
+* reference sharding — the shape of OMPParallelLocalAligner (src/aligner/plocalaligner.cpp:105-143):
+  pieces from _make_string_range dealt round-robin to ranks, per-piece maxima computed locally, ONE
+  all-reduce(MAX) of (score << 32 | ~piece) so the lowest piece index wins ties (serial rule, :125), the
+  owner rank re-aligns the winning piece with default scoring (:135) and broadcasts the result.
+
+The functions take the compute step as a callable so that CPU tests can drive them with the oracle;
+the product callables are methods of capi.Context (GPU only).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def _dev():
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def world():
+    return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+
+
+def shard_block(n, rank, size):
+    """Contiguous block of range(n) for `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n, size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_lpt(weights, size):
+    """Longest-processing-time partition of items by weight (cell count |x|*|y|) — for skewed length
+    distributions such as UniProt.  Deterministic; returns one index array per rank."""
+    w = np.asarray(weights, dtype=np.float64)
+    order = np.argsort(-w, kind="stable")
+    load = np.zeros(size)
+    bins = [[] for _ in range(size)]
+    for i in order:
+        r = int(np.argmin(load))
+        bins[r].append(int(i))
+        load[r] += w[i]
+    return [np.array(sorted(b), dtype=np.int64) for b in bins]
+
+
+def pack_key(score, index):
+    """(score, index) -> int64 so that MAX picks the highest score, then the LOWEST index."""
+    return (int(score) << 32) | (0xFFFFFFFF - int(index))
+
+
+def unpack_key(key):
+    return key >> 32, 0xFFFFFFFF - (key & 0xFFFFFFFF)
+
+
+def allreduce_best(score, index):
+    """One 8-byte all-reduce(MAX): global best (score, index), ties to the lowest index."""
+    rank, size = world()
+    key = pack_key(score, index)
+    if size > 1:
+        t = torch.tensor([key], dtype=torch.int64, device=_dev())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        key = int(t.item())
+    return unpack_key(key)
+
+
+def align_queries_sharded(align_fn, queries, weights=None, gather=True):
+    """Each rank aligns its shard with `align_fn(list_of_queries) -> list of result dicts`.
+    Returns (local_indices, local_results, gathered) where gathered is None or a dict of full-length
+    arrays score/pos/end_x/end_y identical on every rank."""
+    rank, size = world()
+    n = len(queries)
+    if weights is None:
+        lo, hi = shard_block(n, rank, size)
+        idx = np.arange(lo, hi, dtype=np.int64)
+    else:
+        idx = shard_lpt(weights, size)[rank]
+    res = align_fn([queries[i] for i in idx]) if len(idx) else []
+    gathered = None
+    if gather:
+        full = torch.zeros((4, n), dtype=torch.int64, device=_dev())
+        if len(idx):
+            loc = torch.tensor([[int(r["score"]) for r in res], [r["pos"] for r in res], [r["end_x"] for r in res],
+                                [r["end_y"] for r in res]], dtype=torch.int64, device=_dev())
+            full[:, torch.as_tensor(idx, device=_dev())] = loc
+        if size > 1:
+            dist.all_reduce(full, op=dist.ReduceOp.SUM)       # disjoint shards: SUM == gather, one collective
+        full = full.cpu().numpy()
+        gathered = dict(score=full[0].astype(np.float32), pos=full[1], end_x=full[2], end_y=full[3])
+    return idx, res, gathered
+
+
+def align_split_sharded(ranges, piece_maxima_fn, final_align_fn):
+    """Reference sharding.  `ranges` = [(left, right)] from _make_string_range (identical on all ranks);
+    `piece_maxima_fn(list_of_piece_indices) -> maxima` sweeps this rank's pieces;
+    `final_align_fn(piece_index) -> result dict` re-aligns one piece (default scoring) and is run by the
+    owner rank only.  Returns (result dict with pos already shifted by left, winning piece)."""
+    rank, size = world()
+    mine = list(range(rank, len(ranges), size))
+    maxima = piece_maxima_fn(mine) if mine else []
+    key = 0
+    # serial rule (plocalaligner.cpp:122-129): max_score_l starts at -1, strict '>' -> first piece with the max
+    for p, v in zip(mine, maxima):
+        key = max(key, pack_key(int(v) + 1, p))               # +1: a score of 0 still beats "no piece"
+    if size > 1:
+        t = torch.tensor([key], dtype=torch.int64, device=_dev())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        key = int(t.item())
+    _, piece = unpack_key(key)
+    owner = piece % size
+    obj = [None]
+    if rank == owner:
+        r = dict(final_align_fn(piece))
+        left = ranges[piece][0]
+        r["pos"] = r["pos"] + left
+        if r.get("end_y", 0) > 0:
+            r["end_y"] = r["end_y"] + left
+        r["piece"] = piece
+        obj[0] = r
+    if size > 1:
+        dist.broadcast_object_list(obj, src=owner)
+    return obj[0], piece

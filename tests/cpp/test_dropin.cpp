@@ -1,0 +1,74 @@
+// test_dropin.cpp — the reference's own gtest cases (test/test_localaligner.cpp:10-58,
+// test/test_skewedmatrix.cpp:39-66) and the driver loop shape of src/sw_solve_small.cpp:82-93, written
+// against include/parseq/*.h exactly as they are written against the reference's headers.
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <string>
+
+#include "parseq/localaligner.h"
+#include "parseq/plocalaligner.h"
+#include "parseq/similaritymatrix.h"
+#include "parseq/smithwaterman.h"
+
+#define EXPECT(cond)                                                        \
+  do {                                                                      \
+    if (!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } \
+  } while (0)
+
+int main() {
+  {  // SWAligner_Test fixture + Example_small_sequence_alignment + Verify_consensus_strings
+    std::string sequence_x = "GGTTGACTA";
+    std::string sequence_y = "TGTTACGG";
+    auto la = std::make_unique<SWAligner<Similarity_Matrix_Skewed>>(sequence_x, sequence_y);
+    EXPECT(la->getScore() == -1 && la->getPos() == 0);
+    la->calculateScore();
+    EXPECT(la->getScore() == 13);
+    EXPECT(la->getPos() == 2);
+    EXPECT(la->getConsensus_x() == std::string_view("CAGTTG"));
+    EXPECT(la->getConsensus_y() == std::string_view("CA-TTG"));
+    auto [ix, iy, mx] = la->getSimilarity_matrix().find_index_of_maximum();
+    EXPECT(ix == 7 && iy == 6 && mx == 13);
+    EXPECT(la->getSimilarity_matrix()(7, 6) == 13);
+    EXPECT(la->getTimings()[0] > 0);
+  }
+  {  // SimilarityMatrix.SkewedMatrixDP
+    std::string sequence_x = "GGTTGACTA";
+    std::string sequence_y = "TGTTACG";
+    auto len_x = sequence_x.size() + 1;
+    auto len_y = sequence_y.size() + 1;
+    auto skewed = Similarity_Matrix_Skewed(sequence_x, sequence_y);
+    auto normal = Similarity_Matrix(sequence_x, sequence_y);
+    auto skewed2 = Similarity_Matrix_Skewed(sequence_y, sequence_x);
+    auto normal2 = Similarity_Matrix(sequence_y, sequence_x);
+    auto scoring_function = [](const char &a, const char &b) { return a == b ? 3.0 : -3.0; };
+    skewed.iterate(scoring_function, 2.0);
+    normal.iterate(scoring_function, 2.0);
+    skewed2.iterate(scoring_function, 2.0);
+    normal2.iterate(scoring_function, 2.0);
+    for (size_t j = 0; j < len_y; j++)
+      for (size_t i = 0; i < len_x; i++) {
+        EXPECT(normal(i, j) == skewed(i, j));
+        EXPECT(normal2(j, i) == skewed2(j, i));
+      }
+  }
+  {  // custom scoring through std::function, float engine (SURVEY App. B probe: 9 / pos 2)
+    SWAligner<Similarity_Matrix> la("GGTTGACTA", "TGTTACGG", [](const char &a, const char &b) { return a == b ? 2.0f : -1.0f; }, 1.0f);
+    EXPECT(la.calculateScore() == 9 && la.getPos() == 2);
+    EXPECT(la.getConsensus_x() == std::string_view("CAGTTG") && la.getConsensus_y() == std::string_view("CA-TTG"));
+  }
+  {  // OMPParallelLocalAligner as sw_solve_small.cpp:82 constructs it (two equal hits: first piece wins)
+    std::string q = "ACGTACGTTG";
+    std::string ref = "TTTT" + q + "CCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCC" + q + "GGGGGGGGGGGGGGGGGGGGGGGGGGGGG";
+    auto la = std::make_unique<OMPParallelLocalAligner<Similarity_Matrix_Skewed, SWAligner<Similarity_Matrix_Skewed>>>(q, ref, 3, 2.0);
+    EXPECT(la->getScore() == -1);
+    float s = la->calculateScore();
+    EXPECT(s == 30);
+    EXPECT(la->getPos() == 5);
+    EXPECT(la->getConsensus_x() == std::string_view("GTTGCATGCA"));
+    auto r = _make_string_range(4, 10, 100, 2.0f);
+    EXPECT(r.size() == 4 && r[1].first == 20 && r[1].second == 60 && r[3].second == 100);
+  }
+  std::printf("ALL OK\n");
+  return 0;
+}

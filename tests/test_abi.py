@@ -46,3 +46,14 @@ def test_aligner_mirror_defaults(pgs):
     assert la.getScore() == -1.0 and la.getPos() == 0 and la.getConsensus_x() == ""   # smithwaterman.cpp:27-33
     with pytest.raises(AssertionError):
         pgs.OMPParallelLocalAligner("A" * 100, "C" * 120, 4, 2.0)                     # plocalaligner.cpp:52
+
+
+def test_cpp_dropin_headers_compile():
+    """include/parseq/*.h (the C++ mirror of the reference classes) compile and link against the C-ABI."""
+    import subprocess
+    out = os.path.join(ROOT, "tests", "cpp", "test_dropin.bin")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"),
+                           "-L" + os.path.join(ROOT, "parallel-genomeseq_amd"), "-lmi355_sw",
+                           "-Wl,-rpath," + os.path.join(ROOT, "parallel-genomeseq_amd"), "-o", out])
+    assert os.path.exists(out)

@@ -146,3 +146,41 @@ def test_full_size_planted_reads(ctx, pgs):
                 assert r["pos"] <= o + 20 and len(r["cons_x"]) >= 140
             else:
                 assert r["score"] == 255 and r["end_x"] == 85 and r["end_y"] == o + 85
+
+
+def test_cpp_dropin_binary():
+    """The reference's gtest cases compiled against include/parseq/*.h run on the GPU."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "test_dropin.bin")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        g.build()
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert p.returncode == 0 and b"ALL OK" in p.stdout, p.stdout.decode()
+
+
+def test_score_ranges_and_ref_sharding(ctx, oracle, pgs):
+    """mi355_sw_score_ranges (per-piece maxima, plocalaligner.cpp:110-129) and the reference-sharding
+    driver of dist.py with GPU callables (world size 1 here; world size 2 is covered with gloo on CPU)."""
+    from parallel_genomeseq_amd import dist as pd
+    ref = pgs.synth.dna(6, 400_000)
+    q = ref[70_000:70_150].tobytes()
+    refb = ref.tobytes()
+    refb = refb[:300_000] + q + refb[300_150:]
+    for sm, la, npiece in ((0, 0, 8), (1, 1, 17), (1, 0, 4)):
+        ranges = pgs.capi.make_string_range(npiece, len(q), len(refb), 2.0)
+        ctx.set_reference(refb)
+        ctx.batch_upload([q])
+        mx = ctx.score_ranges(ranges, semantics=sm)
+        assert mx.shape == (npiece, 1)
+        for k, (l, r) in enumerate(ranges):
+            assert mx[k, 0] == oracle.score_only(q, refb[l:r], sm), (sm, k)
+        res, piece = pd.align_split_sharded(
+            ranges, lambda pieces: [ctx.score_ranges([ranges[p] for p in pieces], semantics=sm)[i, 0] for i, p in enumerate(pieces)],
+            lambda p: ctx.align(q, refb[ranges[p][0]:ranges[p][1]], la))
+        exp = oracle.align_split(q, refb, npiece, 2.0, sm, la)
+        assert piece == exp["piece"]
+        for k in ("score", "pos", "cons_x", "cons_y"):
+            assert res[k] == exp[k], (sm, la, npiece, k)
