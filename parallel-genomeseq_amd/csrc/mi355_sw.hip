@@ -28,7 +28,7 @@ using namespace mi355sw;
 namespace {
 
 constexpr int kMaxCodes = 48;                 // LDS profile budget: codes incl. pad
-constexpr int kMaxRowsFast = 512;             // 16 lanes x R <= 32 rows
+constexpr int kMaxRowsFast = 512;             // 16 lanes x R <= 32 rows in one strip; longer queries are strip-mined
 constexpr size_t kDirsBudget = 3ull << 30;    // bytes of traceback decisions per exact launch
 constexpr size_t kExactLdsMax = 160 * 1024;
 
@@ -57,12 +57,13 @@ struct RefData {
 };
 
 struct QueryBatch {
-  DevBuf bytes, lens;
+  DevBuf bytes, lens, offs, sel;  // concatenated bytes (16-byte aligned starts), lengths, offsets, length-sorted ids
   std::vector<int32_t> len;
-  std::vector<uint8_t> host;      // [nq][stride]
+  std::vector<int64_t> off;
+  std::vector<int32_t> order;     // query ids sorted by length (stable)
   size_t nq = 0;
-  int stride = 0;
   int maxlen = 0;
+  void release() { bytes.release(); lens.release(); offs.release(); sel.release(); }
 };
 
 struct Range { int64_t lo, hi; };
@@ -83,7 +84,7 @@ struct mi355_sw_ctx {
   RefData ref;                    // resident reference (set_reference)
   QueryBatch batch;               // resident queries (batch_upload)
   // scratch
-  DevBuf keys, ranges, stab, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat;
+  DevBuf keys, ranges, stab, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow;
   double timings[6] = {0, 0, 0, 0, 0, 0};
 };
 
@@ -152,32 +153,50 @@ int upload_reference(mi355_sw_ctx *ctx, RefData &r, const char *y, size_t ny) {
 int upload_queries(mi355_sw_ctx *ctx, QueryBatch &q, size_t n, const char *const *xs, const size_t *nxs) {
   q.nq = n;
   q.len.resize(n);
-  size_t mx = 0;
+  q.off.resize(n);
+  size_t mx = 0, tot = 0;
   for (size_t k = 0; k < n; ++k) {
     if (nxs[k] > 0x3fffffff) return fail(ctx, MI355_SW_EINVAL, "query too long");
     q.len[k] = (int32_t)nxs[k];
+    q.off[k] = (int64_t)tot;
+    tot += (nxs[k] + 15) / 16 * 16;
     mx = std::max(mx, nxs[k]);
   }
   q.maxlen = (int)mx;
-  q.stride = (int)((mx + 15) / 16 * 16);
-  if (q.stride == 0) q.stride = 16;
-  q.host.assign((size_t)q.stride * n, 0);
-  for (size_t k = 0; k < n; ++k) memcpy(&q.host[(size_t)q.stride * k], xs[k], nxs[k]);
-  if (q.bytes.ensure(q.host.size() + 16) || q.lens.ensure(n * 4 + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(queries) failed");
-  HIPCHK(ctx, hipMemcpyAsync(q.bytes.p, q.host.data(), q.host.size(), hipMemcpyHostToDevice, ctx->stream));
+  q.order.resize(n);
+  for (size_t k = 0; k < n; ++k) q.order[k] = (int32_t)k;
+  std::stable_sort(q.order.begin(), q.order.end(), [&](int32_t a, int32_t b) { return q.len[a] < q.len[b]; });
+  std::vector<uint8_t> host(tot + 16, 0);
+  for (size_t k = 0; k < n; ++k) memcpy(&host[(size_t)q.off[k]], xs[k], nxs[k]);
+  if (q.bytes.ensure(host.size()) || q.lens.ensure(n * 4 + 16) || q.offs.ensure(n * 8 + 16) || q.sel.ensure(n * 4 + 16))
+    return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(queries) failed");
+  HIPCHK(ctx, hipMemcpyAsync(q.bytes.p, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(q.lens.p, q.len.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(q.offs.p, q.off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(q.sel.p, q.order.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }
 
 // ---- what the packed 16-bit score kernel covers --------------------------------------------
-struct FastPlan {
+// Score table shared by every launch of a call: which (params, reference alphabet) the packed 16-bit
+// kernel can represent exactly.
+struct ScoreTable {
   bool ok = false;
   std::string why;
-  int R = 0;
-  int64_t warm = 0;          // exactness margin in columns
   int gap = 0, smax = 0;
-  std::vector<int16_t> stab; // [256][ncodes]
+  std::vector<int16_t> stab;  // [256][ncodes]
+};
+
+// A run of length-sorted queries swept by one kernel instance.
+struct Bucket {
+  int first = 0, count = 0;   // positions in QueryBatch::order
+  int maxlen = 0;
+  int R = 0;
+  bool strips = false;        // queries longer than one 512-row strip
+  int64_t warm = 0;           // exactness margin in columns
+  bool fast = false;          // swept by the score kernel (else whole-matrix exact path)
+  int64_t chunk_len = 0;
 };
 
 int pick_R(int maxlen) {
@@ -187,11 +206,9 @@ int pick_R(int maxlen) {
   return 0;
 }
 
-FastPlan plan_fast(const RefData &ref, const QueryBatch &q, const mi355_sw_params &p, int64_t max_range_len) {
-  FastPlan f;
+ScoreTable plan_table(const RefData &ref, const mi355_sw_params &p) {
+  ScoreTable f;
   if (ref.ncodes > kMaxCodes) { f.why = "reference alphabet larger than the LDS profile budget"; return f; }
-  if (q.maxlen > kMaxRowsFast || q.maxlen < 1) { f.why = "query longer than 512 rows (strip-mined kernel not built yet)"; return f; }
-  f.R = pick_R(q.maxlen);
   const int nc = ref.ncodes;
   f.stab.assign((size_t)256 * nc, (int16_t)kPadScore);
   if (p.semantics == MI355_SW_U8SAT) {
@@ -209,27 +226,59 @@ FastPlan plan_fast(const RefData &ref, const QueryBatch &q, const mi355_sw_param
         const float s = lut_or(p, (uint8_t)a, ref.byte_of[c]);
         if (s != std::floor(s) || std::fabs(s) > 8000) { f.why = "substitution scores are not small integers"; return f; }
         f.stab[(size_t)a * nc + c] = (int16_t)s;
-        // only bytes that occur in some query matter for the bound, but 256 x nc is cheap
         smax = std::max(smax, (int)s);
       }
     f.gap = (int)g; f.smax = smax;
-    const int64_t rows = q.maxlen;
-    const int64_t bound = (int64_t)smax * std::min<int64_t>(rows, std::max<int64_t>(max_range_len, 1));
-    if (bound + smax > 32000) { f.why = "score bound exceeds the 16-bit cell range"; return f; }
   }
-  if (f.smax <= 0) { f.warm = 0; }
-  else {
-    // any positive-scoring path ending in a column spans < m + smax*m/gap columns
-    const int64_t m = q.maxlen;
-    f.warm = m + ((int64_t)f.smax * m + f.gap - 1) / f.gap;
-  }
-  f.warm = (f.warm + 3) / 4 * 4;
   f.ok = true;
   return f;
 }
 
+// Length classes of the batch: one bucket per kernel instance (R), plus one strip-mined bucket.
+std::vector<Bucket> make_buckets(const QueryBatch &q, const ScoreTable &t) {
+  std::vector<Bucket> out;
+  for (size_t pos = 0; pos < q.nq; ++pos) {
+    const int len = q.len[q.order[pos]];
+    const bool strips = len > kMaxRowsFast;
+    const int R = strips ? 32 : (len < 1 ? 2 : pick_R(len));
+    if (out.empty() || out.back().R != R || out.back().strips != strips) {
+      Bucket b;
+      b.first = (int)pos; b.R = R; b.strips = strips;
+      out.push_back(b);
+    }
+    out.back().count++;
+    out.back().maxlen = std::max(out.back().maxlen, len);
+  }
+  for (Bucket &b : out) {
+    if (t.smax <= 0 || t.gap <= 0) b.warm = 0;
+    else b.warm = (int64_t)b.maxlen + ((int64_t)t.smax * b.maxlen + t.gap - 1) / t.gap;
+    b.warm = (b.warm + 3) / 4 * 4;
+  }
+  return out;
+}
+
+// May this bucket's queries be swept by the score kernel over a reference range of n columns?
+bool bucket_fast_ok(const ScoreTable &t, const Bucket &b, int64_t n, const mi355_sw_params &p) {
+  if (!t.ok || n < 1 || b.maxlen < 1) return false;
+  // the uint8 engine's storage order is only bounded to a few tiles when the reference is the longer side;
+  // shorter references take the whole-matrix path (which also holds the |x| == |y| quirk)
+  if (p.semantics == MI355_SW_U8SAT && n <= (int64_t)b.maxlen + 1) return false;
+  if (p.semantics == MI355_SW_F32 && (int64_t)t.smax * std::min<int64_t>(b.maxlen, n) + t.smax > 32000) return false;
+  // strip-mining re-streams the range once per 512 rows: only worth it on long ranges
+  if (b.strips && n < 4096) return false;
+  // short references (UniProt shape: many sequences against one 144-residue query): one whole-matrix
+  // pass of the exact kernel does score + argmax + decisions at once; the tile machinery would idle
+  if (n < 1024) return false;
+  return true;
+}
+
 template <int SEM>
-int launch_score_R(int R, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
+int launch_score_R(int R, bool strips, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
+  if (strips) {
+    if (R != 32) return -1;
+    hipLaunchKernelGGL((sw_score_kernel<32, SEM, true>), grid, dim3(256), shmem, st, a);
+    return 0;
+  }
   switch (R) {
 #define CASE_R(r) case r: hipLaunchKernelGGL((sw_score_kernel<r, SEM>), grid, dim3(256), shmem, st, a); return 0;
     CASE_R(2) CASE_R(4) CASE_R(6) CASE_R(8) CASE_R(10) CASE_R(12) CASE_R(16) CASE_R(20) CASE_R(24) CASE_R(32)
@@ -240,77 +289,99 @@ int launch_score_R(int R, dim3 grid, size_t shmem, hipStream_t st, const ScoreAr
 
 int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm) {
   int64_t cl = 16384;
+  while (cl < 8 * warm) cl *= 2;                 // long queries: keep the warm-up redundancy bounded
   // fill the chip: 256 CUs x 32 waves x 4 slots; shrink tiles while they stay >> warm-up
   while (cl > 2048 && cl / 2 >= 4 * warm &&
          (double)npairs * (double)((max_range_len + cl - 1) / cl) < 65536.0) cl /= 2;
   return cl;
 }
 
-struct ScoreOut {
-  std::vector<unsigned long long> keys;   // [nranges][nq]
-  int64_t chunk_len = 0;
-  int64_t warm = 0;
-};
-
-// Score pass over all (query, range) pairs.  Device time is added to ctx->timings[0].
-int score_pass(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const std::vector<Range> &ranges,
-               const mi355_sw_params &p, const FastPlan &plan, ScoreOut &out) {
+// Uploads what every score launch of a call shares and clears the keys.
+int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range> &ranges, const ScoreTable &t) {
   const size_t nq = q.nq, nr = ranges.size();
-  int64_t maxlen = 0;
-  for (auto &r : ranges) maxlen = std::max(maxlen, r.hi - r.lo);
-  const size_t npairs = (nq + 1) / 2;
-  out.warm = plan.warm;
-  out.chunk_len = pick_chunk_len(maxlen, npairs * nr, plan.warm);
-  const int64_t cpr = (maxlen + out.chunk_len - 1) / out.chunk_len;
-  const int64_t cgroups = (cpr + 15) / 16;
-  if ((double)npairs * (double)cgroups > 2.0e9 || nr > 65535) return fail(ctx, MI355_SW_ENOTSUP, "grid too large");
-
+  if (nr > 32768) return fail(ctx, MI355_SW_ENOTSUP, "more than 32768 ranges per launch");
   std::vector<int64_t> rl(2 * nr);
   for (size_t k = 0; k < nr; ++k) { rl[k] = ranges[k].lo; rl[nr + k] = ranges[k].hi; }
-  if (ctx->ranges.ensure(rl.size() * 8) || ctx->keys.ensure(nq * nr * 8) || ctx->stab.ensure(plan.stab.size() * 2))
+  if (ctx->ranges.ensure(rl.size() * 8) || ctx->keys.ensure(nq * nr * 8) || ctx->stab.ensure(t.stab.size() * 2))
     return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
   HIPCHK(ctx, hipMemcpyAsync(ctx->ranges.p, rl.data(), rl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->stab.p, plan.stab.data(), plan.stab.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->stab.p, t.stab.data(), t.stab.size() * 2, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, nq * nr * 8, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // pageable staging buffers above go out of scope
+  return 0;
+}
+
+// One score-kernel launch: bucket b over all ranges.  Device time is added to ctx->timings[0].
+int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const std::vector<Range> &ranges,
+                 const mi355_sw_params &p, const ScoreTable &t, Bucket &b) {
+  const size_t nr = ranges.size();
+  int64_t maxlen = 0;
+  for (auto &r : ranges) maxlen = std::max(maxlen, r.hi - r.lo);
+  const size_t npairs = ((size_t)b.count + 1) / 2;
+  b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm);
+  const int64_t cpr = (maxlen + b.chunk_len - 1) / b.chunk_len;
+  const int64_t cgroups = (cpr + 15) / 16;
+  if ((double)npairs * (double)cgroups > 2.0e9) return fail(ctx, MI355_SW_ENOTSUP, "grid too large");
 
   ScoreArgs a;
   a.refcodes = ref.codes.as<uint8_t>();
   a.ref_len = (int64_t)ref.n;
   a.range_lo = ctx->ranges.as<int64_t>();
   a.range_hi = ctx->ranges.as<int64_t>() + nr;
-  a.chunk_len = out.chunk_len;
-  a.warm = plan.warm;
+  a.chunk_len = b.chunk_len;
+  a.warm = (cpr == 1) ? 0 : b.warm;              // a single tile per range starts at the range's own border
   a.chunks_per_range = (int)cpr;
   a.qbytes = q.bytes.as<uint8_t>();
+  a.qoff = q.offs.as<int64_t>();
   a.qlen = q.lens.as<int32_t>();
-  a.qstride = q.stride;
-  a.nq = (int)nq;
+  a.qsel = q.sel.as<int32_t>();
+  a.qfirst = b.first;
+  a.qcount = b.count;
+  a.nq = (int)q.nq;
   a.stab = ctx->stab.as<int16_t>();
   a.ncodes = ref.ncodes;
-  a.gap2 = (uint32_t)plan.gap * 0x00010001u;
+  a.gap2 = (uint32_t)t.gap * 0x00010001u;
   a.clamp2 = 255u * 0x00010001u;
   a.keys = ctx->keys.as<unsigned long long>();
 
-  const int LS = lane_stride(plan.R);
-  const size_t shmem = (size_t)ref.ncodes * kSlotLanes * LS * 4 + 16 * kCodeBuf;
+  const int LS = lane_stride(b.R);
+  size_t shmem = (size_t)ref.ncodes * kSlotLanes * LS * 4 + 16 * kCodeBuf;
   dim3 grid((unsigned)(npairs * cgroups), (unsigned)nr);
+  a.brow = nullptr;
+  a.brow_stride = 0;
+  if (b.strips) {
+    const int64_t nseg = (a.warm + b.chunk_len + kSlotLanes + kSeg - 1) / kSeg;
+    a.brow_stride = (nseg + 3) * kSeg + 32;
+    const size_t slots = (size_t)grid.x * grid.y * 16;
+    const size_t bytes = slots * 2 * (size_t)a.brow_stride * 4;
+    if (bytes > ((size_t)64 << 30)) return fail(ctx, MI355_SW_ENOTSUP, "strip-mined sweep needs more than 64 GiB of boundary scratch");
+    if (ctx->brow.ensure(bytes)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(strip boundary rows) failed");
+    HIPCHK(ctx, hipMemsetAsync(ctx->brow.p, 0, bytes, ctx->stream));
+    a.brow = ctx->brow.as<uint32_t>();
+    shmem += 2 * 16 * kSeg * 4;
+  }
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  int rc = (p.semantics == MI355_SW_U8SAT) ? launch_score_R<kSemU8>(plan.R, grid, shmem, ctx->stream, a)
-                                           : launch_score_R<kSemI16>(plan.R, grid, shmem, ctx->stream, a);
+  int rc = (p.semantics == MI355_SW_U8SAT) ? launch_score_R<kSemU8>(b.R, b.strips, grid, shmem, ctx->stream, a)
+                                           : launch_score_R<kSemI16>(b.R, b.strips, grid, shmem, ctx->stream, a);
   if (rc) return fail(ctx, MI355_SW_ENOTSUP, "no score kernel instance for this R");
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-  out.keys.resize(nq * nr);
-  HIPCHK(ctx, hipMemcpyAsync(out.keys.data(), ctx->keys.p, nq * nr * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
   float ms = 0;
   HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
   ctx->timings[0] += (double)ms * 1000.0;
   ctx->timings[4] += 1;
   double cells = 0;
-  for (size_t k = 0; k < nq; ++k)
-    for (auto &r : ranges) cells += (double)q.len[k] * (double)(r.hi - r.lo);
+  for (int k = 0; k < b.count; ++k)
+    for (auto &r : ranges) cells += (double)q.len[q.order[b.first + k]] * (double)(r.hi - r.lo);
   ctx->timings[5] += cells;
+  return 0;
+}
+
+int score_fetch(mi355_sw_ctx *ctx, size_t count, std::vector<unsigned long long> &keys) {
+  keys.resize(count);
+  HIPCHK(ctx, hipMemcpyAsync(keys.data(), ctx->keys.p, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }
 
@@ -370,7 +441,7 @@ int run_exact(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   for (size_t k = 0; k < n; ++k) {
     const ExactJob &j = jobs[lo + k];
     ExactProblem &e = pr[k];
-    e.x = q.bytes.as<uint8_t>() + (size_t)j.q * q.stride;
+    e.x = q.bytes.as<uint8_t>() + q.off[j.q];
     e.y = ref.bytes.as<uint8_t>() + j.ylo;
     e.m = q.len[j.q];
     e.nw = j.nw;
@@ -430,7 +501,7 @@ int run_walk(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const s
     const ExactJob &j = jobs[lo + k];
     WalkProblem &w = wp[k];
     const int cap = q.len[j.q] + j.nw + 2;
-    w.x = q.bytes.as<uint8_t>() + (size_t)j.q * q.stride;
+    w.x = q.bytes.as<uint8_t>() + q.off[j.q];
     w.y = ref.bytes.as<uint8_t>() + j.ylo;
     w.dirs = ctx->dirs.as<uint8_t>() + j.dirs_off;
     w.m = q.len[j.q]; w.nw = j.nw;
@@ -479,14 +550,13 @@ void set_result(mi355_sw_result &r, float score, int64_t ix, int64_t iy, const T
 
 // Traceback for located alignments of one range: windows left of the argmax, grown on demand.
 int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
-                  const mi355_sw_params &p, int64_t warm, bool whole_matrix_ok,
+                  const mi355_sw_params &p, const std::vector<int64_t> &qwarm,
                   const std::vector<int> &qidx, const std::vector<Located> &loc, std::vector<TraceOut> &tout) {
   tout.assign(qidx.size(), TraceOut());
   std::vector<size_t> todo;
   for (size_t k = 0; k < qidx.size(); ++k) if (loc[k].score > 0) todo.push_back(k);
   std::vector<int64_t> budget(qidx.size());
   for (size_t k : todo) budget[k] = 2 * (int64_t)q.len[qidx[k]] + 64;
-  (void)whole_matrix_ok;
   while (!todo.empty()) {
     // build jobs in memory-bounded groups
     std::vector<size_t> next;
@@ -501,6 +571,7 @@ int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, co
         const size_t k = todo[pos];
         const int qi = qidx[k];
         const int64_t iy = loc[k].iy;
+        const int64_t warm = qwarm[qi];
         int64_t wl = iy - (budget[k] + warm);           // range-relative 0-based start of window
         if (wl < 0) wl = 0;
         const int64_t nw = iy - wl;
@@ -586,29 +657,22 @@ int exact_full(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
   return 0;
 }
 
-bool range_fast_ok(const FastPlan &plan, const QueryBatch &q, const Range &rg, const mi355_sw_params &p) {
-  if (!plan.ok) return false;
-  const int64_t n = rg.hi - rg.lo;
-  if (n < 1) return false;
-  // the uint8 engine's storage order is only bounded to a few tiles when the reference is the
-  // longer side; shorter references take the whole-matrix path (which also holds the |x|==|y| quirk)
-  if (p.semantics == MI355_SW_U8SAT && n <= (int64_t)q.maxlen + 1) return false;
-  return true;
-}
-
-// Argmax cells for every query of the batch over one range, from the score pass' keys.
+// Argmax cells for the score-kernel queries (qfast[q] != 0) over one range, from the score pass' keys.
+// qchunk / qwarm: tile geometry of each query's bucket.
 int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
-                const mi355_sw_params &p, const ScoreOut &so, const unsigned long long *keys,
-                std::vector<Located> &loc) {
+                const mi355_sw_params &p, const std::vector<char> &qfast, const std::vector<int64_t> &qchunk,
+                const std::vector<int64_t> &qwarm, const unsigned long long *keys, std::vector<Located> &loc) {
   const size_t nq = q.nq;
   const int64_t n = rg.hi - rg.lo;
-  const int64_t nchunks = (n + so.chunk_len - 1) / so.chunk_len;
-  loc.assign(nq, Located());
   std::vector<ExactJob> jobs;
   for (size_t k = 0; k < nq; ++k) {
+    if (!qfast[k]) continue;
     const unsigned long long key = keys[k];
     const int score = (int)(key >> 32);
     if (score <= 0) continue;
+    const int64_t chunk_len = qchunk[k];
+    const int64_t nchunks = (n + chunk_len - 1) / chunk_len;
+    const int64_t warm = nchunks == 1 ? 0 : qwarm[k];
     const int64_t first = (int64_t)(0xFFFFFFFFull - (key & 0xFFFFFFFFull));
     loc[k].score = (float)score;
     int64_t cand[5];
@@ -626,9 +690,9 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
       }
     }
     for (int t = 0; t < nc; ++t) {
-      const int64_t own_lo = cand[t] * so.chunk_len;               // range-relative, 0-based
-      const int64_t own_hi = std::min(own_lo + so.chunk_len, n);
-      const int64_t wl = std::max<int64_t>(0, own_lo - so.warm);
+      const int64_t own_lo = cand[t] * chunk_len;               // range-relative, 0-based
+      const int64_t own_hi = std::min(own_lo + chunk_len, n);
+      const int64_t wl = std::max<int64_t>(0, own_lo - warm);
       ExactJob j;
       j.q = (int)k; j.ylo = rg.lo + wl; j.nw = (int32_t)(own_hi - wl); j.col_offset = wl; j.full_n = n;
       j.own_lo = (int32_t)(own_lo - wl + 1); j.quirk = 0; j.target = (float)score; j.want_dirs = false;
@@ -646,9 +710,16 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
     if (kk < bestkey[j.q]) { bestkey[j.q] = kk; loc[j.q].ix = j.ci; loc[j.q].iy = j.cj; }
   }
   for (size_t k = 0; k < nq; ++k)
-    if (loc[k].score > 0 && bestkey[k] == ~0ull)
+    if (qfast[k] && loc[k].score > 0 && bestkey[k] == ~0ull)
       return fail(ctx, MI355_SW_ENODEV, "internal: maximum of the score pass not found again by the exact kernel");
   return 0;
+}
+
+float elapsed_us(mi355_sw_ctx *ctx, hipEvent_t a, hipEvent_t b) {
+  float ms = 0;
+  if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0;
+  (void)ctx;
+  return ms * 1000.0f;
 }
 
 // All queries of `q` against one range of the reference.
@@ -656,54 +727,118 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
                 const mi355_sw_params &p, int flags, mi355_sw_result *outs) {
   const bool want_trace = !(flags & MI355_SW_SCORE_ONLY);
   const size_t nq = q.nq;
+  const int64_t n = rg.hi - rg.lo;
   HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-  std::vector<Located> loc;
-  std::vector<TraceOut> tout;
-  FastPlan plan = plan_fast(ref, q, p, rg.hi - rg.lo);
-  std::vector<int> all(nq);
-  for (size_t k = 0; k < nq; ++k) all[k] = (int)k;
-  if (rg.hi - rg.lo < 1) {
-    loc.assign(nq, Located()); tout.assign(nq, TraceOut());
-  } else if (range_fast_ok(plan, q, rg, p)) {
-    ScoreOut so;
-    int rc = score_pass(ctx, ref, q, std::vector<Range>{rg}, p, plan, so);
-    if (rc) return rc;
-    HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-    rc = locate_fast(ctx, ref, q, rg, p, so, so.keys.data(), loc);
-    if (rc) return rc;
-    HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-    HIPCHK(ctx, hipEventSynchronize(ctx->ev[3]));
-    float ms = 0;
-    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
-    ctx->timings[1] += (double)ms * 1000.0;
-    if (want_trace) {
+  std::vector<Located> loc(nq);
+  std::vector<TraceOut> tout(nq);
+  if (n >= 1 && nq > 0) {
+    const ScoreTable table = plan_table(ref, p);
+    std::vector<Bucket> buckets = make_buckets(q, table);
+    std::vector<char> qfast(nq, 0);
+    std::vector<int64_t> qchunk(nq, 0), qwarm(nq, 0);
+    bool any_fast = false;
+    for (Bucket &b : buckets) { b.fast = bucket_fast_ok(table, b, n, p); any_fast |= b.fast; }
+    if (any_fast) {
+      const std::vector<Range> ranges{rg};
+      int rc = score_begin(ctx, q, ranges, table);
+      if (rc) return rc;
+      for (Bucket &b : buckets) {
+        if (!b.fast) continue;
+        rc = score_launch(ctx, ref, q, ranges, p, table, b);
+        if (rc) return rc;
+        for (int k = 0; k < b.count; ++k) {
+          const int id = q.order[b.first + k];
+          qfast[id] = 1; qchunk[id] = b.chunk_len; qwarm[id] = b.warm;
+        }
+      }
+      std::vector<unsigned long long> keys;
+      rc = score_fetch(ctx, nq, keys);
+      if (rc) return rc;
       HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-      rc = trace_located(ctx, ref, q, rg, p, so.warm, true, all, loc, tout);
+      rc = locate_fast(ctx, ref, q, rg, p, qfast, qchunk, qwarm, keys.data(), loc);
       if (rc) return rc;
       HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-      HIPCHK(ctx, hipEventSynchronize(ctx->ev[3]));
-      HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
-      ctx->timings[2] += (double)ms * 1000.0;
-    } else tout.assign(nq, TraceOut());
-  } else {
-    HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-    int rc = exact_full(ctx, ref, q, rg, p, all, want_trace, loc, tout);
-    if (rc) { if (!plan.ok && ctx->err.find("outside its coverage") != std::string::npos) ctx->err += " (" + plan.why + ")"; return rc; }
-    HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-    HIPCHK(ctx, hipEventSynchronize(ctx->ev[3]));
-    float ms = 0;
-    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
-    ctx->timings[2] += (double)ms * 1000.0;
+      ctx->timings[1] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
+      if (want_trace) {
+        std::vector<int> fq;
+        std::vector<Located> floc;
+        for (size_t k = 0; k < nq; ++k) if (qfast[k]) { fq.push_back((int)k); floc.push_back(loc[k]); }
+        std::vector<TraceOut> ft;
+        HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+        rc = trace_located(ctx, ref, q, rg, p, qwarm, fq, floc, ft);
+        if (rc) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+        ctx->timings[2] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
+        for (size_t t = 0; t < fq.size(); ++t) tout[fq[t]] = ft[t];
+      }
+    }
+    std::vector<int> slow;
+    for (size_t k = 0; k < nq; ++k) if (!qfast[k]) slow.push_back((int)k);
+    if (!slow.empty()) {
+      std::vector<Located> sl;
+      std::vector<TraceOut> st;
+      HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+      int rc = exact_full(ctx, ref, q, rg, p, slow, want_trace, sl, st);
+      if (rc) {
+        if (!table.ok && ctx->err.find("outside its coverage") != std::string::npos) ctx->err += " (" + table.why + ")";
+        return rc;
+      }
+      HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+      ctx->timings[2] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
+      for (size_t t = 0; t < slow.size(); ++t) { loc[slow[t]] = sl[t]; tout[slow[t]] = st[t]; }
+    }
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
-  HIPCHK(ctx, hipEventSynchronize(ctx->ev[5]));
-  float ms = 0;
-  HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
-  ctx->timings[3] += (double)ms * 1000.0;
+  ctx->timings[3] += elapsed_us(ctx, ctx->ev[4], ctx->ev[5]);
   for (size_t k = 0; k < nq; ++k) {
     set_result(outs[k], loc[k].score, loc[k].ix, loc[k].iy, (want_trace && loc[k].score > 0) ? &tout[k] : nullptr);
     outs[k].timings_us[0] = (float)(ctx->timings[0] > 0 ? ctx->timings[0] : ctx->timings[3]);
     outs[k].timings_us[1] = 0;
+  }
+  return 0;
+}
+
+// Per-range maxima of every query (value half of find_index_of_maximum per piece).
+int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const std::vector<Range> &ranges,
+                 const mi355_sw_params &p, float *maxima /* [nranges][nq] */) {
+  const size_t nq = q.nq, nr = ranges.size();
+  if (nq == 0 || nr == 0) return 0;
+  const ScoreTable table = plan_table(ref, p);
+  std::vector<Bucket> buckets = make_buckets(q, table);
+  std::vector<char> qfast(nq, 0);
+  for (Bucket &b : buckets) {
+    b.fast = true;
+    for (auto &r : ranges) b.fast = b.fast && bucket_fast_ok(table, b, r.hi - r.lo, p);
+  }
+  for (size_t lo = 0; lo < nr; lo += 32768) {
+    const size_t hi = std::min(nr, lo + 32768);
+    const std::vector<Range> sub(ranges.begin() + lo, ranges.begin() + hi);
+    bool any = false;
+    for (Bucket &b : buckets) any |= b.fast;
+    if (!any) break;
+    int rc = score_begin(ctx, q, sub, table);
+    if (rc) return rc;
+    for (Bucket &b : buckets) {
+      if (!b.fast) continue;
+      rc = score_launch(ctx, ref, q, sub, p, table, b);
+      if (rc) return rc;
+      for (int k = 0; k < b.count; ++k) qfast[q.order[b.first + k]] = 1;
+    }
+    std::vector<unsigned long long> keys;
+    rc = score_fetch(ctx, nq * sub.size(), keys);
+    if (rc) return rc;
+    for (size_t r = 0; r < sub.size(); ++r)
+      for (size_t k = 0; k < nq; ++k)
+        if (qfast[k]) maxima[(lo + r) * nq + k] = (float)(keys[r * nq + k] >> 32);
+  }
+  std::vector<int> slow;
+  for (size_t k = 0; k < nq; ++k) if (!qfast[k]) slow.push_back((int)k);
+  for (size_t r = 0; r < nr && !slow.empty(); ++r) {
+    std::vector<Located> loc;
+    std::vector<TraceOut> t;
+    int rc = exact_full(ctx, ref, q, ranges[r], p, slow, false, loc, t);
+    if (rc) return rc;
+    for (size_t i = 0; i < slow.size(); ++i) maxima[r * nq + slow[i]] = loc[i].score;
   }
   return 0;
 }
@@ -750,7 +885,7 @@ void mi355_sw_destroy(mi355_sw_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   DevBuf *bufs[] = {&c->ref.bytes, &c->ref.codes, &c->batch.bytes, &c->batch.lens, &c->keys, &c->ranges, &c->stab,
-                    &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat};
+                    &c->batch.offs, &c->batch.sel, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow};
   for (DevBuf *b : bufs) b->release();
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -802,7 +937,7 @@ int mi355_sw_align(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, s
   rc = upload_reference(ctx, ref, y, ny);
   if (!rc) rc = upload_queries(ctx, q, 1, &x, &nx);
   if (!rc) rc = align_range(ctx, ref, q, Range{0, (int64_t)ny}, *params, 0, out);
-  ref.bytes.release(); ref.codes.release(); q.bytes.release(); q.lens.release();
+  ref.bytes.release(); ref.codes.release(); q.release();
   return rc;
 }
 
@@ -819,7 +954,7 @@ int mi355_sw_argmax(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, 
   rc = upload_reference(ctx, ref, y, ny);
   if (!rc) rc = upload_queries(ctx, q, 1, &x, &nx);
   if (!rc) rc = align_range(ctx, ref, q, Range{0, (int64_t)ny}, *params, MI355_SW_SCORE_ONLY, &r);
-  ref.bytes.release(); ref.codes.release(); q.bytes.release(); q.lens.release();
+  ref.bytes.release(); ref.codes.release(); q.release();
   if (rc) return rc;
   if (index_x) *index_x = r.end_x;
   if (index_y) *index_y = r.end_y;
@@ -869,24 +1004,9 @@ int mi355_sw_align_split(mi355_sw_ctx *ctx, const char *x, size_t nx, const char
     mi355_sw_params ps = *params;
     ps.semantics = sm_semantics;
     std::vector<Range> ranges(npiece);
-    int64_t maxlen = 0;
-    for (int k = 0; k < npiece; ++k) { ranges[k] = Range{lefts[k], rights[k]}; maxlen = std::max(maxlen, rights[k] - lefts[k]); }
-    FastPlan plan = plan_fast(ref, q, ps, maxlen);
-    bool all_fast = plan.ok;
-    for (auto &r : ranges) all_fast = all_fast && range_fast_ok(plan, q, r, ps);
+    for (int k = 0; k < npiece; ++k) ranges[k] = Range{lefts[k], rights[k]};
     std::vector<float> pmax(npiece, 0.0f);
-    if (all_fast) {
-      ScoreOut so;
-      rc = score_pass(ctx, ref, q, ranges, ps, plan, so);
-      if (!rc) for (int k = 0; k < npiece; ++k) pmax[k] = (float)(so.keys[k] >> 32);
-    } else {
-      for (int k = 0; k < npiece && !rc; ++k) {
-        std::vector<Located> loc;
-        std::vector<TraceOut> t;
-        rc = exact_full(ctx, ref, q, ranges[k], ps, std::vector<int>{0}, false, loc, t);
-        if (!rc) pmax[k] = loc[0].score;
-      }
-    }
+    rc = range_maxima(ctx, ref, q, ranges, ps, pmax.data());
     if (!rc) {
       float best = -1.0f;                                  // plocalaligner.cpp:106,122-129
       for (int k = 0; k < npiece; ++k) if (pmax[k] > best) { best = pmax[k]; bp = k; }
@@ -904,7 +1024,7 @@ int mi355_sw_align_split(mi355_sw_ctx *ctx, const char *x, size_t nx, const char
     }
   }
   if (winning_piece) *winning_piece = bp;
-  ref.bytes.release(); ref.codes.release(); q.bytes.release(); q.lens.release();
+  ref.bytes.release(); ref.codes.release(); q.release();
   return rc;
 }
 
@@ -924,29 +1044,8 @@ int mi355_sw_score_ranges(mi355_sw_ctx *ctx, size_t nranges, const int64_t *left
     ranges[k] = Range{lefts[k], rights[k]};
     maxlen = std::max(maxlen, rights[k] - lefts[k]);
   }
-  FastPlan plan = plan_fast(ctx->ref, q, *params, maxlen);
-  bool all_fast = plan.ok;
-  for (auto &r : ranges) all_fast = all_fast && range_fast_ok(plan, q, r, *params);
-  if (all_fast) {
-    for (size_t lo = 0; lo < nranges; lo += 32768) {          // grid.y limit
-      const size_t hi = std::min(nranges, lo + 32768);
-      ScoreOut so;
-      rc = score_pass(ctx, ctx->ref, q, std::vector<Range>(ranges.begin() + lo, ranges.begin() + hi), *params, plan, so);
-      if (rc) return rc;
-      for (size_t k = 0; k < (hi - lo) * q.nq; ++k) maxima[lo * q.nq + k] = (float)(so.keys[k] >> 32);
-    }
-    return 0;
-  }
-  std::vector<int> all(q.nq);
-  for (size_t k = 0; k < q.nq; ++k) all[k] = (int)k;
-  for (size_t k = 0; k < nranges; ++k) {
-    std::vector<Located> loc;
-    std::vector<TraceOut> t;
-    rc = exact_full(ctx, ctx->ref, q, ranges[k], *params, all, false, loc, t);
-    if (rc) return rc;
-    for (size_t i = 0; i < q.nq; ++i) maxima[k * q.nq + i] = loc[i].score;
-  }
-  return 0;
+  (void)maxlen;
+  return range_maxima(ctx, ctx->ref, q, ranges, *params, maxima);
 }
 
 int mi355_sw_fill_matrix(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, size_t ny,
@@ -975,7 +1074,7 @@ int mi355_sw_fill_matrix(mi355_sw_ctx *ctx, const char *x, size_t nx, const char
     rc = run_exact(ctx, ref, q, *params, jobs, 0, 1, ctx->hmat.as<float>());
   }
   if (!rc && hipMemcpy(H, ctx->hmat.p, cells * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, MI355_SW_ENODEV, "hipMemcpy(matrix) failed");
-  ref.bytes.release(); ref.codes.release(); q.bytes.release(); q.lens.release();
+  ref.bytes.release(); ref.codes.release(); q.release();
   return rc;
 }
 

@@ -54,15 +54,21 @@ struct ScoreArgs {
   int64_t chunk_len;         // own columns per tile
   int64_t warm;              // warm-up columns recomputed in front of a tile
   int chunks_per_range;      // max over ranges
-  const uint8_t *qbytes;     // [nq][qstride] raw query bytes
+  const uint8_t *qbytes;     // concatenated raw query bytes
+  const int64_t *qoff;       // [nq] byte offset of each query
   const int32_t *qlen;       // [nq]
-  int qstride;
-  int nq;
+  const int32_t *qsel;       // [nq] query ids sorted by length; this launch sweeps qsel[qfirst .. qfirst+qcount)
+  int qfirst, qcount;
+  int nq;                    // total queries (row length of keys)
   const int16_t *stab;       // [256][ncodes] score(query byte, reference code); column ncodes-1 = pad
   int ncodes;
   uint32_t gap2;             // gap penalty in both halves
   uint32_t clamp2;           // 255 in both halves (U8SAT)
   unsigned long long *keys;  // [nranges][nq]  (max << 32) | (0xFFFFFFFF - chunk)
+  // strip-mined variant only (queries longer than 16*R rows): boundary rows between strips,
+  // two ping-pong buffers of brow_stride dwords per tile, 16 dwords of front padding each
+  uint32_t *brow;
+  int64_t brow_stride;
 };
 
 __device__ __forceinline__ uint32_t as_u32(i16x2 v) { return __builtin_bit_cast(uint32_t, v); }
@@ -75,7 +81,11 @@ __device__ __forceinline__ uint32_t row_shr1(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
 }
 
-template <int R, int SEM>
+// STRIPS = false: the whole query (<= 16*R rows) is one strip held in registers.
+// STRIPS = true : the query is swept in strips of 16*R rows; the bottom row of strip s over the tile's
+// columns goes through a per-tile global scratch row (L2-resident) and enters strip s+1 through the
+// DPP `old` operand of lane 0, where the single-strip kernel gets the zero border row.
+template <int R, int SEM, bool STRIPS = false>
 __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   static_assert(R % 2 == 0, "running max is folded on odd rows: R must be even");
   constexpr int LS = lane_stride(R);
@@ -83,6 +93,8 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t *prof = smem;                                           // [ncodes][16][LS]
   uint8_t *codebuf = reinterpret_cast<uint8_t *>(smem + a.ncodes * kSlotLanes * LS);
+  // STRIPS: [16 slots][64] boundary-in window, then [16 slots][64] boundary-out staging
+  uint32_t *bwin = reinterpret_cast<uint32_t *>(codebuf + 16 * kCodeBuf);
 
   const int tid = threadIdx.x;
   const int l16 = tid & 15;
@@ -91,26 +103,27 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   const int pair = blockIdx.x / cgroups;
   const int cg = blockIdx.x - pair * cgroups;
   const int range = blockIdx.y;
-  const int qA = 2 * pair;
-  const bool hasB = (qA + 1) < a.nq;
-  const int qB = hasB ? qA + 1 : qA;
+  const bool hasB = (2 * pair + 1) < a.qcount;
+  const int qA = a.qsel[a.qfirst + 2 * pair];
+  const int qB = hasB ? a.qsel[a.qfirst + 2 * pair + 1] : qA;
 
-  // ---- query profile for this workgroup's pair -------------------------------------------
-  {
-    const int mA = a.qlen[qA], mB = a.qlen[qB];
-    const uint8_t *xA = a.qbytes + (size_t)qA * a.qstride;
-    const uint8_t *xB = a.qbytes + (size_t)qB * a.qstride;
+  // ---- query profile for this workgroup's pair (rows row0 .. row0 + 16R - 1) ---------------
+  const int mA = a.qlen[qA], mB = a.qlen[qB];
+  auto build_profile = [&](int row0) {
+    const uint8_t *xA = a.qbytes + a.qoff[qA];
+    const uint8_t *xB = a.qbytes + a.qoff[qB];
     const int per_code = kSlotLanes * R;
     for (int e = tid; e < a.ncodes * per_code; e += 256) {
       const int c = e / per_code;
       const int rem = e - c * per_code;
       const int ll = rem / R, r = rem - ll * R;
-      const int i = ll * R + r;
+      const int i = row0 + ll * R + r;
       const int sa = (i < mA) ? a.stab[(int)xA[i] * a.ncodes + c] : kPadScore;
       const int sb = (i < mB) ? a.stab[(int)xB[i] * a.ncodes + c] : kPadScore;
       prof[(c * kSlotLanes + ll) * LS + r] = (uint32_t)(uint16_t)sa | ((uint32_t)(uint16_t)sb << 16);
     }
-  }
+  };
+  build_profile(0);
 
   // ---- this slot's tile -------------------------------------------------------------------
   const int64_t rlo = a.range_lo[range], rhi = a.range_hi[range];
@@ -145,55 +158,104 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   const int64_t total_steps = a.warm + a.chunk_len + kSlotLanes;   // +15 skew, +1 max-fold drain
   const int nseg = (int)((total_steps + kSeg - 1) / kSeg);
 
-  uint32_t nextcodes = stage_load(0);
-  if (l16 < kHist / 4) buf32[l16] = pad4;
-  buf32[kHist / 4 + l16] = nextcodes;
-  nextcodes = stage_load(1);
-  __syncthreads();                                                 // profile + first window ready
-
-  i16x2 H[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) H[r] = as_i16x2(0u);
   i16x2 mx = as_i16x2(0u);
-  uint32_t up_prev = 0;
   const u16x2 gap = __builtin_bit_cast(u16x2, a.gap2);
   const i16x2 clampv = as_i16x2(a.clamp2);
   const int code_stride = kSlotLanes * LS;                         // dwords per reference code
+  const int strip_rows = kSlotLanes * R;
+  const int mmax = mA > mB ? mA : mB;
+  const int nstrips = STRIPS ? (mmax + strip_rows - 1) / strip_rows : 1;
+  // STRIPS: this tile's ping-pong boundary rows (global), and its LDS windows
+  const size_t tile_id = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + slot;
+  uint32_t *brow0 = STRIPS ? a.brow + tile_id * 2 * (size_t)a.brow_stride : nullptr;
+  uint32_t *bin_w = bwin + slot * kSeg;
+  uint32_t *bout_w = bwin + 16 * kSeg + slot * kSeg;
 
-  for (int seg = 0; seg < nseg; ++seg) {
+  for (int strip = 0; strip < nstrips; ++strip) {
+    if (STRIPS && strip > 0) {
+      // the boundary row written by this tile's own lanes in the previous strip is re-read below:
+      // drain the stores, invalidate this CU's L1 (it may hold the row's lines from two strips ago)
+      __threadfence();
+      __syncthreads();                                             // everyone done with the old profile
+      build_profile(strip * strip_rows);
+    }
+    const uint32_t *bin_g = STRIPS ? brow0 + (size_t)(strip & 1) * a.brow_stride + 16 : nullptr;
+    uint32_t *bout_g = STRIPS ? brow0 + (size_t)((strip + 1) & 1) * a.brow_stride + 16 : nullptr;
+    const bool rd = STRIPS && strip > 0, wr = STRIPS && strip + 1 < nstrips;
+    auto bin_load = [&](int seg) -> uint4 {                       // boundary values of stream positions seg*64+4*l16..+3
+      return rd ? *reinterpret_cast<const uint4 *>(bin_g + (size_t)seg * kSeg + 4 * l16) : make_uint4(0, 0, 0, 0);
+    };
+
+    uint32_t nextcodes = stage_load(0);
+    if (l16 < kHist / 4) buf32[l16] = pad4;
+    buf32[kHist / 4 + l16] = nextcodes;
+    nextcodes = stage_load(1);
+    uint4 nextb = make_uint4(0, 0, 0, 0);
+    if (STRIPS) {
+      *reinterpret_cast<uint4 *>(bin_w + 4 * l16) = bin_load(0);
+      nextb = bin_load(1);
+    }
+    __syncthreads();                                               // profile + first window ready
+
+    i16x2 H[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) H[r] = as_i16x2(0u);
+    uint32_t up_prev = 0;
+
+    for (int seg = 0; seg < nseg; ++seg) {
 #pragma unroll 8
-    for (int k = 0; k < kSeg; ++k) {
-      const uint32_t c = buf_lane[k];
-      const uint4 *pp = reinterpret_cast<const uint4 *>(prof_lane + c * code_stride);
-      uint32_t p[NQ4 * 4];
+      for (int k = 0; k < kSeg; ++k) {
+        const uint32_t c = buf_lane[k];
+        const uint4 *pp = reinterpret_cast<const uint4 *>(prof_lane + c * code_stride);
+        uint32_t p[NQ4 * 4];
 #pragma unroll
-      for (int q = 0; q < NQ4; ++q) {
-        const uint4 v = pp[q];
-        p[4 * q + 0] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+        for (int q = 0; q < NQ4; ++q) {
+          const uint4 v = pp[q];
+          p[4 * q + 0] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+        }
+        uint32_t up;                                               // H(i0-1, j) of the lane above
+        if (STRIPS) {
+          // lane 0 takes the previous strip's bottom row through the DPP `old` operand
+          up = (uint32_t)__builtin_amdgcn_update_dpp((int)bin_w[k], (int)as_u32(H[R - 1]), 0x111, 0xf, 0xf, false);
+        } else {
+          up = row_shr1(as_u32(H[R - 1]));
+        }
+        i16x2 diag = as_i16x2(up_prev);                            // H(i0-1, j-1)
+        i16x2 north = as_i16x2(up);
+        up_prev = up;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const i16x2 w = H[r];
+          i16x2 x = diag + as_i16x2(p[r]);
+          if (SEM == kSemU8) x = __builtin_elementwise_min(x, clampv);
+          const i16x2 t = __builtin_elementwise_max(w, north);
+          if (r & 1) mx = __builtin_elementwise_max(mx, t);
+          const i16x2 y = to_i16x2(__builtin_elementwise_sub_sat(as_u16x2(t), gap));
+          const i16x2 h = __builtin_elementwise_max(x, y);
+          diag = w;
+          H[r] = h;
+          north = h;
+        }
+        if (STRIPS) {
+          if (l16 == 15) bout_w[k] = as_u32(H[R - 1]);             // bottom row at stream position seg*64+k-15
+        }
       }
-      const uint32_t up = row_shr1(as_u32(H[R - 1]));              // H(i0-1, j) of the lane above
-      i16x2 diag = as_i16x2(up_prev);                              // H(i0-1, j-1)
-      i16x2 north = as_i16x2(up);
-      up_prev = up;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const i16x2 w = H[r];
-        i16x2 x = diag + as_i16x2(p[r]);
-        if (SEM == kSemU8) x = __builtin_elementwise_min(x, clampv);
-        const i16x2 t = __builtin_elementwise_max(w, north);
-        if (r & 1) mx = __builtin_elementwise_max(mx, t);
-        const i16x2 y = to_i16x2(__builtin_elementwise_sub_sat(as_u16x2(t), gap));
-        const i16x2 h = __builtin_elementwise_max(x, y);
-        diag = w;
-        H[r] = h;
-        north = h;
+      // slide the code window: keep the last 16 bytes as history, append the prefetched segment
+      const uint32_t hist = buf32[kSeg / 4 + (l16 & 3)];
+      if (l16 < kHist / 4) buf32[l16] = hist;
+      buf32[kHist / 4 + l16] = nextcodes;
+      nextcodes = stage_load(seg + 2);
+      if (STRIPS) {
+        if (wr) {
+          // flush 64 bottom-row values: positions seg*64 - 15 + (0..63)
+          uint32_t *g = bout_g + (int64_t)seg * kSeg - 15 + 4 * l16;
+          const uint4 v = *reinterpret_cast<const uint4 *>(bout_w + 4 * l16);
+          g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
+        }
+        *reinterpret_cast<uint4 *>(bin_w + 4 * l16) = nextb;
+        nextb = bin_load(seg + 2);
       }
     }
-    // slide the code window: keep the last 16 bytes as history, append the prefetched segment
-    const uint32_t hist = buf32[kSeg / 4 + (l16 & 3)];
-    if (l16 < kHist / 4) buf32[l16] = hist;
-    buf32[kHist / 4 + l16] = nextcodes;
-    nextcodes = stage_load(seg + 2);
   }
 
   // ---- per-tile maximum -> per-query key -------------------------------------------------

@@ -184,3 +184,36 @@ def test_score_ranges_and_ref_sharding(ctx, oracle, pgs):
         assert piece == exp["piece"]
         for k in ("score", "pos", "cons_x", "cons_y"):
             assert res[k] == exp[k], (sm, la, npiece, k)
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+def test_long_queries_strip_mined(ctx, oracle, pgs, sem):
+    """Queries longer than one 512-row strip (config-5 shape at oracle-sized reference): the strip-mined
+    score kernel hands the bottom row of each strip to the next one through global scratch."""
+    ref = pgs.synth.dna(61, 120_000)
+    refb = ref.tobytes()
+    for k, m in enumerate((512, 513, 700, 1500, 2100)):
+        q, off = pgs.synth.read_from_ref(ref, 700 + k, m, sub_rate=0.02, indel_rate=0.005)
+        exp = oracle.align(q.tobytes(), refb, sem)
+        _cmp(ctx.align(q, refb, sem), exp, "long m=%d sem=%d" % (m, sem))
+    # a batch mixing short and long queries runs entirely on the strip-mined instance
+    qs = [pgs.synth.read_from_ref(ref, 900 + k, m)[0].tobytes() for k, m in enumerate((100, 1300, 150, 600, 40))]
+    for q, got in zip(qs, ctx.align_batch(qs, refb, semantics=sem)):
+        _cmp(got, oracle.align(q, refb, sem), "mixed batch sem=%d |q|=%d" % (sem, len(q)))
+
+
+def test_config5_shape_reduced(ctx, oracle, pgs):
+    """Config 5 at reduced reference: one 10 kbp query, reference split with overlap = 2x query
+    (OMPParallelLocalAligner), against the oracle's serial split aligner; and whole-reference == split."""
+    ref = pgs.synth.dna(6, 400_000)
+    q, off = pgs.synth.read_from_ref(ref, 7, 10_000, sub_rate=0.01, indel_rate=0.001)
+    qb, refb = q.tobytes(), ref.tobytes()
+    whole = ctx.align(qb, refb, 0)
+    assert whole["score"] == oracle.score_only(qb, refb, 0)
+    assert abs(whole["pos"] - (off + 1)) < 200
+    got = ctx.align_split(qb, refb, 4, 2.0, 0, 0)
+    assert got["score"] == whole["score"] and got["pos"] == whole["pos"] and got["cons_x"] == whole["cons_x"]
+    # exact check of score + argmax on a size the float32 oracle can hold (10 kbp x 60 kbp = 2.4 GB)
+    sub = refb[max(0, off - 20_000):off + 40_000]
+    exp = oracle.align(qb, sub, 0)
+    _cmp(ctx.align(qb, sub, 0), exp, "cfg5 reduced")
