@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--semantics", choices=["f32", "u8"], default="f32")
     ap.add_argument("--score-only", action="store_true", help="skip the traceback (diagnostic; not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (rehearsal: ranks may share GPU 0)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,12 +120,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())   # rehearsal on fewer GPUs than ranks
+    torch.cuda.set_device(local_rank)
+    cdev = "cuda" if args.dist_backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     pgs = load_package()
     sem = pgs.F32 if args.semantics == "f32" else pgs.U8SAT
@@ -140,7 +145,7 @@ def main():
         out = ctx.batch_run(semantics=sem, flags=flags, raw=True)
         best = int(out["score"].max()) << 32 | (0xFFFFFFFF - (int(out["score"].argmax()) + rank * args.reads))
         if dist is not None:
-            t = torch.tensor([best], dtype=torch.int64, device="cuda")
+            t = torch.tensor([best], dtype=torch.int64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)                      # per-rank best (score, read) over xGMI
             best = int(t.item())
         return out, best
@@ -170,7 +175,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

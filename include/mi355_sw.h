@@ -121,6 +121,12 @@ int mi355_sw_score_ranges(mi355_sw_ctx *ctx, size_t nranges, const int64_t *left
 int mi355_sw_make_string_range(int npiece, int64_t shortlen, int64_t longlen, float overlap_ratio,
                                int64_t *lefts, int64_t *rights);
 
+/* Host-only helpers: Similarity_Matrix_Skewed::trueindex2rawindex / rawindex2trueindex
+ * (similaritymatrix.cpp:330-346, :353-364) for a matrix built from (x of length nx, y of length ny);
+ * indices are in the skewed class's INTERNAL coordinates (ti = column of y, tj = row of x). */
+void mi355_sw_true2raw(size_t nx, size_t ny, size_t ti, size_t tj, size_t *ri, size_t *rj);
+void mi355_sw_raw2true(size_t nx, size_t ny, size_t ri, size_t rj, size_t *ti, size_t *tj);
+
 /* Full matrix on the device, copied out as float, column-major over y:
  * H[j*(nx+1) + i] = matrix(i, j), i = 0..nx, j = 0..ny.  For small problems (tests, operator()). */
 int mi355_sw_fill_matrix(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, size_t ny,

@@ -127,6 +127,17 @@ class Similarity_Matrix_HIP : public Abstract_Similarity_Matrix {
     }
   }
   Timings getTimings() const override { return timings; }
+  // skewed index maps (similaritymatrix.cpp:330-369); meaningful for the uint8 engine's storage order
+  index_tuple rawindex2trueindex(index_tuple raw_index) const {
+    size_t a, b;
+    mi355_sw_raw2true(sequence_x.size(), sequence_y.size(), (size_t)raw_index.first, (size_t)raw_index.second, &a, &b);
+    return index_tuple((Index)a, (Index)b);
+  }
+  index_tuple trueindex2rawindex(index_tuple true_index) const {
+    size_t a, b;
+    mi355_sw_true2raw(sequence_x.size(), sequence_y.size(), (size_t)true_index.first, (size_t)true_index.second, &a, &b);
+    return index_tuple((Index)a, (Index)b);
+  }
   // used by SWAligner to publish what its own device call already computed
   void set_result(Index ix, Index iy, float mx, float iterate_us, std::shared_ptr<std::vector<float>> l, float g) {
     max_x = ix; max_y = iy; max_v = mx; timings.v[0] = iterate_us; lut = std::move(l); gap = g; cells.clear(); iterated = true;

@@ -15,7 +15,7 @@ EXPORTS = [
     "mi355_sw_create", "mi355_sw_destroy", "mi355_sw_last_error", "mi355_sw_default_params",
     "mi355_sw_align", "mi355_sw_set_reference", "mi355_sw_align_batch", "mi355_sw_batch_upload",
     "mi355_sw_batch_run", "mi355_sw_score_ranges", "mi355_sw_align_split", "mi355_sw_make_string_range", "mi355_sw_fill_matrix",
-    "mi355_sw_argmax", "mi355_sw_last_timings", "mi355_sw_free_result", "mi355_sw_free_results",
+    "mi355_sw_argmax", "mi355_sw_true2raw", "mi355_sw_raw2true", "mi355_sw_last_timings", "mi355_sw_free_result", "mi355_sw_free_results",
     "mi355_sw_build_info",
 ]
 
@@ -207,3 +207,15 @@ def make_string_range(npiece, shortlen, longlen, ratio):
     if rc:
         return None
     return [(int(lefts[k]), int(rights[k])) for k in range(npiece)]
+
+
+def true2raw(nx, ny, ti, tj):
+    ri, rj = C.c_size_t(), C.c_size_t()
+    lib().mi355_sw_true2raw(C.c_size_t(nx), C.c_size_t(ny), C.c_size_t(ti), C.c_size_t(tj), C.byref(ri), C.byref(rj))
+    return ri.value, rj.value
+
+
+def raw2true(nx, ny, ri, rj):
+    ti, tj = C.c_size_t(), C.c_size_t()
+    lib().mi355_sw_raw2true(C.c_size_t(nx), C.c_size_t(ny), C.c_size_t(ri), C.c_size_t(rj), C.byref(ti), C.byref(tj))
+    return ti.value, tj.value

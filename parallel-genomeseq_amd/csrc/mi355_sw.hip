@@ -1078,6 +1078,26 @@ int mi355_sw_fill_matrix(mi355_sw_ctx *ctx, const char *x, size_t nx, const char
   return rc;
 }
 
+void mi355_sw_true2raw(size_t nx, size_t ny, size_t ti, size_t tj, size_t *ri, size_t *rj) {
+  // similaritymatrix.cpp:353-364 with len_x = |y|+1, len_y = |x|+1 (constructor swap, :274-285)
+  const size_t len_x = ny + 1, len_y = nx + 1;
+  const size_t nrows = std::min(len_x, len_y), ncols = std::max(len_x, len_y);
+  if (ti + tj < nrows - 1) { *ri = ti; *rj = ti + tj; }
+  else if (ti + tj > ncols - 1) { *ri = ti - ncols + len_y; *rj = ti + tj - (ncols - 1) - 1; }
+  else { *ri = (len_x <= len_y) ? ti : len_y - 1 - tj; *rj = ti + tj; }
+}
+
+void mi355_sw_raw2true(size_t nx, size_t ny, size_t ri, size_t rj, size_t *ti, size_t *tj) {
+  // similaritymatrix.cpp:330-346
+  const size_t len_x = ny + 1, len_y = nx + 1;
+  const size_t nrows = std::min(len_x, len_y);
+  if (rj < nrows - 1) {
+    if (ri <= rj) { *ti = ri; *tj = rj - ri; }
+    else { *ti = len_x - nrows + ri; *tj = len_y - ri + rj; }
+  } else if (len_x <= len_y) { *ti = ri; *tj = rj - ri; }
+  else { *ti = rj - (nrows - 1) + ri; *tj = nrows - 1 - ri; }
+}
+
 int mi355_sw_last_timings(const mi355_sw_ctx *ctx, double out[6]) {
   if (!ctx || !out) return MI355_SW_EINVAL;
   for (int k = 0; k < 6; ++k) out[k] = ctx->timings[k];

@@ -1,0 +1,72 @@
+// sw_solve_uniprot — the many-alignment batch of the reference driver src/mpi_sw_solve_uniprot.cpp
+// (each database sequence as FIRST argument, the query protein as SECOND, SWAligner<Similarity_Matrix>,
+// default scoring, :120-122) as ONE device batch instead of an MPI task farm with a writer rank.
+//   sw_solve_uniprot [query.fasta] [db] [out.csv] [--count=N]
+// db = directory with <k>.fasta files (the reference's layout, data/uniprot/<k>.fasta, count from
+// stats.txt or --count) or a single multi-FASTA file.  Output as the writer rank's (:143-170):
+// header `read,pos_pred,score`, rows `<first 126 chars of the sequence>, <pos>, <score>`.
+#include <cstdio>
+#include <iostream>
+#include <sys/stat.h>
+
+#include "driver_common.h"
+#include "parseq/similaritymatrix.h"
+
+int main(int argc, char **argv) {
+  const drv::Args a = drv::parse(argc, argv);
+  const std::string fa_file_path = a.pos.size() > 0 ? a.pos[0] : "data/query/P02232.fasta";
+  const std::string db_path = a.pos.size() > 1 ? a.pos[1] : "data/uniprot/";
+  const std::string output_file_path = a.pos.size() > 2 ? a.pos[2] : "data/align_output.csv";
+  std::string fa_string;
+  if (!drv::read_fasta_skip_header(fa_file_path, fa_string)) { std::cerr << "cannot open " << fa_file_path << std::endl; return 2; }
+  std::vector<std::string> seqs;
+  struct stat st;
+  if (stat(db_path.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) {
+    int filecnt = 0;
+    if (a.has("count")) filecnt = std::stoi(a.get("count", "0"));
+    else { std::ifstream stats(db_path + "/stats.txt"); stats >> filecnt; }
+    for (int k = 0; k < filecnt; ++k) {
+      std::string s;
+      if (!drv::read_fasta_skip_header(db_path + "/" + std::to_string(k) + ".fasta", s)) break;
+      seqs.push_back(s);
+    }
+  } else {
+    std::ifstream f(db_path);
+    if (!f) { std::cerr << "cannot open " << db_path << std::endl; return 2; }
+    std::string line, cur;
+    bool any = false;
+    while (std::getline(f, line)) {
+      if (!line.empty() && line.back() == '\r') line.pop_back();
+      if (!line.empty() && line[0] == '>') { if (any) seqs.push_back(cur); cur.clear(); any = true; }
+      else cur += line;
+    }
+    if (any) seqs.push_back(cur);
+  }
+  std::cout << seqs.size() << " sequences against a " << fa_string.size() << "-residue query" << std::endl;
+  mi355_sw_ctx *ctx = parseq::context();
+  parseq::check(mi355_sw_set_reference(ctx, fa_string.data(), fa_string.size()), "set_reference");
+  std::vector<const char *> xs(seqs.size());
+  std::vector<size_t> nxs(seqs.size());
+  double cells = 0;
+  for (size_t k = 0; k < seqs.size(); ++k) { xs[k] = seqs[k].data(); nxs[k] = seqs[k].size(); cells += (double)nxs[k] * fa_string.size(); }
+  std::vector<mi355_sw_result> res(seqs.size());
+  mi355_sw_params p;
+  mi355_sw_default_params(&p);
+  parseq::check(mi355_sw_align_batch(ctx, seqs.size(), xs.data(), nxs.data(), &p, 0, res.data()), "align_batch");
+  double t[6];
+  mi355_sw_last_timings(ctx, t);
+  std::ofstream out(output_file_path);
+  out << "read,pos_pred,score\n";
+  size_t best = 0;
+  for (size_t k = 0; k < seqs.size(); ++k) {
+    char buff[127];
+    std::snprintf(buff, sizeof buff, "%.126s", seqs[k].c_str());
+    out << buff << ", " << res[k].pos << ", " << res[k].score << "\n";
+    if (res[k].score > res[best].score) best = k;
+  }
+  if (!seqs.empty())
+    std::cout << "best: sequence " << best << " score " << res[best].score << " pos " << res[best].pos << std::endl;
+  std::cout << "[INFO] device time " << t[3] * 1e-6 << "s, GCUPS:" << cells / t[3] * 1e-3 << std::endl;
+  mi355_sw_free_results(res.data(), res.size());
+  return 0;
+}

@@ -52,6 +52,22 @@ int main() {
         EXPECT(normal2(j, i) == skewed2(j, i));
       }
   }
+  {  // SimilarityMatrix.SkewedMatrixIndex (test/test_skewedmatrix.cpp:5-37)
+    std::string sequence_x = "GGTTGACTA";
+    std::string sequence_y = "TGTTACG";
+    auto len_x = sequence_x.size() + 1;
+    auto len_y = sequence_y.size() + 1;
+    auto skewed1 = Similarity_Matrix_Skewed(sequence_y, sequence_x);
+    auto skewed2 = Similarity_Matrix_Skewed(sequence_x, sequence_y);
+    for (size_t j = 0; j < len_y; j++)
+      for (size_t i = 0; i < len_x; i++) {
+        auto idx1 = index_tuple(i, j);
+        auto idx2 = index_tuple(j, i);
+        EXPECT(idx1 == skewed1.rawindex2trueindex(skewed1.trueindex2rawindex(idx1)));
+        EXPECT(idx2 == skewed2.rawindex2trueindex(skewed2.trueindex2rawindex(idx2)));
+        EXPECT(idx2 == skewed2.trueindex2rawindex(skewed2.rawindex2trueindex(idx2)));
+      }
+  }
   {  // custom scoring through std::function, float engine (SURVEY App. B probe: 9 / pos 2)
     SWAligner<Similarity_Matrix> la("GGTTGACTA", "TGTTACGG", [](const char &a, const char &b) { return a == b ? 2.0f : -1.0f; }, 1.0f);
     EXPECT(la.calculateScore() == 9 && la.getPos() == 2);

@@ -57,3 +57,16 @@ def test_cpp_dropin_headers_compile():
                            "-L" + os.path.join(ROOT, "parallel-genomeseq_amd"), "-lmi355_sw",
                            "-Wl,-rpath," + os.path.join(ROOT, "parallel-genomeseq_amd"), "-o", out])
     assert os.path.exists(out)
+
+
+def test_index_maps_match_reference(pgs, golden):
+    """mi355_sw_true2raw / raw2true against the real reference's trueindex2rawindex (tests/golden) and
+    the round trip of test/test_skewedmatrix.cpp:5-37."""
+    for c in golden["true2raw"]:
+        m, n, k = c["m"], c["n"], 0
+        for ti in range(n + 1):
+            for tj in range(m + 1):
+                raw = pgs.capi.true2raw(m, n, ti, tj)
+                assert list(raw) == c["raw"][k]
+                assert pgs.capi.raw2true(m, n, *raw) == (ti, tj)
+                k += 1

@@ -217,3 +217,72 @@ def test_config5_shape_reduced(ctx, oracle, pgs):
     sub = refb[max(0, off - 20_000):off + 40_000]
     exp = oracle.align(qb, sub, 0)
     _cmp(ctx.align(qb, sub, 0), exp, "cfg5 reduced")
+
+
+def _drivers_dir():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "parallel-genomeseq_amd", "drivers")
+    if not os.path.exists(os.path.join(d, "sw_solve_small.bin")):
+        import subprocess
+        subprocess.check_call(["make", "-C", d])
+    return d
+
+
+def test_driver_sw_solve_small(data_small, tmp_path):
+    """The sw_solve_small-shaped driver on the reference's own data_small inputs (config 1): CSV rows
+    `<input_line>, <pos>, <score>`; sums equal SURVEY.md Appendix B for both engines and for the
+    17-piece split configuration of the reference's USEOMP build."""
+    import os
+    import subprocess
+    d = _drivers_dir()
+    fa = tmp_path / "genome.fa"
+    ref = data_small["ref"]
+    fa.write_text(">22_5K\n" + "\n".join(ref[i:i + 60] for i in range(0, len(ref), 60)) + "\n")
+    csv = tmp_path / "truth.csv"
+    csv.write_text("index,QNAME,SEQ,POS\n" + "".join("%d,22_5K-1170,%s,%d\n" % (k, r, p) for k, (r, p) in
+                                                       enumerate(zip(data_small["reads"], data_small["sam_pos"]))))
+    for extra, name, ssum, psum in ((["--engine=f32"], "f32", 437131, 2750571), (["--engine=u8"], "u8", 298350, 2688127),
+                                    (["--engine=u8", "--npiece=17", "--overlap=2.0"], None, 298350, 2669362)):
+        out = tmp_path / "out.csv"
+        p = subprocess.run([os.path.join(d, "sw_solve_small.bin"), str(fa), str(csv), str(out)] + extra,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 0 and b"GCUP:" in p.stdout, p.stdout.decode()
+        rows = out.read_text().splitlines()
+        assert rows[0] == "index,QNAME,SEQ,POS,pos_pred,score" and len(rows) == 1171
+        pos = [int(r.split(", ")[1]) for r in rows[1:]]
+        sc = [float(r.split(", ")[2]) for r in rows[1:]]
+        assert rows[1].startswith("0,22_5K-1170,GGTGGAGG") and sum(sc) == ssum and sum(pos) == psum
+        if name:
+            for k, e in enumerate(data_small["first"][name]):
+                assert pos[k] == e["pos"] and sc[k] == e["score"]
+
+
+def test_driver_sw_solve_big_and_uniprot(pgs, oracle, tmp_path):
+    import os
+    import subprocess
+    d = _drivers_dir()
+    ref = pgs.synth.dna(1, 200_000)
+    reads = [pgs.synth.read_from_ref(ref, 40 + k, 150)[0].tobytes().decode() for k in range(3)]
+    (tmp_path / "ref.fa").write_text(ref.tobytes().decode() + "\n")
+    (tmp_path / "reads.csv").write_text("index,QNAME,SEQ,POS\n" + "".join("%d,r%d,%s,0\n" % (k, k, r) for k, r in enumerate(reads)))
+    for npiece in ("0", "2"):
+        p = subprocess.run([os.path.join(d, "sw_solve_big.bin"), npiece, "2", str(tmp_path / "ref.fa"), str(tmp_path / "reads.csv")],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 0 and b"[INFO] GCUPS avg:" in p.stdout, p.stdout.decode()
+    # UniProt-shaped batch: each database sequence is the FIRST argument, the query the SECOND
+    query = pgs.synth.protein(9, 144).tobytes().decode()
+    db = [pgs.synth.protein(100 + k, n).tobytes().decode() for k, n in enumerate((30, 200, 361, 700, 90))]
+    db[2] = db[2][:100] + query[20:120] + db[2][200:]
+    (tmp_path / "q.fasta").write_text(">sp|Q\n" + query[:60] + "\n" + query[60:] + "\n")
+    (tmp_path / "db.fasta").write_text("".join(">s%d\n%s\n" % (k, s) for k, s in enumerate(db)))
+    out = tmp_path / "u.csv"
+    p = subprocess.run([os.path.join(d, "sw_solve_uniprot.bin"), str(tmp_path / "q.fasta"), str(tmp_path / "db.fasta"), str(out)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0 and b"best: sequence 2" in p.stdout, p.stdout.decode()
+    rows = out.read_text().splitlines()
+    assert rows[0] == "read,pos_pred,score" and len(rows) == 6
+    for k, s in enumerate(db):
+        e = oracle.align(s, query, oracle.F32)
+        seq, pos, sc = rows[1 + k].split(", ")
+        assert seq == s[:126] and int(pos) == e["pos"] and float(sc) == e["score"]
