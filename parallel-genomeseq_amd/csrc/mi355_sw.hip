@@ -30,7 +30,7 @@ namespace {
 constexpr int kMaxCodes = 48;                 // LDS profile budget: codes incl. pad
 constexpr int kMaxRowsFast = 512;             // 16 lanes x R <= 32 rows in one strip; longer queries are strip-mined
 constexpr size_t kDirsBudget = 3ull << 30;    // bytes of traceback decisions per exact launch
-constexpr size_t kExactLdsMax = 160 * 1024;
+constexpr size_t kExactLdsMax = 159 * 1024;    // dynamic part; the wide instance adds < 1 KiB of static LDS
 
 struct DevBuf {
   void *p = nullptr;
@@ -460,10 +460,17 @@ int run_exact(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   int rc = 0;
   const ExactScoring sc = make_scoring(ctx, p, lut_up, rc);
   if (rc) return fail(ctx, rc, "scoring table upload failed");
-  if (p.semantics == MI355_SW_U8SAT)
-    hipLaunchKernelGGL((sw_exact_kernel<1>), dim3((unsigned)n), dim3(64), lds, ctx->stream, ctx->probs.as<ExactProblem>(), sc);
-  else
-    hipLaunchKernelGGL((sw_exact_kernel<0>), dim3((unsigned)n), dim3(64), lds, ctx->stream, ctx->probs.as<ExactProblem>(), sc);
+  // few problems with long diagonals: sixteen wavefronts per problem; otherwise one wavefront each
+  int mindiag = 1 << 30;
+  for (size_t k = lo; k < hi; ++k) mindiag = std::min(mindiag, std::min<int>(q.len[jobs[k].q], jobs[k].nw));
+  const bool wide = n <= 2048 && mindiag >= 1024;
+  if (p.semantics == MI355_SW_U8SAT) {
+    if (wide) hipLaunchKernelGGL((sw_exact_kernel<1, 1024>), dim3((unsigned)n), dim3(1024), lds, ctx->stream, ctx->probs.as<ExactProblem>(), sc);
+    else hipLaunchKernelGGL((sw_exact_kernel<1, 64>), dim3((unsigned)n), dim3(64), lds, ctx->stream, ctx->probs.as<ExactProblem>(), sc);
+  } else {
+    if (wide) hipLaunchKernelGGL((sw_exact_kernel<0, 1024>), dim3((unsigned)n), dim3(1024), lds, ctx->stream, ctx->probs.as<ExactProblem>(), sc);
+    else hipLaunchKernelGGL((sw_exact_kernel<0, 64>), dim3((unsigned)n), dim3(64), lds, ctx->stream, ctx->probs.as<ExactProblem>(), sc);
+  }
   HIPCHK(ctx, hipGetLastError());
   std::vector<float> bf(n);
   std::vector<int64_t> ci(2 * n);
@@ -875,8 +882,10 @@ int mi355_sw_create(mi355_sw_ctx **out, int device) {
   c->device = device;
   if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return MI355_SW_ENODEV; }
   for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return MI355_SW_ENODEV; }
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_exact_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kExactLdsMax);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_exact_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kExactLdsMax);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_exact_kernel<0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kExactLdsMax);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_exact_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kExactLdsMax);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_exact_kernel<0, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kExactLdsMax);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_exact_kernel<1, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kExactLdsMax);
   *out = c;
   return 0;
 }

@@ -59,8 +59,11 @@ __device__ __forceinline__ unsigned long long order_key(int64_t i, int64_t j, in
   return ((unsigned long long)rj << 32) | (unsigned long long)ri;
 }
 
-template <int SEM>
-__global__ __launch_bounds__(64) void sw_exact_kernel(const ExactProblem *probs, const ExactScoring sc) {
+// NT = 64: one wavefront per problem, no barriers (its LDS operations complete in order).
+// NT = 1024: sixteen wavefronts share one problem's diagonals (long queries / wide windows), one
+// workgroup barrier per diagonal.
+template <int SEM, int NT>
+__global__ __launch_bounds__(NT) void sw_exact_kernel(const ExactProblem *probs, const ExactScoring sc) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
   const ExactProblem P = probs[blockIdx.x];
   const int lane = threadIdx.x;
@@ -71,9 +74,9 @@ __global__ __launch_bounds__(64) void sw_exact_kernel(const ExactProblem *probs,
   float *D1 = D0 + plen;
   float *D2 = D1 + plen;
   uint8_t *xs = reinterpret_cast<uint8_t *>(D2 + plen);
-  for (int k = lane; k < 3 * plen; k += 64) D0[k] = 0.0f;
-  for (int k = lane; k < m; k += 64) xs[k] = P.x[k];
-  // (single wavefront: LDS operations complete in order, no barrier needed)
+  for (int k = lane; k < 3 * plen; k += NT) D0[k] = 0.0f;
+  for (int k = lane; k < m; k += NT) xs[k] = P.x[k];
+  if (NT > 64) __syncthreads();
 
   float best = -1.0f;
   unsigned long long bkey = ~0ull;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(64) void sw_exact_kernel(const ExactProblem *probs,
     }
     const int ilo = d - nw > 1 ? d - nw : 1;
     const int ihi = d - 1 < m ? d - 1 : m;
-    for (int i = ilo + lane; i <= ihi; i += 64) {
+    for (int i = ilo + lane; i <= ihi; i += NT) {
       const int jl = d - i;
       const int ic = rows_short ? i : jl;          // index of (i, jl)
       const int iw = rows_short ? i : jl - 1;      // (i, jl-1)   on d-1
@@ -135,6 +138,7 @@ __global__ __launch_bounds__(64) void sw_exact_kernel(const ExactProblem *probs,
         }
       }
     }
+    if (NT > 64) __syncthreads();
   }
   // wave reduction: larger value first, then smaller key
 #pragma unroll
@@ -144,6 +148,18 @@ __global__ __launch_bounds__(64) void sw_exact_kernel(const ExactProblem *probs,
     const long long oi = __shfl_xor((long long)bi, off);
     const long long oj = __shfl_xor((long long)bj, off);
     if (ob > best || (ob == best && ok < bkey)) { best = ob; bkey = ok; bi = oi; bj = oj; }
+  }
+  if (NT > 64) {
+    // combine the wavefronts' winners through LDS (the diagonal buffers are free now)
+    __shared__ float sb[NT / 64];
+    __shared__ unsigned long long sk[NT / 64];
+    __shared__ long long si[NT / 64], sj[NT / 64];
+    const int w = lane >> 6;
+    if ((lane & 63) == 0) { sb[w] = best; sk[w] = bkey; si[w] = bi; sj[w] = bj; }
+    __syncthreads();
+    if (lane == 0)
+      for (int k = 1; k < NT / 64; ++k)
+        if (sb[k] > best || (sb[k] == best && sk[k] < bkey)) { best = sb[k]; bkey = sk[k]; bi = si[k]; bj = sj[k]; }
   }
   if (lane == 0) {
     if (P.best) *P.best = best;
