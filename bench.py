@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--ref-len", type=int, default=50_000_000)
     ap.add_argument("--semantics", choices=["f32", "u8"], default="f32")
     ap.add_argument("--score-only", action="store_true", help="skip the traceback (diagnostic; not the headline)")
+    ap.add_argument("--match", type=float, default=3.0)
+    ap.add_argument("--mismatch", type=float, default=-3.0)
+    ap.add_argument("--gap", type=float, default=2.0, help="non-integer scoring selects the float32-cell kernel instance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (rehearsal: ranks may share GPU 0)")
     args = ap.parse_args()
@@ -142,7 +145,7 @@ def main():
     cells_per_step = float(args.reads) * args.read_len * args.ref_len
 
     def step():
-        out = ctx.batch_run(semantics=sem, flags=flags, raw=True)
+        out = ctx.batch_run(semantics=sem, match=args.match, mismatch=args.mismatch, gap=args.gap, flags=flags, raw=True)
         best = int(out["score"].max()) << 32 | (0xFFFFFFFF - (int(out["score"].argmax()) + rank * args.reads))
         if dist is not None:
             t = torch.tensor([best], dtype=torch.int64, device=cdev)
@@ -156,7 +159,7 @@ def main():
         tp = time.perf_counter()
         ctx.set_reference(ref)
         ctx.batch_upload([r.tobytes() for r in reads])
-        ctx.batch_run(semantics=sem, flags=flags, raw=True)
+        ctx.batch_run(semantics=sem, match=args.match, mismatch=args.mismatch, gap=args.gap, flags=flags, raw=True)
         pcie = time.perf_counter() - tp
     for _ in range(args.warmup):
         step()

@@ -27,7 +27,7 @@ using namespace mi355sw;
 
 namespace {
 
-constexpr int kMaxCodes = 48;                 // LDS profile budget: codes incl. pad
+constexpr size_t kProfileLdsMax = 120 * 1024;  // LDS budget of the query profile (ncodes x 16 lanes x stride x 4 B)
 constexpr int kMaxRowsFast = 512;             // 16 lanes x R <= 32 rows in one strip; longer queries are strip-mined
 constexpr size_t kDirsBudget = 3ull << 30;    // bytes of traceback decisions per exact launch
 constexpr size_t kExactLdsMax = 159 * 1024;    // dynamic part; the wide instance adds < 1 KiB of static LDS
@@ -84,7 +84,7 @@ struct mi355_sw_ctx {
   RefData ref;                    // resident reference (set_reference)
   QueryBatch batch;               // resident queries (batch_upload)
   // scratch
-  DevBuf keys, ranges, stab, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow;
+  DevBuf keys, ranges, stab, ftab, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow;
   double timings[6] = {0, 0, 0, 0, 0, 0};
 };
 
@@ -182,10 +182,13 @@ int upload_queries(mi355_sw_ctx *ctx, QueryBatch &q, size_t n, const char *const
 // Score table shared by every launch of a call: which (params, reference alphabet) the packed 16-bit
 // kernel can represent exactly.
 struct ScoreTable {
-  bool ok = false;
+  bool ok = false;            // some score-kernel instance can represent (params, alphabet) exactly
+  bool integral = false;      // the packed 16-bit instances can
   std::string why;
-  int gap = 0, smax = 0;
+  int gap = 0, smax = 0;      // packed instances
+  float gapf = 0, smaxf = 0;  // float32 instance
   std::vector<int16_t> stab;  // [256][ncodes]
+  std::vector<float> ftab;    // [256][ncodes]
 };
 
 // A run of length-sorted queries swept by one kernel instance.
@@ -193,6 +196,7 @@ struct Bucket {
   int first = 0, count = 0;   // positions in QueryBatch::order
   int maxlen = 0;
   int R = 0;
+  int sem = kSemI16;          // kernel instance: kSemI16 / kSemU8 packed pairs, kSemF32 one query per slot
   bool strips = false;        // queries longer than one 512-row strip
   int64_t warm = 0;           // exactness margin in columns
   bool fast = false;          // swept by the score kernel (else whole-matrix exact path)
@@ -208,7 +212,6 @@ int pick_R(int maxlen) {
 
 ScoreTable plan_table(const RefData &ref, const mi355_sw_params &p) {
   ScoreTable f;
-  if (ref.ncodes > kMaxCodes) { f.why = "reference alphabet larger than the LDS profile budget"; return f; }
   const int nc = ref.ncodes;
   f.stab.assign((size_t)256 * nc, (int16_t)kPadScore);
   if (p.semantics == MI355_SW_U8SAT) {
@@ -217,25 +220,34 @@ ScoreTable plan_table(const RefData &ref, const mi355_sw_params &p) {
     for (int a = 0; a < 256; ++a)
       for (int c = 0; c < nc - 1; ++c) f.stab[(size_t)a * nc + c] = (int16_t)((uint8_t)a == ref.byte_of[c] ? u.M : -u.X);
     f.gap = u.G; f.smax = u.M;
+    f.integral = true;
   } else {
     const float g = p.gap;
-    if (!(g >= 1.0f) || g != std::floor(g) || g > 8000) { f.why = "gap penalty is not an integer >= 1"; return f; }
-    int smax = 0;
+    if (!(g > 0.0f) || !std::isfinite(g)) { f.why = "gap penalty is not positive: no finite warm-up margin"; return f; }
+    f.ftab.assign((size_t)256 * nc, kPadScoreF);
+    bool integral = g >= 1.0f && g == std::floor(g) && g <= 8000;
+    float smaxf = 0;
     for (int a = 0; a < 256; ++a)
       for (int c = 0; c < nc - 1; ++c) {
         const float s = lut_or(p, (uint8_t)a, ref.byte_of[c]);
-        if (s != std::floor(s) || std::fabs(s) > 8000) { f.why = "substitution scores are not small integers"; return f; }
-        f.stab[(size_t)a * nc + c] = (int16_t)s;
-        smax = std::max(smax, (int)s);
+        if (!std::isfinite(s) || std::fabs(s) > 1e6f) { f.why = "substitution score out of range"; return f; }
+        f.ftab[(size_t)a * nc + c] = s;
+        smaxf = std::max(smaxf, s);
+        if (s != std::floor(s) || std::fabs(s) > 8000) integral = false;
+        else f.stab[(size_t)a * nc + c] = (int16_t)s;
       }
-    f.gap = (int)g; f.smax = smax;
+    f.gapf = g; f.smaxf = smaxf;
+    f.integral = integral;
+    if (integral) { f.gap = (int)g; f.smax = (int)smaxf; }
   }
   f.ok = true;
   return f;
 }
 
+size_t profile_lds_bytes(int ncodes, int R) { return (size_t)ncodes * kSlotLanes * lane_stride(R) * 4; }
+
 // Length classes of the batch: one bucket per kernel instance (R), plus one strip-mined bucket.
-std::vector<Bucket> make_buckets(const QueryBatch &q, const ScoreTable &t) {
+std::vector<Bucket> make_buckets(const QueryBatch &q, const ScoreTable &t, const mi355_sw_params &p, int64_t n) {
   std::vector<Bucket> out;
   for (size_t pos = 0; pos < q.nq; ++pos) {
     const int len = q.len[q.order[pos]];
@@ -250,20 +262,32 @@ std::vector<Bucket> make_buckets(const QueryBatch &q, const ScoreTable &t) {
     out.back().maxlen = std::max(out.back().maxlen, len);
   }
   for (Bucket &b : out) {
-    if (t.smax <= 0 || t.gap <= 0) b.warm = 0;
-    else b.warm = (int64_t)b.maxlen + ((int64_t)t.smax * b.maxlen + t.gap - 1) / t.gap;
+    if (p.semantics == MI355_SW_U8SAT) b.sem = kSemU8;
+    else {
+      // packed 16-bit cells when scores are small integers and the score bound fits; float32 cells otherwise
+      const bool fits = t.integral && (int64_t)t.smax * std::min<int64_t>(b.maxlen, std::max<int64_t>(n, 1)) + t.smax <= 32000;
+      b.sem = fits ? kSemI16 : kSemF32;
+    }
+    const double smax = b.sem == kSemF32 ? (double)t.smaxf : (double)t.smax;
+    const double gap = b.sem == kSemF32 ? (double)t.gapf : (double)t.gap;
+    if (smax <= 0 || gap <= 0) b.warm = 0;
+    else b.warm = (int64_t)b.maxlen + (int64_t)std::ceil(smax * b.maxlen / gap);
     b.warm = (b.warm + 3) / 4 * 4;
   }
   return out;
 }
 
 // May this bucket's queries be swept by the score kernel over a reference range of n columns?
-bool bucket_fast_ok(const ScoreTable &t, const Bucket &b, int64_t n, const mi355_sw_params &p) {
+bool bucket_fast_ok(const RefData &ref, const ScoreTable &t, const Bucket &b, int64_t n, const mi355_sw_params &p) {
   if (!t.ok || n < 1 || b.maxlen < 1) return false;
+  if (profile_lds_bytes(ref.ncodes, b.R) > kProfileLdsMax) return false;       // alphabet too large for this R
   // the uint8 engine's storage order is only bounded to a few tiles when the reference is the longer side;
   // shorter references take the whole-matrix path (which also holds the |x| == |y| quirk)
   if (p.semantics == MI355_SW_U8SAT && n <= (int64_t)b.maxlen + 1) return false;
-  if (p.semantics == MI355_SW_F32 && (int64_t)t.smax * std::min<int64_t>(b.maxlen, n) + t.smax > 32000) return false;
+  // float32 cells stay exact integers only below 2^24
+  if (b.sem == kSemF32 && t.integral && (double)t.smax * (double)std::min<int64_t>(b.maxlen, n) > 1.6e7) return false;
+  // the warm-up margin must stay a small fraction of the range (tiny gap penalties)
+  if (b.warm > 64 * (int64_t)b.maxlen + 1024) return false;
   // strip-mining re-streams the range once per 512 rows: only worth it on long ranges
   if (b.strips && n < 4096) return false;
   // short references (UniProt shape: many sequences against one 144-residue query): one whole-matrix
@@ -272,15 +296,23 @@ bool bucket_fast_ok(const ScoreTable &t, const Bucket &b, int64_t n, const mi355
   return true;
 }
 
+template <class K>
+void launch_score(K kernel, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
+  // large alphabets x many rows per lane need more than the default 64 KiB of dynamic LDS
+  if (shmem > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  hipLaunchKernelGGL(kernel, grid, dim3(256), shmem, st, a);
+}
+
 template <int SEM>
 int launch_score_R(int R, bool strips, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
   if (strips) {
     if (R != 32) return -1;
-    hipLaunchKernelGGL((sw_score_kernel<32, SEM, true>), grid, dim3(256), shmem, st, a);
+    launch_score(sw_score_kernel<32, SEM, true>, grid, shmem, st, a);
     return 0;
   }
   switch (R) {
-#define CASE_R(r) case r: hipLaunchKernelGGL((sw_score_kernel<r, SEM>), grid, dim3(256), shmem, st, a); return 0;
+#define CASE_R(r) case r: launch_score(sw_score_kernel<r, SEM, false>, grid, shmem, st, a); return 0;
     CASE_R(2) CASE_R(4) CASE_R(6) CASE_R(8) CASE_R(10) CASE_R(12) CASE_R(16) CASE_R(20) CASE_R(24) CASE_R(32)
 #undef CASE_R
   }
@@ -302,10 +334,13 @@ int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range>
   if (nr > 32768) return fail(ctx, MI355_SW_ENOTSUP, "more than 32768 ranges per launch");
   std::vector<int64_t> rl(2 * nr);
   for (size_t k = 0; k < nr; ++k) { rl[k] = ranges[k].lo; rl[nr + k] = ranges[k].hi; }
-  if (ctx->ranges.ensure(rl.size() * 8) || ctx->keys.ensure(nq * nr * 8) || ctx->stab.ensure(t.stab.size() * 2))
+  if (ctx->ranges.ensure(rl.size() * 8) || ctx->keys.ensure(nq * nr * 8) || ctx->stab.ensure(t.stab.size() * 2) ||
+      ctx->ftab.ensure(t.ftab.size() * 4 + 16))
     return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
   HIPCHK(ctx, hipMemcpyAsync(ctx->ranges.p, rl.data(), rl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ctx->stab.p, t.stab.data(), t.stab.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+  if (!t.ftab.empty())
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ftab.p, t.ftab.data(), t.ftab.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, nq * nr * 8, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // pageable staging buffers above go out of scope
   return 0;
@@ -317,7 +352,7 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   const size_t nr = ranges.size();
   int64_t maxlen = 0;
   for (auto &r : ranges) maxlen = std::max(maxlen, r.hi - r.lo);
-  const size_t npairs = ((size_t)b.count + 1) / 2;
+  const size_t npairs = b.sem == kSemF32 ? (size_t)b.count : ((size_t)b.count + 1) / 2;   // queries per workgroup: 1 or 2
   b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm);
   const int64_t cpr = (maxlen + b.chunk_len - 1) / b.chunk_len;
   const int64_t cgroups = (cpr + 15) / 16;
@@ -338,9 +373,10 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   a.qfirst = b.first;
   a.qcount = b.count;
   a.nq = (int)q.nq;
-  a.stab = ctx->stab.as<int16_t>();
+  a.stab = b.sem == kSemF32 ? ctx->ftab.p : ctx->stab.p;
   a.ncodes = ref.ncodes;
-  a.gap2 = (uint32_t)t.gap * 0x00010001u;
+  if (b.sem == kSemF32) memcpy(&a.gap2, &t.gapf, 4);
+  else a.gap2 = (uint32_t)t.gap * 0x00010001u;
   a.clamp2 = 255u * 0x00010001u;
   a.keys = ctx->keys.as<unsigned long long>();
 
@@ -361,8 +397,9 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     shmem += 2 * 16 * kSeg * 4;
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  int rc = (p.semantics == MI355_SW_U8SAT) ? launch_score_R<kSemU8>(b.R, b.strips, grid, shmem, ctx->stream, a)
-                                           : launch_score_R<kSemI16>(b.R, b.strips, grid, shmem, ctx->stream, a);
+  int rc = b.sem == kSemU8 ? launch_score_R<kSemU8>(b.R, b.strips, grid, shmem, ctx->stream, a)
+           : b.sem == kSemF32 ? launch_score_R<kSemF32>(b.R, b.strips, grid, shmem, ctx->stream, a)
+                              : launch_score_R<kSemI16>(b.R, b.strips, grid, shmem, ctx->stream, a);
   if (rc) return fail(ctx, MI355_SW_ENOTSUP, "no score kernel instance for this R");
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -668,20 +705,23 @@ int exact_full(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
 // qchunk / qwarm: tile geometry of each query's bucket.
 int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
                 const mi355_sw_params &p, const std::vector<char> &qfast, const std::vector<int64_t> &qchunk,
-                const std::vector<int64_t> &qwarm, const unsigned long long *keys, std::vector<Located> &loc) {
+                const std::vector<int64_t> &qwarm, const std::vector<char> &qfloat, const unsigned long long *keys,
+                std::vector<Located> &loc) {
   const size_t nq = q.nq;
   const int64_t n = rg.hi - rg.lo;
   std::vector<ExactJob> jobs;
   for (size_t k = 0; k < nq; ++k) {
     if (!qfast[k]) continue;
     const unsigned long long key = keys[k];
-    const int score = (int)(key >> 32);
-    if (score <= 0) continue;
+    float score;
+    if (qfloat[k]) { const uint32_t bits = (uint32_t)(key >> 32); memcpy(&score, &bits, 4); }
+    else score = (float)(int)(key >> 32);
+    if (!(score > 0)) continue;
     const int64_t chunk_len = qchunk[k];
     const int64_t nchunks = (n + chunk_len - 1) / chunk_len;
     const int64_t warm = nchunks == 1 ? 0 : qwarm[k];
     const int64_t first = (int64_t)(0xFFFFFFFFull - (key & 0xFFFFFFFFull));
-    loc[k].score = (float)score;
+    loc[k].score = score;
     int64_t cand[5];
     int nc = 0;
     cand[nc++] = first;
@@ -702,7 +742,7 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
       const int64_t wl = std::max<int64_t>(0, own_lo - warm);
       ExactJob j;
       j.q = (int)k; j.ylo = rg.lo + wl; j.nw = (int32_t)(own_hi - wl); j.col_offset = wl; j.full_n = n;
-      j.own_lo = (int32_t)(own_lo - wl + 1); j.quirk = 0; j.target = (float)score; j.want_dirs = false;
+      j.own_lo = (int32_t)(own_lo - wl + 1); j.quirk = 0; j.target = score; j.want_dirs = false;
       jobs.push_back(j);
     }
   }
@@ -740,11 +780,11 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
   std::vector<TraceOut> tout(nq);
   if (n >= 1 && nq > 0) {
     const ScoreTable table = plan_table(ref, p);
-    std::vector<Bucket> buckets = make_buckets(q, table);
-    std::vector<char> qfast(nq, 0);
+    std::vector<Bucket> buckets = make_buckets(q, table, p, n);
+    std::vector<char> qfast(nq, 0), qfloat(nq, 0);
     std::vector<int64_t> qchunk(nq, 0), qwarm(nq, 0);
     bool any_fast = false;
-    for (Bucket &b : buckets) { b.fast = bucket_fast_ok(table, b, n, p); any_fast |= b.fast; }
+    for (Bucket &b : buckets) { b.fast = bucket_fast_ok(ref, table, b, n, p); any_fast |= b.fast; }
     if (any_fast) {
       const std::vector<Range> ranges{rg};
       int rc = score_begin(ctx, q, ranges, table);
@@ -755,14 +795,14 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
         if (rc) return rc;
         for (int k = 0; k < b.count; ++k) {
           const int id = q.order[b.first + k];
-          qfast[id] = 1; qchunk[id] = b.chunk_len; qwarm[id] = b.warm;
+          qfast[id] = 1; qchunk[id] = b.chunk_len; qwarm[id] = b.warm; qfloat[id] = b.sem == kSemF32;
         }
       }
       std::vector<unsigned long long> keys;
       rc = score_fetch(ctx, nq, keys);
       if (rc) return rc;
       HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-      rc = locate_fast(ctx, ref, q, rg, p, qfast, qchunk, qwarm, keys.data(), loc);
+      rc = locate_fast(ctx, ref, q, rg, p, qfast, qchunk, qwarm, qfloat, keys.data(), loc);
       if (rc) return rc;
       HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
       ctx->timings[1] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
@@ -811,11 +851,13 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   const size_t nq = q.nq, nr = ranges.size();
   if (nq == 0 || nr == 0) return 0;
   const ScoreTable table = plan_table(ref, p);
-  std::vector<Bucket> buckets = make_buckets(q, table);
-  std::vector<char> qfast(nq, 0);
+  int64_t maxn = 0;
+  for (auto &r : ranges) maxn = std::max(maxn, r.hi - r.lo);
+  std::vector<Bucket> buckets = make_buckets(q, table, p, maxn);
+  std::vector<char> qfast(nq, 0), qfloat(nq, 0);
   for (Bucket &b : buckets) {
     b.fast = true;
-    for (auto &r : ranges) b.fast = b.fast && bucket_fast_ok(table, b, r.hi - r.lo, p);
+    for (auto &r : ranges) b.fast = b.fast && bucket_fast_ok(ref, table, b, r.hi - r.lo, p);
   }
   for (size_t lo = 0; lo < nr; lo += 32768) {
     const size_t hi = std::min(nr, lo + 32768);
@@ -829,14 +871,19 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
       if (!b.fast) continue;
       rc = score_launch(ctx, ref, q, sub, p, table, b);
       if (rc) return rc;
-      for (int k = 0; k < b.count; ++k) qfast[q.order[b.first + k]] = 1;
+      for (int k = 0; k < b.count; ++k) { qfast[q.order[b.first + k]] = 1; qfloat[q.order[b.first + k]] = b.sem == kSemF32; }
     }
     std::vector<unsigned long long> keys;
     rc = score_fetch(ctx, nq * sub.size(), keys);
     if (rc) return rc;
     for (size_t r = 0; r < sub.size(); ++r)
       for (size_t k = 0; k < nq; ++k)
-        if (qfast[k]) maxima[(lo + r) * nq + k] = (float)(keys[r * nq + k] >> 32);
+        if (qfast[k]) {
+          const uint32_t hi32 = (uint32_t)(keys[r * nq + k] >> 32);
+          float v;
+          if (qfloat[k]) memcpy(&v, &hi32, 4); else v = (float)hi32;
+          maxima[(lo + r) * nq + k] = v;
+        }
   }
   std::vector<int> slow;
   for (size_t k = 0; k < nq; ++k) if (!qfast[k]) slow.push_back((int)k);
@@ -864,7 +911,7 @@ void reset_timings(mi355_sw_ctx *ctx) { for (double &t : ctx->timings) t = 0; }
 // ================================= C-ABI ======================================================
 extern "C" {
 
-const char *mi355_sw_build_info(void) { return "mi355_sw gfx950 hip; score kernel R={2,4,6,8,10,12,16,20,24,32} x {i16,u8sat}"; }
+const char *mi355_sw_build_info(void) { return "mi355_sw gfx950 hip; score kernel R={2,4,6,8,10,12,16,20,24,32} x {i16 pairs,u8sat pairs,f32} + strip-mined R=32"; }
 
 void mi355_sw_default_params(mi355_sw_params *p) {
   if (!p) return;
@@ -894,7 +941,7 @@ void mi355_sw_destroy(mi355_sw_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   DevBuf *bufs[] = {&c->ref.bytes, &c->ref.codes, &c->batch.bytes, &c->batch.lens, &c->keys, &c->ranges, &c->stab,
-                    &c->batch.offs, &c->batch.sel, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow};
+                    &c->batch.offs, &c->batch.sel, &c->ftab, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow};
   for (DevBuf *b : bufs) b->release();
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -35,8 +35,11 @@ constexpr int kSeg = 64;               // steps between two refills of the code 
 constexpr int kHist = 16;              // bytes of history kept in front of a segment
 constexpr int kCodeBuf = kHist + kSeg; // bytes per slot
 constexpr int kPadScore = -16384;      // substitution score of padding rows / columns
-constexpr int kSemI16 = 0;             // Similarity_Matrix semantics on integer scores
-constexpr int kSemU8 = 1;              // Similarity_Matrix_Skewed semantics (saturate at 255)
+constexpr int kSemI16 = 0;             // Similarity_Matrix semantics on integer scores, two queries per register
+constexpr int kSemU8 = 1;              // Similarity_Matrix_Skewed semantics (saturate at 255), two queries per register
+constexpr int kSemF32 = 2;             // Similarity_Matrix semantics in float32 cells (any table, any positive gap),
+                                       // one query per register: the general instance behind the packed ones
+constexpr float kPadScoreF = -1.0e30f;
 
 // LDS stride (dwords) between the profile rows of two adjacent lanes: a multiple of 4 (b128
 // alignment) that is ≡ 4 (mod 8), so that the sixteen 16-byte windows of a ds_read_b128 lane
@@ -60,9 +63,10 @@ struct ScoreArgs {
   const int32_t *qsel;       // [nq] query ids sorted by length; this launch sweeps qsel[qfirst .. qfirst+qcount)
   int qfirst, qcount;
   int nq;                    // total queries (row length of keys)
-  const int16_t *stab;       // [256][ncodes] score(query byte, reference code); column ncodes-1 = pad
+  const void *stab;          // [256][ncodes] score(query byte, reference code); column ncodes-1 = pad;
+                             // int16 for the packed instances, float for kSemF32
   int ncodes;
-  uint32_t gap2;             // gap penalty in both halves
+  uint32_t gap2;             // gap penalty in both halves (packed) / float bits (kSemF32)
   uint32_t clamp2;           // 255 in both halves (U8SAT)
   unsigned long long *keys;  // [nranges][nq]  (max << 32) | (0xFFFFFFFF - chunk)
   // strip-mined variant only (queries longer than 16*R rows): boundary rows between strips,
@@ -75,6 +79,35 @@ __device__ __forceinline__ uint32_t as_u32(i16x2 v) { return __builtin_bit_cast(
 __device__ __forceinline__ i16x2 as_i16x2(uint32_t v) { return __builtin_bit_cast(i16x2, v); }
 __device__ __forceinline__ u16x2 as_u16x2(i16x2 v) { return __builtin_bit_cast(u16x2, v); }
 __device__ __forceinline__ i16x2 to_i16x2(u16x2 v) { return __builtin_bit_cast(i16x2, v); }
+
+// Cell arithmetic of the three instances.  A cell register is handled as raw 32 bits outside these helpers.
+template <int SEM> struct Cell {
+  typedef i16x2 T;
+  static constexpr int kQueries = 2;
+  static __device__ __forceinline__ T from_bits(uint32_t v) { return as_i16x2(v); }
+  static __device__ __forceinline__ uint32_t bits(T v) { return as_u32(v); }
+  static __device__ __forceinline__ T add(T d, T sc, uint32_t clamp2) {
+    T x = d + sc;
+    if (SEM == kSemU8) x = __builtin_elementwise_min(x, as_i16x2(clamp2));
+    return x;
+  }
+  static __device__ __forceinline__ T vmax(T a, T b) { return __builtin_elementwise_max(a, b); }
+  static __device__ __forceinline__ T sub_gap(T t, uint32_t gap2) {      // max(t - g, 0): unsigned saturation
+    return to_i16x2(__builtin_elementwise_sub_sat(as_u16x2(t), __builtin_bit_cast(u16x2, gap2)));
+  }
+  static __device__ __forceinline__ T cell(T x, T y) { return __builtin_elementwise_max(x, y); }
+};
+template <> struct Cell<kSemF32> {
+  typedef float T;
+  static constexpr int kQueries = 1;
+  static __device__ __forceinline__ T from_bits(uint32_t v) { return __uint_as_float(v); }
+  static __device__ __forceinline__ uint32_t bits(T v) { return __float_as_uint(v); }
+  static __device__ __forceinline__ T add(T d, T sc, uint32_t) { return d + sc; }
+  static __device__ __forceinline__ T vmax(T a, T b) { return fmaxf(a, b); }
+  // max(w - g, n - g) == max(w, n) - g exactly (rounding is monotone): similaritymatrix.cpp:49-54
+  static __device__ __forceinline__ T sub_gap(T t, uint32_t gap2) { return t - __uint_as_float(gap2); }
+  static __device__ __forceinline__ T cell(T x, T y) { return fmaxf(fmaxf(x, y), 0.0f); }
+};
 
 // value of the lane above inside the 16-lane DPP row, 0 for the first lane (row H(0,.) = 0)
 __device__ __forceinline__ uint32_t row_shr1(uint32_t v) {
@@ -103,8 +136,11 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   const int pair = blockIdx.x / cgroups;
   const int cg = blockIdx.x - pair * cgroups;
   const int range = blockIdx.y;
-  const bool hasB = (2 * pair + 1) < a.qcount;
-  const int qA = a.qsel[a.qfirst + 2 * pair];
+  typedef Cell<SEM> C;
+  typedef typename C::T T;
+  constexpr int NQ = C::kQueries;                                  // queries per workgroup ("pair")
+  const bool hasB = NQ == 2 && (2 * pair + 1) < a.qcount;
+  const int qA = a.qsel[a.qfirst + NQ * pair];
   const int qB = hasB ? a.qsel[a.qfirst + 2 * pair + 1] : qA;
 
   // ---- query profile for this workgroup's pair (rows row0 .. row0 + 16R - 1) ---------------
@@ -118,9 +154,17 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
       const int rem = e - c * per_code;
       const int ll = rem / R, r = rem - ll * R;
       const int i = row0 + ll * R + r;
-      const int sa = (i < mA) ? a.stab[(int)xA[i] * a.ncodes + c] : kPadScore;
-      const int sb = (i < mB) ? a.stab[(int)xB[i] * a.ncodes + c] : kPadScore;
-      prof[(c * kSlotLanes + ll) * LS + r] = (uint32_t)(uint16_t)sa | ((uint32_t)(uint16_t)sb << 16);
+      uint32_t e32;
+      if (SEM == kSemF32) {
+        const float *ft = static_cast<const float *>(a.stab);
+        e32 = __float_as_uint((i < mA) ? ft[(int)xA[i] * a.ncodes + c] : kPadScoreF);
+      } else {
+        const int16_t *st = static_cast<const int16_t *>(a.stab);
+        const int sa = (i < mA) ? st[(int)xA[i] * a.ncodes + c] : kPadScore;
+        const int sb = (i < mB) ? st[(int)xB[i] * a.ncodes + c] : kPadScore;
+        e32 = (uint32_t)(uint16_t)sa | ((uint32_t)(uint16_t)sb << 16);
+      }
+      prof[(c * kSlotLanes + ll) * LS + r] = e32;
     }
   };
   build_profile(0);
@@ -158,9 +202,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   const int64_t total_steps = a.warm + a.chunk_len + kSlotLanes;   // +15 skew, +1 max-fold drain
   const int nseg = (int)((total_steps + kSeg - 1) / kSeg);
 
-  i16x2 mx = as_i16x2(0u);
-  const u16x2 gap = __builtin_bit_cast(u16x2, a.gap2);
-  const i16x2 clampv = as_i16x2(a.clamp2);
+  T mx = C::from_bits(0u);
   const int code_stride = kSlotLanes * LS;                         // dwords per reference code
   const int strip_rows = kSlotLanes * R;
   const int mmax = mA > mB ? mA : mB;
@@ -197,9 +239,9 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
     }
     __syncthreads();                                               // profile + first window ready
 
-    i16x2 H[R];
+    T H[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) H[r] = as_i16x2(0u);
+    for (int r = 0; r < R; ++r) H[r] = C::from_bits(0u);
     uint32_t up_prev = 0;
 
     for (int seg = 0; seg < nseg; ++seg) {
@@ -216,28 +258,27 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
         uint32_t up;                                               // H(i0-1, j) of the lane above
         if (STRIPS) {
           // lane 0 takes the previous strip's bottom row through the DPP `old` operand
-          up = (uint32_t)__builtin_amdgcn_update_dpp((int)bin_w[k], (int)as_u32(H[R - 1]), 0x111, 0xf, 0xf, false);
+          up = (uint32_t)__builtin_amdgcn_update_dpp((int)bin_w[k], (int)C::bits(H[R - 1]), 0x111, 0xf, 0xf, false);
         } else {
-          up = row_shr1(as_u32(H[R - 1]));
+          up = row_shr1(C::bits(H[R - 1]));
         }
-        i16x2 diag = as_i16x2(up_prev);                            // H(i0-1, j-1)
-        i16x2 north = as_i16x2(up);
+        T diag = C::from_bits(up_prev);                            // H(i0-1, j-1)
+        T north = C::from_bits(up);
         up_prev = up;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const i16x2 w = H[r];
-          i16x2 x = diag + as_i16x2(p[r]);
-          if (SEM == kSemU8) x = __builtin_elementwise_min(x, clampv);
-          const i16x2 t = __builtin_elementwise_max(w, north);
-          if (r & 1) mx = __builtin_elementwise_max(mx, t);
-          const i16x2 y = to_i16x2(__builtin_elementwise_sub_sat(as_u16x2(t), gap));
-          const i16x2 h = __builtin_elementwise_max(x, y);
+          const T w = H[r];
+          const T x = C::add(diag, C::from_bits(p[r]), a.clamp2);
+          const T t = C::vmax(w, north);
+          if (r & 1) mx = C::vmax(mx, t);
+          const T y = C::sub_gap(t, a.gap2);
+          const T h = C::cell(x, y);
           diag = w;
           H[r] = h;
           north = h;
         }
         if (STRIPS) {
-          if (l16 == 15) bout_w[k] = as_u32(H[R - 1]);             // bottom row at stream position seg*64+k-15
+          if (l16 == 15) bout_w[k] = C::bits(H[R - 1]);            // bottom row at stream position seg*64+k-15
         }
       }
       // slide the code window: keep the last 16 bytes as history, append the prefetched segment
@@ -259,17 +300,22 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   }
 
   // ---- per-tile maximum -> per-query key -------------------------------------------------
-  uint32_t m32 = as_u32(mx);
+  uint32_t m32 = C::bits(mx);
 #pragma unroll
   for (int off = 8; off >= 1; off >>= 1) {
     const uint32_t o = (uint32_t)__shfl_xor((int)m32, off, 16);
-    m32 = as_u32(__builtin_elementwise_max(as_i16x2(m32), as_i16x2(o)));
+    m32 = C::bits(C::vmax(C::from_bits(m32), C::from_bits(o)));
   }
   if (l16 == 0 && active) {
     const unsigned long long tag = 0xFFFFFFFFull - (unsigned long long)chunk;
     unsigned long long *k = a.keys + (size_t)range * a.nq;
-    atomicMax(k + qA, ((unsigned long long)(m32 & 0xFFFFu) << 32) | tag);
-    if (hasB) atomicMax(k + qB, ((unsigned long long)(m32 >> 16) << 32) | tag);
+    if (SEM == kSemF32) {
+      // non-negative floats order like their bit patterns
+      atomicMax(k + qA, ((unsigned long long)m32 << 32) | tag);
+    } else {
+      atomicMax(k + qA, ((unsigned long long)(m32 & 0xFFFFu) << 32) | tag);
+      if (hasB) atomicMax(k + qB, ((unsigned long long)(m32 >> 16) << 32) | tag);
+    }
   }
 }
 

@@ -286,3 +286,45 @@ def test_driver_sw_solve_big_and_uniprot(pgs, oracle, tmp_path):
         e = oracle.align(s, query, oracle.F32)
         seq, pos, sc = rows[1 + k].split(", ")
         assert seq == s[:126] and int(pos) == e["pos"] and float(sc) == e["score"]
+
+
+def test_protein_alphabet_and_high_bytes(ctx, oracle, pgs):
+    """Large alphabets (LDS profile > 64 KiB on the 32-row instances), table scoring on proteins, and bytes
+    >= 128 (the reference compares raw chars / casts to uint8, no case folding)."""
+    ref = pgs.synth.protein(71, 30_000).tobytes()
+    lut = pgs.synth.make_lut(12345, 1.0)
+    for k, m in enumerate((60, 144, 400, 700)):
+        q = bytearray(ref[5000 + 997 * k:5000 + 997 * k + m])
+        for i in range(0, m, 17):
+            q[i] = ord("W")
+        q = bytes(q)
+        for sem in (0, 1):
+            _cmp(ctx.align(q, ref, sem), oracle.align(q, ref, sem), "protein identity m=%d sem=%d" % (m, sem))
+        _cmp(ctx.align(q, ref, 0, gap=3.0, lut=lut), oracle.align(q, ref, 0, gap=3.0, lut=lut), "protein lut m=%d" % m)
+    rng = np.random.default_rng(5)
+    hi = rng.integers(120, 256, size=20_000, dtype=np.uint8).tobytes()
+    q = hi[7000:7090]
+    for sem in (0, 1):
+        _cmp(ctx.align(q, hi, sem), oracle.align(q, hi, sem), "high bytes sem=%d" % sem)
+    assert ctx.align("acgtacgtacgt", "ACGTACGTACGT" * 100)["score"] == 0        # no case folding
+
+
+def test_float32_instance(ctx, oracle, pgs):
+    """The float32-cell instance of the score kernel: fractional tables / gaps (std::function scoring of the
+    float engine) and integer scores beyond the 16-bit cell range, on references too large for the
+    whole-matrix path; incl. the strip-mined variant.  Scores are dyadic rationals here, so float sums are
+    exact and the comparison is bit-exact; tolerance stated by north_star is 1e-5."""
+    ref = pgs.synth.dna(81, 200_000)
+    refb = ref.tobytes()
+    lutq = pgs.synth.make_lut(777, 0.25)
+    reads = [pgs.synth.read_from_ref(ref, 300 + k, m, sub_rate=0.03, indel_rate=0.01)[0].tobytes()
+             for k, m in enumerate((40, 150, 151, 300, 640))]
+    for q, got in zip(reads, ctx.align_batch(reads, refb, semantics=0, gap=1.5, lut=lutq)):
+        _cmp(got, oracle.align(q, refb, 0, gap=1.5, lut=lutq), "f32 lut x0.25 gap 1.5 |q|=%d" % len(q))
+    for q in reads[1:3]:
+        _cmp(ctx.align(q, refb, 0, 2.5, -1.75, 0.5), oracle.align(q, refb, 0, 2.5, -1.75, 0.5), "f32 2.5/-1.75/0.5")
+    # integer scores whose bound exceeds 16 bits: 2000 rows x 20 = 40000
+    q = pgs.synth.read_from_ref(ref, 999, 2000, sub_rate=0.02, indel_rate=0.004)[0].tobytes()
+    exp = oracle.align(q, refb, 0, 20.0, -15.0, 8.0)
+    assert exp["score"] > 32767
+    _cmp(ctx.align(q, refb, 0, 20.0, -15.0, 8.0), exp, "f32 score > 2^15")
