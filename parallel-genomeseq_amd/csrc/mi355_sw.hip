@@ -267,6 +267,9 @@ std::vector<Bucket> make_buckets(const QueryBatch &q, const ScoreTable &t, const
       // packed 16-bit cells when scores are small integers and the score bound fits; float32 cells otherwise
       const bool fits = t.integral && (int64_t)t.smax * std::min<int64_t>(b.maxlen, std::max<int64_t>(n, 1)) + t.smax <= 32000;
       b.sem = fits ? kSemI16 : kSemF32;
+      // a lone query would fill both halves of every packed register with itself; the float32 instance
+      // (one query per slot, exact for integer scores below 2^24) sweeps it ~1.5x faster
+      if (b.count == 1 && b.sem == kSemI16 && (double)t.smax * b.maxlen < 1.6e7) b.sem = kSemF32;
     }
     const double smax = b.sem == kSemF32 ? (double)t.smaxf : (double)t.smax;
     const double gap = b.sem == kSemF32 ? (double)t.gapf : (double)t.gap;
@@ -325,6 +328,11 @@ int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm) {
   // fill the chip: 256 CUs x 32 waves x 4 slots; shrink tiles while they stay >> warm-up
   while (cl > 2048 && cl / 2 >= 4 * warm &&
          (double)npairs * (double)((max_range_len + cl - 1) / cl) < 65536.0) cl /= 2;
+  // few tiles (one long query): filling the SIMDs beats the warm-up redundancy down to cl == warm
+  // (measured, 10 kbp x 250 Mbp: 1.17 s at 131 k columns, 0.58 s at 32 k; profiles/r01_config5*.log)
+  while (cl / 2 >= std::max<int64_t>(warm, 2048) &&
+         (double)npairs * (double)((max_range_len + cl - 1) / cl) < 8192.0) cl /= 2;
+  if (const char *e = std::getenv("MI355_SW_CHUNK")) { const long v = std::atol(e); if (v >= 256) cl = v / 64 * 64; }   // tuning aid
   return cl;
 }
 
