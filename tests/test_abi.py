@@ -70,3 +70,24 @@ def test_index_maps_match_reference(pgs, golden):
                 assert list(raw) == c["raw"][k]
                 assert pgs.capi.raw2true(m, n, *raw) == (ti, tj)
                 k += 1
+
+
+def test_dataset_tools(tmp_path):
+    """tools/make_dataset.py writes the reference drivers' file shapes; tools/eval_pos.py reproduces the
+    mismatch count of py/eval.py:112-121 on a driver-shaped CSV."""
+    import importlib.util
+    for name in ("make_dataset", "eval_pos"):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        globals()[name] = mod
+    make_dataset.main([str(tmp_path), "--ref-len", "5000", "--reads", "7", "--read-len", "50"])
+    ref = open(tmp_path / "custom_ref_1.fa").read().split("\n")
+    assert len(ref[0]) == 5000 and set(ref[0]) <= set("ACGT")
+    rows = open(tmp_path / "custom_reads_1.csv").read().splitlines()
+    assert rows[0] == "index,QNAME,SEQ,POS" and len(rows) == 8 and len(rows[1].split(",")[2]) == 50
+    fa = open(tmp_path / "genome.fa").read().splitlines()
+    assert fa[0].startswith(">") and "".join(fa[1:]) == ref[0]
+    out = tmp_path / "out.csv"
+    out.write_text("index,QNAME,SEQ,POS,pos_pred,score\n0,a,ACGT,10, 10, 12\n1,b,ACGT,20, 17, 12\n")
+    assert eval_pos.count_mismatches(str(out)) == (2, 1)
