@@ -27,7 +27,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (packed op = 1 lane-op)
-OPS_PER_CELL = {0: 2.4, 1: 2.9}  # VALU instructions per cell of sw_score_kernel<10,*>
+
+
+def kernel_shape(read_len):
+    """(SL, R) the library picks for this read length (mi355_sw.hip pick_shape) and the VALU instructions per
+    cell of that sw_score_kernel instance: per step and lane 4R (5R uint8) recurrence ops +
+    R/2 max-fold + DPP/mask/address/extract, for 2R cells."""
+    r16 = next(r for r in (2, 4, 6, 8, 10, 12, 16, 20, 24, 32) if r >= (read_len + 15) // 16)
+    r8 = next((r for r in (13, 16, 19, 26, 32) if r >= (read_len + 7) // 8), 0) if read_len >= 64 else 0
+    if r8 and 8 * r8 <= 16 * r16:
+        return 8, r8
+    return 16, r16
+
+
+def ops_per_cell(sl, r, sem):
+    over = 4 if sl == 8 else 3
+    core = (5 if sem == 1 else 4) * r + (r + 1) // 2 + (r % 2) + over
+    return core / (2.0 * r)
 
 
 def load_package():
@@ -182,6 +198,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    kshape = kernel_shape(args.read_len)
     if rank == 0:
         total_cells = cells_per_step * args.steps * world
         gcups = total_cells / dt * 1e-9
@@ -198,6 +215,7 @@ def main():
             except Exception:
                 traffic = None
         kern_cells_per_s = cells_per_step / avg_launch_s
+        opc = ops_per_cell(kshape[0], kshape[1], sem)
         line = {
             "metric": "GCUPS (cell updates/s), 150 bp reads vs 50 Mbp reference, whole job (score + argmax + traceback)",
             "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -210,13 +228,14 @@ def main():
                        "reads_per_gpu_per_step": args.reads, "read_len": args.read_len, "ref_len": args.ref_len,
                        "parallelism": "reads sharded x%d, reference replicated" % world, "score_only": bool(args.score_only)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "sw_score_kernel<R=%d>" % next(r for r in (2, 4, 6, 8, 10, 12, 16, 20, 24, 32) if r >= (args.read_len + 15) // 16),
+                         "traffic": traffic, "kernel": "sw_score_kernel<R=%d, SL=%d>" % (kshape[1], kshape[0]),
                          "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "scalar recurrence: VALU-bound, not HBM-bound (DESIGN.md §5); see valu"},
-            "valu": {"kernel_gcups": kern_cells_per_s * 1e-9, "lane_ops_per_cell": OPS_PER_CELL[sem],
-                     "achieved_lane_ops_per_s": kern_cells_per_s * OPS_PER_CELL[sem],
+            "valu": {"kernel_gcups": kern_cells_per_s * 1e-9, "lane_ops_per_cell": opc,
+                     "achieved_lane_ops_per_s": kern_cells_per_s * opc,
                      "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                     "frac": kern_cells_per_s * OPS_PER_CELL[sem] / VALU_PEAK_LANE_OPS},
+                     "frac": kern_cells_per_s * opc / VALU_PEAK_LANE_OPS,
+                     "note": "peak = 2 cycles per wave64 instruction; packed 16-bit (VOP3P) ops issue at 4 (profiles/r01_valu_instruction_rates.txt)"},
             "phases_ms_per_step": {"score_kernel": kern_us / args.steps * 1e-3, "locate": locate_us / args.steps * 1e-3,
                                    "traceback": trace_us / args.steps * 1e-3},
         }

@@ -196,6 +196,7 @@ struct Bucket {
   int first = 0, count = 0;   // positions in QueryBatch::order
   int maxlen = 0;
   int R = 0;
+  int SL = 16;                // lanes per tile: 16, or 8 where 8*R rows fit the reads more tightly
   int sem = kSemI16;          // kernel instance: kSemI16 / kSemU8 packed pairs, kSemF32 one query per slot
   bool strips = false;        // queries longer than one 512-row strip
   int64_t warm = 0;           // exactness margin in columns
@@ -208,6 +209,22 @@ int pick_R(int maxlen) {
   const int need = (maxlen + 15) / 16;
   for (int r : rs) if (r >= need) return r;
   return 0;
+}
+
+// 8-lane tiles: instances for the common short-read lengths (<= 104, 128, 152, 208, 256 rows)
+int pick_R8(int maxlen) {
+  static const int rs[] = {13, 16, 19, 26, 32};
+  const int need = (maxlen + 7) / 8;
+  for (int r : rs) if (r >= need) return r;
+  return 0;
+}
+
+// (SL, R) with the fewest padded rows; ties go to 8 lanes (fewer per-step overhead ops per cell)
+void pick_shape(int len, int &SL, int &R) {
+  SL = 16; R = len < 1 ? 2 : pick_R(len);
+  const int r8 = len < 64 ? 0 : pick_R8(len);
+  if (r8 && 8 * r8 <= 16 * R) { SL = 8; R = r8; }
+  if (const char *e = std::getenv("MI355_SW_SLOT")) { if (std::atoi(e) == 16) { SL = 16; R = len < 1 ? 2 : pick_R(len); } }   // tuning aid
 }
 
 ScoreTable plan_table(const RefData &ref, const mi355_sw_params &p) {
@@ -252,10 +269,11 @@ std::vector<Bucket> make_buckets(const QueryBatch &q, const ScoreTable &t, const
   for (size_t pos = 0; pos < q.nq; ++pos) {
     const int len = q.len[q.order[pos]];
     const bool strips = len > kMaxRowsFast;
-    const int R = strips ? 32 : (len < 1 ? 2 : pick_R(len));
-    if (out.empty() || out.back().R != R || out.back().strips != strips) {
+    int SL = 16, R = 32;
+    if (!strips) pick_shape(len, SL, R);
+    if (out.empty() || out.back().R != R || out.back().SL != SL || out.back().strips != strips) {
       Bucket b;
-      b.first = (int)pos; b.R = R; b.strips = strips;
+      b.first = (int)pos; b.R = R; b.SL = SL; b.strips = strips;
       out.push_back(b);
     }
     out.back().count++;
@@ -308,11 +326,19 @@ void launch_score(K kernel, dim3 grid, size_t shmem, hipStream_t st, const Score
 }
 
 template <int SEM>
-int launch_score_R(int R, bool strips, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
+int launch_score_R(int R, int SL, bool strips, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
   if (strips) {
-    if (R != 32) return -1;
+    if (R != 32 || SL != 16) return -1;
     launch_score(sw_score_kernel<32, SEM, true>, grid, shmem, st, a);
     return 0;
+  }
+  if (SL == 8) {
+    switch (R) {
+#define CASE_R8(r) case r: launch_score(sw_score_kernel<r, SEM, false, 8>, grid, shmem, st, a); return 0;
+      CASE_R8(13) CASE_R8(16) CASE_R8(19) CASE_R8(26) CASE_R8(32)
+#undef CASE_R8
+    }
+    return -1;
   }
   switch (R) {
 #define CASE_R(r) case r: launch_score(sw_score_kernel<r, SEM, false>, grid, shmem, st, a); return 0;
@@ -363,7 +389,8 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   const size_t npairs = b.sem == kSemF32 ? (size_t)b.count : ((size_t)b.count + 1) / 2;   // queries per workgroup: 1 or 2
   b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm);
   const int64_t cpr = (maxlen + b.chunk_len - 1) / b.chunk_len;
-  const int64_t cgroups = (cpr + 15) / 16;
+  const int nslot = 256 / b.SL;                                     // tiles per workgroup
+  const int64_t cgroups = (cpr + nslot - 1) / nslot;
   if ((double)npairs * (double)cgroups > 2.0e9) return fail(ctx, MI355_SW_ENOTSUP, "grid too large");
 
   ScoreArgs a;
@@ -389,25 +416,25 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   a.keys = ctx->keys.as<unsigned long long>();
 
   const int LS = lane_stride(b.R);
-  size_t shmem = (size_t)ref.ncodes * kSlotLanes * LS * 4 + 16 * kCodeBuf;
+  size_t shmem = (size_t)ref.ncodes * kSlotLanes * LS * 4 + (size_t)nslot * kCodeBuf;
   dim3 grid((unsigned)(npairs * cgroups), (unsigned)nr);
   a.brow = nullptr;
   a.brow_stride = 0;
   if (b.strips) {
     const int64_t nseg = (a.warm + b.chunk_len + kSlotLanes + kSeg - 1) / kSeg;
     a.brow_stride = (nseg + 3) * kSeg + 32;
-    const size_t slots = (size_t)grid.x * grid.y * 16;
+    const size_t slots = (size_t)grid.x * grid.y * nslot;
     const size_t bytes = slots * 2 * (size_t)a.brow_stride * 4;
     if (bytes > ((size_t)64 << 30)) return fail(ctx, MI355_SW_ENOTSUP, "strip-mined sweep needs more than 64 GiB of boundary scratch");
     if (ctx->brow.ensure(bytes)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(strip boundary rows) failed");
     HIPCHK(ctx, hipMemsetAsync(ctx->brow.p, 0, bytes, ctx->stream));
     a.brow = ctx->brow.as<uint32_t>();
-    shmem += 2 * 16 * kSeg * 4;
+    shmem += (size_t)2 * nslot * kSeg * 4;
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  int rc = b.sem == kSemU8 ? launch_score_R<kSemU8>(b.R, b.strips, grid, shmem, ctx->stream, a)
-           : b.sem == kSemF32 ? launch_score_R<kSemF32>(b.R, b.strips, grid, shmem, ctx->stream, a)
-                              : launch_score_R<kSemI16>(b.R, b.strips, grid, shmem, ctx->stream, a);
+  int rc = b.sem == kSemU8 ? launch_score_R<kSemU8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
+           : b.sem == kSemF32 ? launch_score_R<kSemF32>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
+                              : launch_score_R<kSemI16>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a);
   if (rc) return fail(ctx, MI355_SW_ENOTSUP, "no score kernel instance for this R");
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));

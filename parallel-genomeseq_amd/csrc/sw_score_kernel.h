@@ -30,7 +30,7 @@ namespace mi355sw {
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kSlotLanes = 16;
+constexpr int kSlotLanes = 16;         // lanes of a DPP row; a tile ("slot") takes 16 or 8 of them
 constexpr int kSeg = 64;               // steps between two refills of the code window
 constexpr int kHist = 16;              // bytes of history kept in front of a segment
 constexpr int kCodeBuf = kHist + kSeg; // bytes per slot
@@ -114,25 +114,30 @@ __device__ __forceinline__ uint32_t row_shr1(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
 }
 
-// STRIPS = false: the whole query (<= 16*R rows) is one strip held in registers.
-// STRIPS = true : the query is swept in strips of 16*R rows; the bottom row of strip s over the tile's
+// SL = lanes per tile ("slot"): 16 (one DPP row) or 8 (half a DPP row; the DPP shift then needs one mask op
+// per step, but 8*R rows fit the read length more tightly: 150 bp = 8 x 19 rows instead of 16 x 10).
+// STRIPS = false: the whole query (<= SL*R rows) is one strip held in registers.
+// STRIPS = true : the query is swept in strips of SL*R rows; the bottom row of strip s over the tile's
 // columns goes through a per-tile global scratch row (L2-resident) and enters strip s+1 through the
 // DPP `old` operand of lane 0, where the single-strip kernel gets the zero border row.
-template <int R, int SEM, bool STRIPS = false>
+template <int R, int SEM, bool STRIPS = false, int SL = 16>
 __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
-  static_assert(R % 2 == 0, "running max is folded on odd rows: R must be even");
+  static_assert(SL == 16 || SL == 8, "a slot is a whole or half DPP row");
+  static_assert(!(STRIPS && SL != 16), "the strip-mined instance uses whole DPP rows");
   constexpr int LS = lane_stride(R);
   constexpr int NQ4 = (R + 3) / 4;
+  constexpr int NSLOT = 256 / SL;                                  // tiles per workgroup
+  constexpr int CPL = kSeg / SL;                                   // reference codes fetched per lane per segment
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  uint32_t *prof = smem;                                           // [ncodes][16][LS]
-  uint8_t *codebuf = reinterpret_cast<uint8_t *>(smem + a.ncodes * kSlotLanes * LS);
-  // STRIPS: [16 slots][64] boundary-in window, then [16 slots][64] boundary-out staging
-  uint32_t *bwin = reinterpret_cast<uint32_t *>(codebuf + 16 * kCodeBuf);
+  uint32_t *prof = smem;                                           // [ncodes][16 lane positions][LS]
+  uint8_t *codebuf = reinterpret_cast<uint8_t *>(smem + a.ncodes * 16 * LS);
+  // STRIPS: [NSLOT][64] boundary-in window, then [NSLOT][64] boundary-out staging
+  uint32_t *bwin = reinterpret_cast<uint32_t *>(codebuf + NSLOT * kCodeBuf);
 
   const int tid = threadIdx.x;
-  const int l16 = tid & 15;
-  const int slot = tid >> 4;                                       // 0..15 within the workgroup
-  const int cgroups = (a.chunks_per_range + 15) >> 4;
+  const int ls = tid & (SL - 1);                                   // lane within the slot
+  const int slot = tid / SL;                                       // 0..NSLOT-1 within the workgroup
+  const int cgroups = (a.chunks_per_range + NSLOT - 1) / NSLOT;
   const int pair = blockIdx.x / cgroups;
   const int cg = blockIdx.x - pair * cgroups;
   const int range = blockIdx.y;
@@ -143,17 +148,19 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   const int qA = a.qsel[a.qfirst + NQ * pair];
   const int qB = hasB ? a.qsel[a.qfirst + 2 * pair + 1] : qA;
 
-  // ---- query profile for this workgroup's pair (rows row0 .. row0 + 16R - 1) ---------------
+  // ---- query profile for this workgroup's pair (rows row0 .. row0 + SL*R - 1) --------------
+  // 16 lane positions of a DPP row; with SL = 8 positions 8..15 repeat 0..7, so that the sixteen lanes of a
+  // ds_read_b128 lane group still hit disjoint banks
   const int mA = a.qlen[qA], mB = a.qlen[qB];
   auto build_profile = [&](int row0) {
     const uint8_t *xA = a.qbytes + a.qoff[qA];
     const uint8_t *xB = a.qbytes + a.qoff[qB];
-    const int per_code = kSlotLanes * R;
+    const int per_code = 16 * R;
     for (int e = tid; e < a.ncodes * per_code; e += 256) {
       const int c = e / per_code;
       const int rem = e - c * per_code;
       const int ll = rem / R, r = rem - ll * R;
-      const int i = row0 + ll * R + r;
+      const int i = row0 + (ll & (SL - 1)) * R + r;
       uint32_t e32;
       if (SEM == kSemF32) {
         const float *ft = static_cast<const float *>(a.stab);
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
         const int sb = (i < mB) ? st[(int)xB[i] * a.ncodes + c] : kPadScore;
         e32 = (uint32_t)(uint16_t)sa | ((uint32_t)(uint16_t)sb << 16);
       }
-      prof[(c * kSlotLanes + ll) * LS + r] = e32;
+      prof[(c * 16 + ll) * LS + r] = e32;
     }
   };
   build_profile(0);
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   // ---- this slot's tile -------------------------------------------------------------------
   const int64_t rlo = a.range_lo[range], rhi = a.range_hi[range];
   const int64_t nchunks = (rhi - rlo + a.chunk_len - 1) / a.chunk_len;
-  const int64_t chunk = (int64_t)cg * 16 + slot;
+  const int64_t chunk = (int64_t)cg * NSLOT + slot;
   const bool active = chunk < nchunks;
   const int64_t own_lo = rlo + chunk * a.chunk_len;
   const int64_t own_hi = (own_lo + a.chunk_len < rhi) ? own_lo + a.chunk_len : rhi;
@@ -180,38 +187,49 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   const uint32_t pad = (uint32_t)(a.ncodes - 1);
   const uint32_t pad4 = pad * 0x01010101u;
 
-  // codes of stream positions seg*64 + 4*l16 .. +3 (pad outside [rlo, own_hi))
-  auto stage_load = [&](int seg) -> uint32_t {
-    const int64_t c0 = s0 + (int64_t)seg * kSeg + 4 * l16;
-    uint32_t w = 0;
+  // codes of stream positions seg*64 + CPL*ls .. +CPL-1 (pad outside [rlo, own_hi)), CPL/4 dwords
+  struct Codes { uint32_t w[CPL / 4]; };
+  auto stage_load = [&](int seg) -> Codes {
+    Codes out;
+    const int64_t c0 = s0 + (int64_t)seg * kSeg + CPL * ls;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int64_t col = c0 + b;
-      const bool ok = active && col >= rlo && col < own_hi;
-      const uint32_t code = ok ? (uint32_t)a.refcodes[col] : pad;
-      w |= code << (8 * b);
+    for (int d = 0; d < CPL / 4; ++d) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int64_t col = c0 + 4 * d + b;
+        const bool ok = active && col >= rlo && col < own_hi;
+        const uint32_t code = ok ? (uint32_t)a.refcodes[col] : pad;
+        w |= code << (8 * b);
+      }
+      out.w[d] = w;
     }
-    return w;
+    return out;
   };
 
   uint8_t *buf = codebuf + slot * kCodeBuf;
   uint32_t *buf32 = reinterpret_cast<uint32_t *>(buf);
-  const uint8_t *buf_lane = buf + kHist - l16;                     // + k = code of step k
-  const uint32_t *prof_lane = prof + l16 * LS;
+  const uint8_t *buf_lane = buf + kHist - ls;                      // + k = code of step k
+  const uint32_t *prof_lane = prof + (tid & 15) * LS;
+  auto window_put = [&](const Codes &c) {
+#pragma unroll
+    for (int d = 0; d < CPL / 4; ++d) buf32[kHist / 4 + (CPL / 4) * ls + d] = c.w[d];
+  };
 
-  const int64_t total_steps = a.warm + a.chunk_len + kSlotLanes;   // +15 skew, +1 max-fold drain
+  const int64_t total_steps = a.warm + a.chunk_len + SL;           // + SL-1 skew, + 1 max-fold drain
   const int nseg = (int)((total_steps + kSeg - 1) / kSeg);
 
   T mx = C::from_bits(0u);
-  const int code_stride = kSlotLanes * LS;                         // dwords per reference code
-  const int strip_rows = kSlotLanes * R;
+  const int code_stride = 16 * LS;                                 // dwords per reference code
+  const int strip_rows = SL * R;
   const int mmax = mA > mB ? mA : mB;
   const int nstrips = STRIPS ? (mmax + strip_rows - 1) / strip_rows : 1;
+  const uint32_t first_lane_zero = ls == 0 ? 0u : 0xFFFFFFFFu;     // SL = 8: zero border row for lane 0 of the slot
   // STRIPS: this tile's ping-pong boundary rows (global), and its LDS windows
-  const size_t tile_id = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + slot;
+  const size_t tile_id = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NSLOT + slot;
   uint32_t *brow0 = STRIPS ? a.brow + tile_id * 2 * (size_t)a.brow_stride : nullptr;
   uint32_t *bin_w = bwin + slot * kSeg;
-  uint32_t *bout_w = bwin + 16 * kSeg + slot * kSeg;
+  uint32_t *bout_w = bwin + NSLOT * kSeg + slot * kSeg;
 
   for (int strip = 0; strip < nstrips; ++strip) {
     if (STRIPS && strip > 0) {
@@ -224,17 +242,17 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
     const uint32_t *bin_g = STRIPS ? brow0 + (size_t)(strip & 1) * a.brow_stride + 16 : nullptr;
     uint32_t *bout_g = STRIPS ? brow0 + (size_t)((strip + 1) & 1) * a.brow_stride + 16 : nullptr;
     const bool rd = STRIPS && strip > 0, wr = STRIPS && strip + 1 < nstrips;
-    auto bin_load = [&](int seg) -> uint4 {                       // boundary values of stream positions seg*64+4*l16..+3
-      return rd ? *reinterpret_cast<const uint4 *>(bin_g + (size_t)seg * kSeg + 4 * l16) : make_uint4(0, 0, 0, 0);
+    auto bin_load = [&](int seg) -> uint4 {                       // boundary values of stream positions seg*64+4*ls..+3
+      return rd ? *reinterpret_cast<const uint4 *>(bin_g + (size_t)seg * kSeg + 4 * ls) : make_uint4(0, 0, 0, 0);
     };
 
-    uint32_t nextcodes = stage_load(0);
-    if (l16 < kHist / 4) buf32[l16] = pad4;
-    buf32[kHist / 4 + l16] = nextcodes;
+    Codes nextcodes = stage_load(0);
+    if (ls < kHist / 4) buf32[ls] = pad4;
+    window_put(nextcodes);
     nextcodes = stage_load(1);
     uint4 nextb = make_uint4(0, 0, 0, 0);
     if (STRIPS) {
-      *reinterpret_cast<uint4 *>(bin_w + 4 * l16) = bin_load(0);
+      *reinterpret_cast<uint4 *>(bin_w + 4 * ls) = bin_load(0);
       nextb = bin_load(1);
     }
     __syncthreads();                                               // profile + first window ready
@@ -261,6 +279,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
           up = (uint32_t)__builtin_amdgcn_update_dpp((int)bin_w[k], (int)C::bits(H[R - 1]), 0x111, 0xf, 0xf, false);
         } else {
           up = row_shr1(C::bits(H[R - 1]));
+          if (SL == 8) up &= first_lane_zero;                      // lane 8 of the DPP row starts another tile
         }
         T diag = C::from_bits(up_prev);                            // H(i0-1, j-1)
         T north = C::from_bits(up);
@@ -270,30 +289,31 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
           const T w = H[r];
           const T x = C::add(diag, C::from_bits(p[r]), a.clamp2);
           const T t = C::vmax(w, north);
-          if (r & 1) mx = C::vmax(mx, t);
+          if (r & 1) mx = C::vmax(mx, t);                          // covers (r, j-1) and (r-1, j)
           const T y = C::sub_gap(t, a.gap2);
           const T h = C::cell(x, y);
           diag = w;
           H[r] = h;
           north = h;
         }
+        if (R & 1) mx = C::vmax(mx, H[R - 1]);                     // odd R: the last (even) row is in no tracked t
         if (STRIPS) {
-          if (l16 == 15) bout_w[k] = C::bits(H[R - 1]);            // bottom row at stream position seg*64+k-15
+          if (ls == SL - 1) bout_w[k] = C::bits(H[R - 1]);         // bottom row at stream position seg*64+k-(SL-1)
         }
       }
       // slide the code window: keep the last 16 bytes as history, append the prefetched segment
-      const uint32_t hist = buf32[kSeg / 4 + (l16 & 3)];
-      if (l16 < kHist / 4) buf32[l16] = hist;
-      buf32[kHist / 4 + l16] = nextcodes;
+      const uint32_t hist = buf32[kSeg / 4 + (ls & 3)];
+      if (ls < kHist / 4) buf32[ls] = hist;
+      window_put(nextcodes);
       nextcodes = stage_load(seg + 2);
       if (STRIPS) {
         if (wr) {
-          // flush 64 bottom-row values: positions seg*64 - 15 + (0..63)
-          uint32_t *g = bout_g + (int64_t)seg * kSeg - 15 + 4 * l16;
-          const uint4 v = *reinterpret_cast<const uint4 *>(bout_w + 4 * l16);
+          // flush 64 bottom-row values: positions seg*64 - (SL-1) + (0..63)
+          uint32_t *g = bout_g + (int64_t)seg * kSeg - (SL - 1) + 4 * ls;
+          const uint4 v = *reinterpret_cast<const uint4 *>(bout_w + 4 * ls);
           g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
         }
-        *reinterpret_cast<uint4 *>(bin_w + 4 * l16) = nextb;
+        *reinterpret_cast<uint4 *>(bin_w + 4 * ls) = nextb;
         nextb = bin_load(seg + 2);
       }
     }
@@ -302,11 +322,11 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   // ---- per-tile maximum -> per-query key -------------------------------------------------
   uint32_t m32 = C::bits(mx);
 #pragma unroll
-  for (int off = 8; off >= 1; off >>= 1) {
-    const uint32_t o = (uint32_t)__shfl_xor((int)m32, off, 16);
+  for (int off = SL / 2; off >= 1; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)m32, off, SL);
     m32 = C::bits(C::vmax(C::from_bits(m32), C::from_bits(o)));
   }
-  if (l16 == 0 && active) {
+  if (ls == 0 && active) {
     const unsigned long long tag = 0xFFFFFFFFull - (unsigned long long)chunk;
     unsigned long long *k = a.keys + (size_t)range * a.nq;
     if (SEM == kSemF32) {
