@@ -201,7 +201,8 @@ struct Bucket {
   bool strips = false;        // queries longer than one 512-row strip
   int64_t warm = 0;           // exactness margin in columns
   bool fast = false;          // swept by the score kernel (else whole-matrix exact path)
-  int64_t chunk_len = 0;
+  int64_t chunk_len = 0;      // own columns per tile
+  int64_t sub_len = 0;        // granularity at which tile maxima are reported (= what locate re-runs)
 };
 
 int pick_R(int maxlen) {
@@ -293,7 +294,7 @@ std::vector<Bucket> make_buckets(const QueryBatch &q, const ScoreTable &t, const
     const double gap = b.sem == kSemF32 ? (double)t.gapf : (double)t.gap;
     if (smax <= 0 || gap <= 0) b.warm = 0;
     else b.warm = (int64_t)b.maxlen + (int64_t)std::ceil(smax * b.maxlen / gap);
-    b.warm = (b.warm + 3) / 4 * 4;
+    b.warm = (b.warm + 63) / 64 * 64;
   }
   return out;
 }
@@ -349,7 +350,7 @@ int launch_score_R(int R, int SL, bool strips, dim3 grid, size_t shmem, hipStrea
 }
 
 int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm) {
-  int64_t cl = 16384;
+  int64_t cl = 65536;
   while (cl < 8 * warm) cl *= 2;                 // long queries: keep the warm-up redundancy bounded
   // fill the chip: 256 CUs x 32 waves x 4 slots; shrink tiles while they stay >> warm-up
   while (cl > 2048 && cl / 2 >= 4 * warm &&
@@ -388,6 +389,11 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   for (auto &r : ranges) maxlen = std::max(maxlen, r.hi - r.lo);
   const size_t npairs = b.sem == kSemF32 ? (size_t)b.count : ((size_t)b.count + 1) / 2;   // queries per workgroup: 1 or 2
   b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm);
+  // report maxima per 4096-column sub-chunk (>= query length, so that the uint8 storage order stays within
+  // two neighbouring sub-chunks); the strip-mined instance reports per tile
+  b.sub_len = 4096;
+  while (b.sub_len < b.maxlen) b.sub_len *= 2;
+  if (b.strips || b.sub_len > b.chunk_len || b.chunk_len % b.sub_len != 0) b.sub_len = b.chunk_len;
   const int64_t cpr = (maxlen + b.chunk_len - 1) / b.chunk_len;
   const int nslot = 256 / b.SL;                                     // tiles per workgroup
   const int64_t cgroups = (cpr + nslot - 1) / nslot;
@@ -399,6 +405,7 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   a.range_lo = ctx->ranges.as<int64_t>();
   a.range_hi = ctx->ranges.as<int64_t>() + nr;
   a.chunk_len = b.chunk_len;
+  a.sub_len = b.sub_len;
   a.warm = (cpr == 1) ? 0 : b.warm;              // a single tile per range starts at the range's own border
   a.chunks_per_range = (int)cpr;
   a.qbytes = q.bytes.as<uint8_t>();
@@ -752,9 +759,9 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
     if (qfloat[k]) { const uint32_t bits = (uint32_t)(key >> 32); memcpy(&score, &bits, 4); }
     else score = (float)(int)(key >> 32);
     if (!(score > 0)) continue;
-    const int64_t chunk_len = qchunk[k];
+    const int64_t chunk_len = qchunk[k];           // sub-chunk granularity of this query's bucket
     const int64_t nchunks = (n + chunk_len - 1) / chunk_len;
-    const int64_t warm = nchunks == 1 ? 0 : qwarm[k];
+    const int64_t warm = qwarm[k];
     const int64_t first = (int64_t)(0xFFFFFFFFull - (key & 0xFFFFFFFFull));
     loc[k].score = score;
     int64_t cand[5];
@@ -772,8 +779,9 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
       }
     }
     for (int t = 0; t < nc; ++t) {
-      const int64_t own_lo = cand[t] * chunk_len;               // range-relative, 0-based
-      const int64_t own_hi = std::min(own_lo + chunk_len, n);
+      // lanes lag by up to 15 columns: the end of the previous sub-chunk is reported with this one
+      const int64_t own_lo = std::max<int64_t>(0, cand[t] * chunk_len - 15);   // range-relative, 0-based
+      const int64_t own_hi = std::min((cand[t] + 1) * chunk_len, n);
       const int64_t wl = std::max<int64_t>(0, own_lo - warm);
       ExactJob j;
       j.q = (int)k; j.ylo = rg.lo + wl; j.nw = (int32_t)(own_hi - wl); j.col_offset = wl; j.full_n = n;
@@ -830,7 +838,7 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
         if (rc) return rc;
         for (int k = 0; k < b.count; ++k) {
           const int id = q.order[b.first + k];
-          qfast[id] = 1; qchunk[id] = b.chunk_len; qwarm[id] = b.warm; qfloat[id] = b.sem == kSemF32;
+          qfast[id] = 1; qchunk[id] = b.sub_len; qwarm[id] = b.warm; qfloat[id] = b.sem == kSemF32;
         }
       }
       std::vector<unsigned long long> keys;

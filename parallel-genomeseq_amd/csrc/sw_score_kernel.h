@@ -55,7 +55,8 @@ struct ScoreArgs {
   const int64_t *range_lo;   // [nranges] sub-problems (pieces) of the reference, [lo,hi)
   const int64_t *range_hi;
   int64_t chunk_len;         // own columns per tile
-  int64_t warm;              // warm-up columns recomputed in front of a tile
+  int64_t sub_len;           // the tile's maximum is reported per sub-chunk of sub_len columns (divides chunk_len)
+  int64_t warm;              // warm-up columns recomputed in front of a tile; multiple of 64
   int chunks_per_range;      // max over ranges
   const uint8_t *qbytes;     // concatenated raw query bytes
   const int64_t *qoff;       // [nq] byte offset of each query
@@ -68,7 +69,7 @@ struct ScoreArgs {
   int ncodes;
   uint32_t gap2;             // gap penalty in both halves (packed) / float bits (kSemF32)
   uint32_t clamp2;           // 255 in both halves (U8SAT)
-  unsigned long long *keys;  // [nranges][nq]  (max << 32) | (0xFFFFFFFF - chunk)
+  unsigned long long *keys;  // [nranges][nq]  (max << 32) | (0xFFFFFFFF - sub-chunk index in the range)
   // strip-mined variant only (queries longer than 16*R rows): boundary rows between strips,
   // two ping-pong buffers of brow_stride dwords per tile, 16 dwords of front padding each
   uint32_t *brow;
@@ -231,6 +232,32 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   uint32_t *bin_w = bwin + slot * kSeg;
   uint32_t *bout_w = bwin + NSLOT * kSeg + slot * kSeg;
 
+  // per-sub-chunk maximum -> per-query key.  Lanes lag lane 0 by up to SL-1 columns, so up to SL-1 trailing
+  // columns of a sub-chunk are reported with the next one; the host widens its search accordingly.
+  const int64_t subs_per_tile = a.chunk_len / a.sub_len;
+  auto publish = [&](int64_t sub) {
+    uint32_t m32 = C::bits(mx);
+#pragma unroll
+    for (int off = SL / 2; off >= 1; off >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)m32, off, SL);
+      m32 = C::bits(C::vmax(C::from_bits(m32), C::from_bits(o)));
+    }
+    if (ls == 0 && active && m32 != 0) {
+      const unsigned long long tag = 0xFFFFFFFFull - (unsigned long long)(chunk * subs_per_tile + sub);
+      unsigned long long *k = a.keys + (size_t)range * a.nq;
+      if (SEM == kSemF32) {
+        atomicMax(k + qA, ((unsigned long long)m32 << 32) | tag);   // non-negative floats order like their bits
+      } else {
+        if (m32 & 0xFFFFu) atomicMax(k + qA, ((unsigned long long)(m32 & 0xFFFFu) << 32) | tag);
+        if (hasB && (m32 >> 16)) atomicMax(k + qB, ((unsigned long long)(m32 >> 16) << 32) | tag);
+      }
+    }
+    mx = C::from_bits(0u);
+  };
+  const int segs_per_sub = (int)(a.sub_len / kSeg);
+  const int warm_segs = (int)(a.warm / kSeg);
+  int64_t sub = 0;
+
   for (int strip = 0; strip < nstrips; ++strip) {
     if (STRIPS && strip > 0) {
       // the boundary row written by this tile's own lanes in the previous strip is re-read below:
@@ -306,6 +333,11 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
       if (ls < kHist / 4) buf32[ls] = hist;
       window_put(nextcodes);
       nextcodes = stage_load(seg + 2);
+      if (!STRIPS) {
+        // lane 0 has just finished a sub-chunk (and it is not the tile's last): report and restart the maximum
+        const int done = seg + 1 - warm_segs;
+        if (done > 0 && done % segs_per_sub == 0 && done / segs_per_sub < subs_per_tile) publish(sub++);
+      }
       if (STRIPS) {
         if (wr) {
           // flush 64 bottom-row values: positions seg*64 - (SL-1) + (0..63)
@@ -319,24 +351,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
     }
   }
 
-  // ---- per-tile maximum -> per-query key -------------------------------------------------
-  uint32_t m32 = C::bits(mx);
-#pragma unroll
-  for (int off = SL / 2; off >= 1; off >>= 1) {
-    const uint32_t o = (uint32_t)__shfl_xor((int)m32, off, SL);
-    m32 = C::bits(C::vmax(C::from_bits(m32), C::from_bits(o)));
-  }
-  if (ls == 0 && active) {
-    const unsigned long long tag = 0xFFFFFFFFull - (unsigned long long)chunk;
-    unsigned long long *k = a.keys + (size_t)range * a.nq;
-    if (SEM == kSemF32) {
-      // non-negative floats order like their bit patterns
-      atomicMax(k + qA, ((unsigned long long)m32 << 32) | tag);
-    } else {
-      atomicMax(k + qA, ((unsigned long long)(m32 & 0xFFFFu) << 32) | tag);
-      if (hasB) atomicMax(k + qB, ((unsigned long long)(m32 >> 16) << 32) | tag);
-    }
-  }
+  publish(sub);                                                    // the tile's last (or only) sub-chunk
 }
 
 }  // namespace mi355sw
