@@ -7,7 +7,7 @@
 //                                         reference's storage order -> argmax cell
 //   3. traceback       sw_exact_kernel  — window left of the argmax -> greedy decisions,
 //                      sw_walk_kernel   — the walk itself (smithwaterman.cpp:40-78)
-// Problems the score kernel does not cover (see fast_eligible) run 2+3 on the whole matrix.
+// Problems the score kernel does not cover (see bucket_fast_ok) run 2+3 on the whole matrix.
 #include "../../include/mi355_sw.h"
 
 #include <hip/hip_runtime.h>
@@ -481,6 +481,9 @@ struct ExactJob {
   size_t dirs_off = 0;
 };
 
+// bytes of the diagonal-major decision array of an (m x nw) window (sw_exact_kernel.h)
+size_t dirs_bytes(int64_t m, int64_t nw) { return (size_t)(m + nw + 1) * (size_t)std::max<int64_t>(1, std::min(m, nw)) + 16; }
+
 size_t exact_lds_bytes(int m, int nw) { return (size_t)3 * (std::min(m, nw) + 2) * 4 + (size_t)m + 16; }
 
 ExactScoring make_scoring(mi355_sw_ctx *ctx, const mi355_sw_params &p, bool &lut_uploaded, int &rc) {
@@ -510,7 +513,7 @@ int run_exact(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   for (size_t k = lo; k < hi; ++k) {
     ExactJob &j = jobs[k];
     lds = std::max(lds, exact_lds_bytes(q.len[j.q], j.nw));
-    if (j.want_dirs) { j.dirs_off = dirs_total; dirs_total += ((size_t)j.nw + 1) * ((size_t)q.len[j.q] + 1); dirs_total = (dirs_total + 15) & ~(size_t)15; }
+    if (j.want_dirs) { j.dirs_off = dirs_total; dirs_total += dirs_bytes(q.len[j.q], j.nw); dirs_total = (dirs_total + 15) & ~(size_t)15; }
   }
   if (lds > kExactLdsMax) return fail(ctx, MI355_SW_ENOTSUP, "anti-diagonal longer than the exact kernel's LDS window");
   if (ctx->probs.ensure(n * sizeof(ExactProblem)) || ctx->outs_f.ensure(n * 4) || ctx->outs_i.ensure(n * 16) ||
@@ -661,13 +664,13 @@ int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, co
         int64_t wl = iy - (budget[k] + warm);           // range-relative 0-based start of window
         if (wl < 0) wl = 0;
         const int64_t nw = iy - wl;
-        const size_t need = ((size_t)nw + 1) * ((size_t)q.len[qi] + 1) + 16;
+        const size_t need = dirs_bytes(q.len[qi], nw) + 16;
         if (need > kDirsBudget) return fail(ctx, MI355_SW_ENOTSUP, "traceback window exceeds the device scratch budget");
         if (!jobs.empty() && bytes + need > kDirsBudget) break;
         ExactJob j;
         j.q = qi; j.ylo = rg.lo + wl; j.nw = (int32_t)nw; j.col_offset = wl; j.full_n = rg.hi - rg.lo;
         j.own_lo = (int32_t)(nw + 1);                   // nothing competes: decisions only
-        j.quirk = 0;                                    // |x| == |y| never reaches the score path (range_fast_ok)
+        j.quirk = 0;                                    // |x| == |y| never reaches the score path (bucket_fast_ok)
         j.target = 1e30f; j.want_dirs = true;
         jobs.push_back(j); owner.push_back(k);
         starts.emplace_back((int32_t)loc[k].ix, (int32_t)nw);
@@ -707,7 +710,7 @@ int exact_full(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
     size_t bytes = 0;
     while (pos < qidx.size()) {
       const int qi = qidx[pos];
-      const size_t need = ((size_t)n + 1) * ((size_t)q.len[qi] + 1) + 16;
+      const size_t need = dirs_bytes(q.len[qi], n) + 16;
       if (want_trace && need > kDirsBudget) return fail(ctx, MI355_SW_ENOTSUP, "problem needs the score kernel but is outside its coverage");
       if (!jobs.empty() && want_trace && bytes + need > kDirsBudget) break;
       if (jobs.size() >= 65536) break;

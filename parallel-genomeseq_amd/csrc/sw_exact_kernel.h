@@ -30,7 +30,9 @@ struct ExactProblem {
   int32_t own_lo;         // only local columns >= own_lo compete for the argmax
   int32_t square_quirk;   // uint8 engine with |x| == |y|, window == whole problem
   float target;           // >= 0: only cells equal to target compete; < 0: track the maximum
-  uint8_t *dirs;          // [(nw+1)][(m+1)] traceback decisions, or null
+  uint8_t *dirs;          // traceback decisions, diagonal-major: dirs[d * dstride + (i - max(1, d - nw))] for
+                          // cell (i, jl), d = i + jl, dstride = min(m, nw) — lanes of a diagonal store
+                          // consecutive bytes; or null
   float *hout;            // [(nw+1)][(m+1)] matrix values, or null (borders pre-zeroed)
   // outputs
   float *best;            // maximum (or target) found, -1 when nothing competed
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(NT) void sw_exact_kernel(const ExactProblem *probs,
   int64_t bi = 0, bj = 0;
   const float g = sc.gap;
 
+  const int dstride = m < nw ? m : nw;
   float *Dc = D0, *Dp = D1, *Dpp = D2;   // current, d-1, d-2
   // diagonals d = i + jl; d = 0 and 1 are all border (zero, already cleared)
   for (int d = 2; d <= m + nw; ++d) {
@@ -118,8 +121,7 @@ __global__ __launch_bounds__(NT) void sw_exact_kernel(const ExactProblem *probs,
         h = fmaxf(fmaxf(xx, yy), zz);
       }
       Dc[ic] = h;
-      const size_t off = (size_t)jl * (size_t)(m + 1) + (size_t)i;
-      if (P.hout) P.hout[off] = h;
+      if (P.hout) P.hout[(size_t)jl * (size_t)(m + 1) + (size_t)i] = h;
       if (P.dirs) {
         // smithwaterman.cpp:51,59,66,72 evaluated at cell (i, jl)
         int dir;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(NT) void sw_exact_kernel(const ExactProblem *probs,
         else if (n1 >= n2 && n1 >= n3) dir = kDirNW;
         else if (n2 >= n1 && n2 >= n3) dir = kDirW;
         else dir = kDirN;
-        P.dirs[off] = (uint8_t)dir;
+        P.dirs[(size_t)d * (size_t)dstride + (size_t)(i - ilo)] = (uint8_t)dir;
       }
       if (jl >= P.own_lo && h > 0.0f) {
         const bool cand = (P.target >= 0.0f) ? (h == P.target) : (h >= best);
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(NT) void sw_exact_kernel(const ExactProblem *probs,
 struct WalkProblem {
   const uint8_t *x;
   const uint8_t *y;       // window base, as ExactProblem::y
-  const uint8_t *dirs;    // [(nw+1)][(m+1)]
+  const uint8_t *dirs;    // diagonal-major, as ExactProblem::dirs
   int32_t m, nw;
   int32_t start_i, start_jl;
   int32_t exact_lo;       // decisions at local columns < exact_lo read inexact cells (0 = all exact)
@@ -196,7 +198,10 @@ __global__ void sw_walk_kernel(const WalkProblem *probs, int n) {
     // the decision at (ix, jl) looks at columns jl-1 and jl: both must be exact
     if (jl - 1 < W.exact_lo && W.exact_lo > 0) { status = 1; break; }
     if (len >= W.cap) { status = 2; break; }
-    const int dir = W.dirs[(size_t)jl * (size_t)(W.m + 1) + (size_t)ix];
+    const int d = ix + jl;
+    const int ilo = d - W.nw > 1 ? d - W.nw : 1;
+    const int dstride = W.m < W.nw ? W.m : W.nw;
+    const int dir = W.dirs[(size_t)d * (size_t)dstride + (size_t)(ix - ilo)];
     if (dir == kDirStop) {
       W.cons_x[len] = (char)W.x[ix - 1]; W.cons_y[len] = (char)W.y[jl - 1]; ++len;
       pos = W.col_offset + jl;
