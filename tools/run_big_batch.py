@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Robustness run: a larger slice of config 3 (default 8192 x 150 bp reads vs 50 Mbp) in ONE batch call,
+checked by the planted-read property (reads are substrings with 1 % substitutions: end_y must be the cut
+position + 150 for almost all of them and score >= 390)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g  # noqa: E402
+
+pgs = g._load_package()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+ref = pgs.synth.dna(3, 50_000_000)
+reads, offs = pgs.synth.fast_reads_from_ref(ref, 4, n, 150)
+ctx = pgs.Context(0)
+ctx.set_reference(ref)
+ctx.batch_upload([r.tobytes() for r in reads])
+t0 = time.time()
+out = ctx.batch_run(semantics=pgs.F32, raw=True)
+dt = time.time() - t0
+tm = ctx.last_timings()
+ok = (out["end_y"] == offs + 150)
+print("reads %d  wall %.2fs  %.1f GCUPS  launches %d  score_kernel %.1f ms  end_y==cut+150: %.4f  min score %d" %
+      (n, dt, n * 150 * 50e6 / dt * 1e-9, tm["score_launches"], tm["score_us"] / 1e3, ok.mean(), out["score"].min()))
+assert ok.mean() > 0.97 and out["score"].min() >= 380
+ctx.close()
