@@ -220,7 +220,8 @@ def main():
             "metric": "GCUPS (cell updates/s), 150 bp reads vs 50 Mbp reference, whole job (score + argmax + traceback)",
             "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "i16 (packed 2x16-bit cells; exact for the float32 engine's integer scores)" if sem == pgs.F32 else "u8 (saturating, held in packed 16-bit lanes)",
+            "dtype": ("f32" if (args.match != int(args.match) or args.mismatch != int(args.mismatch) or args.gap != int(args.gap)) else "i16") if sem == pgs.F32 else "u8",
+            "dtype_note": "i16 = packed 2x16-bit cells, exact for the float32 engine's integer scores; u8 = saturating uint8 semantics held in packed 16-bit lanes; f32 = float32 cells (fractional scoring)",
             "data": "synthetic",
             "config": {"workload": "configs[2]: %d x %d bp reads per GPU per step vs %d bp reference (one batch of the 100k-read set)"
                                    % (args.reads, args.read_len, args.ref_len),

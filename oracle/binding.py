@@ -141,3 +141,13 @@ def raw2true(m, n, ri, rj):
     lib().sw_oracle_raw2true(C.c_size_t(ri), C.c_size_t(rj), C.c_size_t(nrows), C.c_size_t(ncols),
                              C.c_size_t(len_x), C.c_size_t(len_y), C.byref(ti), C.byref(tj))
     return ti.value, tj.value
+
+
+def locate(x, y, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None):
+    """(score, index_x, index_y) of find_index_of_maximum without the matrix (sizes beyond memory)."""
+    x, y = _b(x), _b(y)
+    sc, keep = _scoring(match, mismatch, gap, lut)
+    mx, ix, iy = C.c_float(), C.c_int64(), C.c_int64()
+    lib().sw_oracle_locate(x, C.c_size_t(len(x)), y, C.c_size_t(len(y)), C.byref(sc), C.c_int(semantics),
+                           C.byref(mx), C.byref(ix), C.byref(iy))
+    return mx.value, ix.value, iy.value

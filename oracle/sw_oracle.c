@@ -319,3 +319,50 @@ float sw_oracle_score_only(const char *x, size_t m, const char *y, size_t n,
     return (float)best;
   }
 }
+
+/* src/aligner/similaritymatrix.cpp:21-28 / :291-299 without storing the matrix (see sw_oracle.h). */
+void sw_oracle_locate(const char *x, size_t m, const char *y, size_t n, const sw_oracle_scoring *sc,
+                      int semantics, float *mx, int64_t *ix, int64_t *iy) {
+  *mx = 0; *ix = 0; *iy = 0;
+  if (semantics == SW_ORACLE_F32) {
+    float *col = (float *)calloc(m + 1, sizeof(float));
+    float best = 0;
+    for (size_t j = 1; j <= n; ++j) {
+      float nw = 0, north = 0;
+      const char b = y[j - 1];
+      for (size_t i = 1; i <= m; ++i) {
+        float w = col[i];
+        float h = dp_f32(north, w, nw, score_of(sc, x[i - 1], b), sc->gap);
+        nw = w; col[i] = h; north = h;
+        if (h > best) { best = h; *ix = (int64_t)i; *iy = (int64_t)j; }   /* columns outer, rows inner, strict */
+      }
+    }
+    free(col);
+    *mx = best;
+  } else {
+    const u8_params p = u8_params_of(sc);
+    const size_t len_x = n + 1, len_y = m + 1;
+    const size_t nrows = len_x < len_y ? len_x : len_y;
+    const size_t ncols = len_x < len_y ? len_y : len_x;
+    uint8_t *col = (uint8_t *)calloc(m + 1, 1);
+    uint8_t best = 0;
+    size_t bri = 0, brj = 0;
+    for (size_t j = 1; j <= n; ++j) {
+      uint8_t nw = 0, north = 0, north2 = 0;
+      const char b = y[j - 1];
+      for (size_t i = 1; i <= m; ++i) {
+        uint8_t w = col[i];
+        uint8_t d = (m == n && i + j == n + 1) ? north2 : nw;
+        uint8_t h = dp_u8(north, w, d, x[i - 1] == b, p);
+        nw = w; col[i] = h; north2 = north; north = h;
+        if (h >= best && h > 0) {
+          size_t ri, rj;
+          sw_oracle_true2raw(j, i, nrows, ncols, len_x, len_y, &ri, &rj);
+          if (h > best || rj < brj || (rj == brj && ri < bri)) { best = h; bri = ri; brj = rj; *ix = (int64_t)i; *iy = (int64_t)j; }
+        }
+      }
+    }
+    free(col);
+    *mx = (float)best;
+  }
+}

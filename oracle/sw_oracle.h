@@ -81,6 +81,12 @@ int sw_oracle_align_split(const char *x, size_t m, const char *y, size_t n,
                           int npiece, float overlap_ratio, sw_oracle_result *out,
                           int *winning_piece);
 
+/* Memory-lean iterate + find_index_of_maximum: rolling column, no matrix.  Same first-maximum rule as
+ * sw_oracle_argmax_f32 / _u8 (column-major strict '>' for F32; smallest raw (rj, ri) key for U8SAT).
+ * For sizes where the full matrix does not fit (150 bp x 50 Mbp = 30 GB in float). */
+void sw_oracle_locate(const char *x, size_t m, const char *y, size_t n, const sw_oracle_scoring *sc,
+                      int semantics, float *mx, int64_t *ix, int64_t *iy);
+
 void sw_oracle_free_result(sw_oracle_result *r);
 
 /* Score-only rolling-column pass (no matrix): max cell value.  Used for the

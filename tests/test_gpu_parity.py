@@ -328,3 +328,28 @@ def test_float32_instance(ctx, oracle, pgs):
     exp = oracle.align(q, refb, 0, 20.0, -15.0, 8.0)
     assert exp["score"] > 32767
     _cmp(ctx.align(q, refb, 0, 20.0, -15.0, 8.0), exp, "f32 score > 2^15")
+
+
+def test_full_size_against_lean_oracle(ctx, oracle, pgs):
+    """Config 3 at FULL reference size against the oracle: 150 bp x 50 Mbp does not fit a matrix (30 GB), so the
+    oracle's rolling-column locate gives (score, argmax) for the whole reference, and the traceback is checked
+    against the oracle's full aligner on the 20 kbp of reference that end at the argmax (the walk reads nothing
+    to the right of it; SURVEY.md App. A.5 validates the window)."""
+    from concurrent.futures import ThreadPoolExecutor
+    ref = pgs.synth.dna(3, 50_000_000)
+    refb = ref.tobytes()
+    reads = [pgs.synth.read_from_ref(ref, 4 + 31 * k, 150, sub_rate=0.02, indel_rate=0.004)[0].tobytes() for k in range(3)]
+    reads.append(pgs.synth.dna(4242, 150).tobytes())                 # unrelated read: background maximum, ties likely
+    jobs = [(q, sem) for q in reads for sem in (0, 1)]
+    with ThreadPoolExecutor(8) as ex:                                  # ctypes releases the GIL
+        exp = list(ex.map(lambda js: oracle.locate(js[0], refb, js[1]), jobs))
+    ctx.set_reference(ref)
+    ctx.batch_upload(reads)
+    got = {0: ctx.batch_run(semantics=0), 1: ctx.batch_run(semantics=1)}
+    for (q, sem), (mx, ix, iy) in zip(jobs, exp):
+        r = got[sem][reads.index(q)]
+        assert (r["score"], r["end_x"], r["end_y"]) == (mx, ix, iy), (sem, reads.index(q))
+        lo = max(0, iy - 20_000)
+        w = oracle.align(q, refb[lo:iy], sem)
+        if (w["end_x"], w["end_y"]) == (ix, iy - lo):                  # same start cell => same walk
+            assert (r["cons_x"], r["cons_y"], r["pos"]) == (w["cons_x"], w["cons_y"], w["pos"] + lo)

@@ -129,3 +129,12 @@ def test_no_match_is_defined(oracle):
     # deliberate divergence from the reference's UB
     r = oracle.align("AAAA", "CCCCCC", oracle.F32)
     assert r["score"] == 0 and r["pos"] == 0 and r["cons_x"] == "" and r["cons_y"] == ""
+
+
+def test_lean_locate_equals_full_argmax(oracle, golden):
+    """sw_oracle_locate (no matrix) against the matrix-based argmax on every golden alignment case."""
+    for c in golden["align"][:200] + golden["kat"]:
+        if c["expect"]["score"] <= 0:
+            continue
+        got = oracle.locate(c["x"], c["y"], c["sem"], c["match"], c["mismatch"], c["gap"])
+        assert got == (c["expect"]["score"], c["expect"]["end_x"], c["expect"]["end_y"]), c
