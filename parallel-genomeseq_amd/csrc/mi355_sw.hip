@@ -423,9 +423,9 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   for (auto &r : ranges) maxlen = std::max(maxlen, r.hi - r.lo);
   const size_t npairs = b.sem == kSemF32 ? (size_t)b.count : ((size_t)b.count + 1) / 2;   // queries per workgroup: 1 or 2
   b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm);
-  // report maxima per 4096-column sub-chunk (>= query length, so that the uint8 storage order stays within
-  // two neighbouring sub-chunks); the strip-mined instance reports per tile
-  b.sub_len = 4096;
+  // report maxima per sub-chunk of >= 256 columns (>= query length, so that the uint8 storage order stays
+  // within two neighbouring sub-chunks): that is what locate re-runs; the strip-mined instance reports per tile
+  b.sub_len = 256;
   while (b.sub_len < b.maxlen) b.sub_len *= 2;
   if (b.strips || b.sub_len > b.chunk_len || b.chunk_len % b.sub_len != 0) b.sub_len = b.chunk_len;
   const int64_t cpr = (maxlen + b.chunk_len - 1) / b.chunk_len;

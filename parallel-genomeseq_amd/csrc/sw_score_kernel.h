@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   // per-sub-chunk maximum -> per-query key.  Lanes lag lane 0 by up to SL-1 columns, so up to SL-1 trailing
   // columns of a sub-chunk are reported with the next one; the host widens its search accordingly.
   const int64_t subs_per_tile = a.chunk_len / a.sub_len;
+  uint32_t best_a = 0, best_b = 0;                                 // this tile's best published value per query
   auto publish = [&](int64_t sub) {
     uint32_t m32 = C::bits(mx);
 #pragma unroll
@@ -242,14 +243,20 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
       const uint32_t o = (uint32_t)__shfl_xor((int)m32, off, SL);
       m32 = C::bits(C::vmax(C::from_bits(m32), C::from_bits(o)));
     }
-    if (ls == 0 && active && m32 != 0) {
+    // Only a sub-chunk that strictly beats the tile's earlier ones can become the query's (max, first
+    // sub-chunk) key, so all others skip the atomic (a tile publishes O(log) times, not once per sub-chunk).
+    if (ls == 0 && active) {
       const unsigned long long tag = 0xFFFFFFFFull - (unsigned long long)(chunk * subs_per_tile + sub);
       unsigned long long *k = a.keys + (size_t)range * a.nq;
       if (SEM == kSemF32) {
-        atomicMax(k + qA, ((unsigned long long)m32 << 32) | tag);   // non-negative floats order like their bits
+        if (m32 > best_a) {                                         // non-negative floats order like their bits
+          best_a = m32;
+          atomicMax(k + qA, ((unsigned long long)m32 << 32) | tag);
+        }
       } else {
-        if (m32 & 0xFFFFu) atomicMax(k + qA, ((unsigned long long)(m32 & 0xFFFFu) << 32) | tag);
-        if (hasB && (m32 >> 16)) atomicMax(k + qB, ((unsigned long long)(m32 >> 16) << 32) | tag);
+        const uint32_t va = m32 & 0xFFFFu, vb = m32 >> 16;
+        if (va > best_a) { best_a = va; atomicMax(k + qA, ((unsigned long long)va << 32) | tag); }
+        if (hasB && vb > best_b) { best_b = vb; atomicMax(k + qB, ((unsigned long long)vb << 32) | tag); }
       }
     }
     mx = C::from_bits(0u);
