@@ -353,3 +353,82 @@ def test_full_size_against_lean_oracle(ctx, oracle, pgs):
         w = oracle.align(q, refb[lo:iy], sem)
         if (w["end_x"], w["end_y"]) == (ix, iy - lo):                  # same start cell => same walk
             assert (r["cons_x"], r["cons_y"], r["pos"]) == (w["cons_x"], w["cons_y"], w["pos"] + lo)
+
+
+def test_fuzz_paths_vs_oracle(ctx, oracle, pgs):
+    """Seeded fuzz across the host's path selection: tile shapes (8/16 lanes, every R class edge), strip
+    threshold, short-reference threshold (1024), uint8 |y| <= |x|+1 rule, unusual scorings (large match, small
+    gap -> long warm-up, fractional -> float32 instance), repeats and low-complexity inputs."""
+    rng = np.random.default_rng(20261003)
+    lens = [1, 2, 15, 16, 17, 63, 64, 65, 100, 104, 105, 127, 128, 129, 150, 152, 153, 160, 200, 208, 209, 255, 256, 257,
+            300, 511, 512, 513, 600]
+    scorings = [(3.0, -3.0, 2.0)] * 4 + [(2.0, -1.0, 1.0), (5.0, -4.0, 3.0), (10.0, -2.0, 1.0), (1.0, -1.0, 4.0),
+                                         (3.5, -2.25, 1.5), (2.0, -7.0, 2.0), (100.0, -90.0, 60.0)]
+    nbad = 0
+    for t in range(220):
+        m = int(rng.choice(lens))
+        n = int(rng.choice([1, 7, 150, 151, 152, 600, 1023, 1024, 1025, 3000, 9000, 40000]))
+        kind = t % 5
+        if kind == 0:
+            unit = pgs.synth.dna(int(rng.integers(1, 1 << 30)), int(rng.integers(1, 9))).tobytes()
+            ref = (unit * (n // len(unit) + 1))[:n]
+        else:
+            ref = pgs.synth.dna(int(rng.integers(1, 1 << 30)), n).tobytes()
+        if kind in (1, 2) and n > m + 2:
+            o = int(rng.integers(0, n - m))
+            q = bytearray(ref[o:o + m])
+            for i in range(m):
+                if rng.random() < 0.04:
+                    q[i] = b"ACGT"[int(rng.integers(0, 4))]
+            q = bytes(q)
+        elif kind == 0:
+            q = (ref * 3)[:m] if len(ref) >= 1 else b"A" * m
+            q = (q * (m // max(1, len(q)) + 1))[:m]
+        else:
+            q = pgs.synth.dna(int(rng.integers(1, 1 << 30)), m).tobytes()
+        sem = int(rng.integers(0, 2))
+        ma, mi, g = scorings[int(rng.integers(0, len(scorings)))]
+        exp = oracle.align(q, ref, sem, ma, mi, g)
+        got = ctx.align(q, ref, sem, ma, mi, g)
+        for k in ("score", "pos", "end_x", "end_y", "cons_x", "cons_y"):
+            if got[k] != exp[k]:
+                nbad += 1
+                print("FUZZ MISMATCH t=%d m=%d n=%d sem=%d sc=%s key=%s got=%r exp=%r" % (t, m, n, sem, (ma, mi, g), k, got[k], exp[k]))
+                break
+    assert nbad == 0
+
+
+def test_fuzz_batches_and_splits(ctx, oracle, pgs):
+    """Seeded fuzz of ragged batches (several length classes in one call, odd counts, empty and unmatched
+    reads) and of the split aligner with all four engine combinations."""
+    rng = np.random.default_rng(77)
+    for t in range(6):
+        n = int(rng.choice([2000, 9000, 70000]))
+        ref = pgs.synth.dna(int(rng.integers(1, 1 << 30)), n).tobytes()
+        qs = []
+        for k in range(int(rng.integers(3, 40))):
+            m = int(rng.choice([0, 1, 30, 64, 100, 125, 150, 151, 250, 400, 520, 700]))
+            if m and rng.random() < 0.7 and n > m + 1:
+                o = int(rng.integers(0, n - m))
+                qs.append(ref[o:o + m])
+            else:
+                qs.append(pgs.synth.dna(int(rng.integers(1, 1 << 30)), m).tobytes() if m else b"")
+        for sem in (0, 1):
+            for q, got in zip(qs, ctx.align_batch(qs, ref, semantics=sem)):
+                _cmp(got, oracle.align(q, ref, sem), "fuzz batch t=%d sem=%d |q|=%d" % (t, sem, len(q)))
+    for t in range(24):
+        n = int(rng.choice([3000, 20000, 60000]))
+        m = int(rng.choice([20, 60, 150, 300]))
+        ref = pgs.synth.dna(int(rng.integers(1, 1 << 30)), n).tobytes()
+        o = int(rng.integers(0, n - m))
+        q = ref[o:o + m]
+        npiece = int(rng.choice([1, 2, 3, 5, 8, 17]))
+        ratio = float(rng.choice([2.0, 1.0, 1.5]))
+        sm, la = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        ma, mi, g = [(3.0, -3.0, 2.0), (2.0, -1.0, 1.0), (4.0, -6.0, 3.0)][t % 3]
+        if oracle.make_string_range(npiece, m, n, ratio) is None:
+            continue
+        exp = oracle.align_split(q, ref, npiece, ratio, sm, la, ma, mi, g)
+        got = ctx.align_split(q, ref, npiece, ratio, sm, la, ma, mi, g)
+        assert got["piece"] == exp["piece"]
+        _cmp(got, {k: exp[k] for k in ("score", "pos", "cons_x", "cons_y")}, "fuzz split t=%d" % t)
