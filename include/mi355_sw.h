@@ -75,7 +75,8 @@ typedef struct {
   int64_t end_x;        /* argmax row    (1-based index into x), 0 when score == 0 */
   int64_t end_y;        /* argmax column (1-based index into y), 0 when score == 0 */
   char *cons_x;         /* getConsensus_x(): reversed, '-' for gaps, NUL terminated */
-  char *cons_y;         /* getConsensus_y() */
+  char *cons_y;         /* getConsensus_y(); lives in the same allocation as cons_x: release both with
+                           mi355_sw_free_result, never with free() */
   size_t cons_len;
   float timings_us[2];  /* getTimings(): [0] DP-fill device time of the call that produced this
                            result (shared by all results of one batch), [1] sum over pieces */

@@ -31,6 +31,14 @@ class Result(C.Structure):
                 ("timings_us", C.c_float * 2)]
 
 
+_RESULT_DTYPE = np.dtype({"names": ["score", "pos", "end_x", "end_y", "cons_x", "cons_y", "cons_len", "t0", "t1"],
+                          "formats": ["<f4", "<u4", "<i8", "<i8", "<u8", "<u8", "<u8", "<f4", "<f4"],
+                          "offsets": [Result.score.offset, Result.pos.offset, Result.end_x.offset, Result.end_y.offset,
+                                      Result.cons_x.offset, Result.cons_y.offset, Result.cons_len.offset,
+                                      Result.timings_us.offset, Result.timings_us.offset + 4],
+                          "itemsize": C.sizeof(Result)})
+
+
 class MI355Error(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("mi355_sw error %d: %s" % (code, msg))
@@ -167,10 +175,9 @@ class Context:
         res = (Result * n)()
         self._chk(self._L.mi355_sw_batch_run(self._ctx, C.byref(p), C.c_int(flags), res))
         if raw:
-            out = dict(score=np.array([r.score for r in res], dtype=np.float32),
-                       pos=np.array([r.pos for r in res], dtype=np.int64),
-                       end_x=np.array([r.end_x for r in res], dtype=np.int64),
-                       end_y=np.array([r.end_y for r in res], dtype=np.int64))
+            v = np.frombuffer(res, dtype=_RESULT_DTYPE, count=n)       # no per-result Python objects
+            out = dict(score=v["score"].astype(np.float32), pos=v["pos"].astype(np.int64),
+                       end_x=v["end_x"].astype(np.int64), end_y=v["end_y"].astype(np.int64))
         else:
             out = [_take(r) for r in res]
         self._L.mi355_sw_free_results(res, C.c_size_t(n))

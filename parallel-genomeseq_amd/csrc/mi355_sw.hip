@@ -22,6 +22,7 @@
 
 #include "sw_exact_kernel.h"
 #include "sw_score_kernel.h"
+#include "sw_wave_kernel.h"
 
 using namespace mi355sw;
 
@@ -89,7 +90,7 @@ struct mi355_sw_ctx {
   bool adhoc_valid = false;
   QueryBatch one;                 // the single query of such a call
   // scratch
-  DevBuf keys, ranges, stab, ftab, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow;
+  DevBuf keys, ranges, stab, ftab, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs;
   double timings[6] = {0, 0, 0, 0, 0, 0};
 };
 
@@ -668,6 +669,209 @@ int run_walk(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const s
   return 0;
 }
 
+// ---- wavefront exact kernel (sw_wave_kernel.h): small problems, identity scoring ---------------
+constexpr int kWaveMaxLanesSide = 512;
+
+// Scoring the wave kernel evaluates: no table, and penalties that strictly lower a path (so that padding cells
+// can never reach the maximum).
+bool wave_scoring_ok(const mi355_sw_params &p) {
+  if (p.semantics == MI355_SW_U8SAT) { const U8Params u = u8_params(p); return u.M > 0; }
+  return p.lut == nullptr && p.match > 0 && p.mismatch < 0 && p.gap > 0 && std::isfinite(p.match) &&
+         std::isfinite(p.mismatch) && std::isfinite(p.gap);
+}
+
+// rows per lane of the wave kernel instance that covers `na` cells on the lane side, and its decision bytes
+int wave_R(int na) { return na <= 160 ? 10 : (na <= 320 ? 20 : 32); }
+size_t wave_dirs_bytes(int64_t nb, int R) { return (size_t)nb * 16 * (size_t)((R + 15) / 16) * 4 + 64; }
+
+struct WaveJob {
+  int q;                  // query index
+  int orient;             // 0: lanes = rows of x, stream = columns of y; 1: lanes = columns of y, stream = rows of x
+  int64_t s_lo;           // stream window start (0-based, range-relative), nb positions
+  int32_t nb;
+  bool track, dirs;
+  // results
+  float best = 0;
+  int64_t ci = 0, cj = 0;
+  size_t dirs_off = 0;
+};
+
+template <int R, int ORIENT, bool U8>
+void launch_wave_flags(bool track, bool dirs, unsigned blocks, hipStream_t st, const WaveProblem *pr, int n, const WaveScoring &sc) {
+  if (track && dirs) hipLaunchKernelGGL((sw_wave_kernel<R, ORIENT, U8, true, true>), dim3(blocks), dim3(256), 0, st, pr, n, sc);
+  else if (track) hipLaunchKernelGGL((sw_wave_kernel<R, ORIENT, U8, true, false>), dim3(blocks), dim3(256), 0, st, pr, n, sc);
+  else hipLaunchKernelGGL((sw_wave_kernel<R, ORIENT, U8, false, true>), dim3(blocks), dim3(256), 0, st, pr, n, sc);
+}
+
+template <int R>
+void launch_wave_R(int orient, bool u8, bool track, bool dirs, unsigned blocks, hipStream_t st, const WaveProblem *pr, int n, const WaveScoring &sc) {
+  if (orient == 0) { if (u8) launch_wave_flags<R, 0, true>(track, dirs, blocks, st, pr, n, sc); else launch_wave_flags<R, 0, false>(track, dirs, blocks, st, pr, n, sc); }
+  else { if (u8) launch_wave_flags<R, 1, true>(track, dirs, blocks, st, pr, n, sc); else launch_wave_flags<R, 1, false>(track, dirs, blocks, st, pr, n, sc); }
+}
+
+// One launch: all jobs share orientation and flags; lanes side <= 512.
+int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg, const mi355_sw_params &p,
+             std::vector<WaveJob> &jobs) {
+  const size_t n = jobs.size();
+  if (n == 0) return 0;
+  const int orient = jobs[0].orient;
+  const bool track = jobs[0].track, dirs = jobs[0].dirs;
+  const int64_t nref = rg.hi - rg.lo;
+  size_t dirs_total = 0;
+  int maxna = 0;
+  for (WaveJob &j : jobs) maxna = std::max(maxna, orient == 0 ? q.len[j.q] : (int)nref);
+  if (maxna > kWaveMaxLanesSide) return fail(ctx, MI355_SW_EINVAL, "internal: wave kernel side too long");
+  const int R = wave_R(maxna);
+  for (WaveJob &j : jobs)
+    if (dirs) { j.dirs_off = dirs_total; dirs_total += wave_dirs_bytes(j.nb, R); }
+  if (ctx->wprobs.ensure(n * sizeof(WaveProblem)) || ctx->outs_f.ensure(n * 4) || ctx->outs_i.ensure(n * 16) ||
+      (dirs_total && ctx->dirs.ensure(dirs_total)))
+    return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(wave scratch) failed");
+  std::vector<WaveProblem> pr(n);
+  for (size_t k = 0; k < n; ++k) {
+    const WaveJob &j = jobs[k];
+    WaveProblem &w = pr[k];
+    const uint8_t *xq = q.bytes.as<uint8_t>() + q.off[j.q];
+    const uint8_t *yr = ref.bytes.as<uint8_t>() + rg.lo;
+    if (orient == 0) { w.a = xq; w.na = q.len[j.q]; w.b = yr + j.s_lo; }
+    else { w.a = yr; w.na = (int32_t)nref; w.b = xq + j.s_lo; }
+    w.nb = j.nb;
+    w.b_offset = j.s_lo;
+    w.dirs = dirs ? reinterpret_cast<uint32_t *>(ctx->dirs.as<uint8_t>() + j.dirs_off) : nullptr;
+    w.best = ctx->outs_f.as<float>() + k;
+    w.cell = ctx->outs_i.as<int64_t>() + 2 * k;
+  }
+  HIPCHK(ctx, hipMemcpyAsync(ctx->wprobs.p, pr.data(), n * sizeof(WaveProblem), hipMemcpyHostToDevice, ctx->stream));
+  WaveScoring sc;
+  sc.match = p.match; sc.mismatch = p.mismatch; sc.gap = p.gap;
+  const U8Params u = u8_params(p);
+  sc.u8M = (float)u.M; sc.u8X = (float)u.X; sc.u8G = (float)u.G;
+  const bool u8 = p.semantics == MI355_SW_U8SAT;
+  const unsigned blocks = (unsigned)((n + 15) / 16);
+  const WaveProblem *dp = ctx->wprobs.as<WaveProblem>();
+  if (R == 10) launch_wave_R<10>(orient, u8, track, dirs, blocks, ctx->stream, dp, (int)n, sc);
+  else if (R == 20) launch_wave_R<20>(orient, u8, track, dirs, blocks, ctx->stream, dp, (int)n, sc);
+  else launch_wave_R<32>(orient, u8, track, dirs, blocks, ctx->stream, dp, (int)n, sc);
+  HIPCHK(ctx, hipGetLastError());
+  if (track) {
+    std::vector<float> bf(n);
+    std::vector<int64_t> ci(2 * n);
+    HIPCHK(ctx, hipMemcpyAsync(bf.data(), ctx->outs_f.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ci.data(), ctx->outs_i.p, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t k = 0; k < n; ++k) { jobs[k].best = bf[k]; jobs[k].ci = ci[2 * k]; jobs[k].cj = ci[2 * k + 1]; }
+  }
+  return 0;
+}
+
+// Traceback of located alignments with the wave kernel: decisions over a window that ends at the argmax along
+// the streamed side, grown on demand; then the greedy walk.  orient as WaveJob.
+int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg, const mi355_sw_params &p,
+               int orient, const std::vector<int> &qidx, const std::vector<Located> &loc, std::vector<TraceOut> &tout) {
+  const int64_t nref = rg.hi - rg.lo;
+  tout.assign(qidx.size(), TraceOut());
+  std::vector<size_t> todo;
+  for (size_t k = 0; k < qidx.size(); ++k) if (loc[k].score > 0) todo.push_back(k);
+  // exactness margin along the stream: a positive path ending at a stream index spans fewer than
+  // na + smax*na/g stream positions (DESIGN.md §3.3 with the roles of the two sequences as given)
+  double smax, g;
+  if (p.semantics == MI355_SW_U8SAT) { const U8Params u = u8_params(p); smax = u.M; g = u.G; }
+  else { smax = p.match; g = p.gap; }
+  std::vector<int64_t> budget(qidx.size()), warm(qidx.size());
+  for (size_t k : todo) {
+    const int64_t na = orient == 0 ? q.len[qidx[k]] : nref;
+    budget[k] = 2 * na + 64;
+    warm[k] = g > 0 ? na + (int64_t)std::ceil(smax * (double)na / g) : (int64_t)1 << 40;
+  }
+  while (!todo.empty()) {
+    std::vector<size_t> next;
+    size_t pos = 0;
+    while (pos < todo.size()) {
+      std::vector<WaveJob> jobs;
+      std::vector<size_t> owner;
+      size_t bytes = 0;
+      while (pos < todo.size() && jobs.size() < 262144) {
+        const size_t k = todo[pos];
+        const int qi = qidx[k];
+        const int64_t na = orient == 0 ? q.len[qi] : nref;
+        const int64_t s_end = orient == 0 ? loc[k].iy : loc[k].ix;   // 1-based stream index of the argmax
+        const int64_t wl = std::max<int64_t>(0, s_end - (budget[k] + warm[k]));
+        const int64_t nb = s_end - wl;
+        const size_t need = wave_dirs_bytes(nb, 32);               // upper bound whatever instance the group gets
+        (void)na;
+        if (need > kDirsBudget) return fail(ctx, MI355_SW_ENOTSUP, "traceback window exceeds the device scratch budget");
+        if (!jobs.empty() && bytes + need > kDirsBudget) break;
+        WaveJob j;
+        j.q = qi; j.orient = orient; j.s_lo = wl; j.nb = (int32_t)nb; j.track = false; j.dirs = true;
+        jobs.push_back(j); owner.push_back(k);
+        bytes += need;
+        ++pos;
+      }
+      int rc = run_wave(ctx, ref, q, rg, p, jobs);
+      if (rc) return rc;
+      int gmax = 0;
+      for (const WaveJob &j : jobs) gmax = std::max(gmax, orient == 0 ? q.len[j.q] : (int)nref);
+      const int groupR = wave_R(gmax);                              // the instance run_wave picked for this group
+      // walk: measure, lay out, write (only the bytes that exist are copied back)
+      const size_t n = jobs.size();
+      std::vector<WaveWalk> wp(n);
+      if (ctx->walkp.ensure(n * sizeof(WaveWalk) + n * 24 + n * 8 + 64))
+        return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(walk scratch) failed");
+      int64_t *wout = reinterpret_cast<int64_t *>(ctx->walkp.as<uint8_t>() + n * sizeof(WaveWalk));
+      int64_t *woffs = wout + 3 * n;
+      for (size_t t = 0; t < n; ++t) {
+        const WaveJob &j = jobs[t];
+        const size_t k = owner[t];
+        WaveWalk &w = wp[t];
+        const int na = orient == 0 ? q.len[j.q] : (int)nref;
+        w.x = q.bytes.as<uint8_t>() + q.off[j.q];
+        w.y = ref.bytes.as<uint8_t>() + rg.lo;
+        w.dirs = reinterpret_cast<const uint32_t *>(ctx->dirs.as<uint8_t>() + j.dirs_off);
+        w.na = na;
+        w.nb = j.nb;
+        w.orient = orient;
+        w.R = groupR;
+        w.b_offset = j.s_lo;
+        w.start_i = loc[k].ix; w.start_j = loc[k].iy;
+        w.exact_from = j.s_lo == 0 ? 0 : j.s_lo + warm[k];
+        w.cap = na + j.nb + 2;                                      // a walk inside the window emits <= na + nb pairs
+        w.out = wout + 3 * t;
+      }
+      HIPCHK(ctx, hipMemcpyAsync(ctx->walkp.p, wp.data(), n * sizeof(WaveWalk), hipMemcpyHostToDevice, ctx->stream));
+      const unsigned wblocks = (unsigned)((n + 63) / 64);
+      hipLaunchKernelGGL(sw_wave_walk_kernel<false>, dim3(wblocks), dim3(64), 0, ctx->stream, ctx->walkp.as<WaveWalk>(), (int)n,
+                         (char *)nullptr, (const int64_t *)nullptr);
+      HIPCHK(ctx, hipGetLastError());
+      std::vector<int64_t> wo(3 * n), offs(n);
+      HIPCHK(ctx, hipMemcpyAsync(wo.data(), wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      size_t ctot = 0;
+      for (size_t t = 0; t < n; ++t) { offs[t] = (int64_t)ctot; if (wo[3 * t + 2] == 0) ctot += 2 * (size_t)wo[3 * t]; }
+      if (ctx->cons.ensure(ctot + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(consensus) failed");
+      HIPCHK(ctx, hipMemcpyAsync(woffs, offs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(sw_wave_walk_kernel<true>, dim3(wblocks), dim3(64), 0, ctx->stream, ctx->walkp.as<WaveWalk>(), (int)n,
+                         ctx->cons.as<char>(), (const int64_t *)woffs);
+      HIPCHK(ctx, hipGetLastError());
+      std::vector<char> cons(ctot + 1);
+      if (ctot) HIPCHK(ctx, hipMemcpyAsync(cons.data(), ctx->cons.p, ctot, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      for (size_t t = 0; t < n; ++t) {
+        const size_t k = owner[t];
+        const int st = (int)wo[3 * t + 2];
+        if (st == 0) {
+          const size_t len = (size_t)wo[3 * t];
+          tout[k].cx.assign(cons.data() + offs[t], len);
+          tout[k].cy.assign(cons.data() + offs[t] + len, len);
+          tout[k].pos = (uint32_t)wo[3 * t + 1];
+        } else if (st == 1) { budget[k] *= 4; next.push_back(k); }
+        else return fail(ctx, MI355_SW_ENOTSUP, "consensus longer than |x| + |y|");
+      }
+    }
+    todo.swap(next);
+  }
+  return 0;
+}
+
 void set_result(mi355_sw_result &r, float score, int64_t ix, int64_t iy, const TraceOut *t) {
   r.score = score;
   r.end_x = score > 0 ? ix : 0;
@@ -676,8 +880,9 @@ void set_result(mi355_sw_result &r, float score, int64_t ix, int64_t iy, const T
   const std::string empty;
   const std::string &cx = t ? t->cx : empty, &cy = t ? t->cy : empty;
   r.cons_len = cx.size();
-  r.cons_x = (char *)malloc(cx.size() + 1);
-  r.cons_y = (char *)malloc(cy.size() + 1);
+  // both strings live in ONE allocation owned through cons_x (mi355_sw_free_result frees only that)
+  r.cons_x = (char *)malloc(cx.size() + cy.size() + 2);
+  r.cons_y = r.cons_x + cx.size() + 1;
   memcpy(r.cons_x, cx.data(), cx.size()); r.cons_x[cx.size()] = 0;
   memcpy(r.cons_y, cy.data(), cy.size()); r.cons_y[cy.size()] = 0;
 }
@@ -688,7 +893,23 @@ int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, co
                   const std::vector<int> &qidx, const std::vector<Located> &loc, std::vector<TraceOut> &tout) {
   tout.assign(qidx.size(), TraceOut());
   std::vector<size_t> todo;
-  for (size_t k = 0; k < qidx.size(); ++k) if (loc[k].score > 0) todo.push_back(k);
+  // short reads with identity scoring: decisions by the register-wavefront kernel (lanes = rows of x)
+  if (wave_scoring_ok(p) && std::getenv("MI355_SW_NO_WAVE") == nullptr) {
+    std::vector<int> sub;
+    std::vector<Located> sl;
+    std::vector<size_t> owner;
+    for (size_t k = 0; k < qidx.size(); ++k)
+      if (loc[k].score > 0 && q.len[qidx[k]] <= kWaveMaxLanesSide) { sub.push_back(qidx[k]); sl.push_back(loc[k]); owner.push_back(k); }
+    if (!sub.empty()) {
+      std::vector<TraceOut> t2;
+      int rc = wave_trace(ctx, ref, q, rg, p, 0, sub, sl, t2);
+      if (rc) return rc;
+      for (size_t t = 0; t < sub.size(); ++t) tout[owner[t]] = t2[t];
+    }
+    for (size_t k = 0; k < qidx.size(); ++k) if (loc[k].score > 0 && q.len[qidx[k]] > kWaveMaxLanesSide) todo.push_back(k);
+  } else {
+    for (size_t k = 0; k < qidx.size(); ++k) if (loc[k].score > 0) todo.push_back(k);
+  }
   std::vector<int64_t> budget(qidx.size());
   for (size_t k : todo) budget[k] = 2 * (int64_t)q.len[qidx[k]] + 64;
   while (!todo.empty()) {
@@ -741,10 +962,10 @@ int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, co
   return 0;
 }
 
-// Whole-matrix path (exact kernel only) for the listed queries over one range.
-int exact_full(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
-               const mi355_sw_params &p, const std::vector<int> &qidx, bool want_trace,
-               std::vector<Located> &loc, std::vector<TraceOut> &tout) {
+// Whole-matrix path on the LDS anti-diagonal kernel (sw_exact_kernel.h) for the listed queries over one range.
+int exact_full_lds(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
+                   const mi355_sw_params &p, const std::vector<int> &qidx, bool want_trace,
+                   std::vector<Located> &loc, std::vector<TraceOut> &tout) {
   const int64_t n = rg.hi - rg.lo;
   loc.assign(qidx.size(), Located());
   tout.assign(qidx.size(), TraceOut());
@@ -786,6 +1007,84 @@ int exact_full(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         if (st[t] != 0) return fail(ctx, MI355_SW_ENOTSUP, "traceback walk failed on a whole-matrix window");
         tout[owner[t]] = outs[t];
       }
+    }
+  }
+  return 0;
+}
+
+// Whole-matrix path for the listed queries over one range (problems the score kernel does not take).
+// Small problems with identity scoring run on the register-wavefront kernel (sw_wave_kernel.h): argmax tracking
+// for the float engine, traceback decisions for both engines; everything else on the LDS anti-diagonal kernel.
+int exact_full(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
+               const mi355_sw_params &p, const std::vector<int> &qidx, bool want_trace,
+               std::vector<Located> &loc, std::vector<TraceOut> &tout) {
+  const int64_t n = rg.hi - rg.lo;
+  loc.assign(qidx.size(), Located());
+  tout.assign(qidx.size(), TraceOut());
+  const bool wave_ok = wave_scoring_ok(p) && std::getenv("MI355_SW_NO_WAVE") == nullptr;
+  const bool u8 = p.semantics == MI355_SW_U8SAT;
+  // orientation per query: -1 = LDS kernel for everything
+  std::vector<int> orient(qidx.size(), -1);
+  for (size_t k = 0; k < qidx.size(); ++k) {
+    const int m = q.len[qidx[k]];
+    if (!wave_ok || m < 1 || n < 1) continue;
+    if (u8 && m == n) continue;                                   // |x| == |y| quirk lives in the LDS kernel
+    if (m <= kWaveMaxLanesSide && m <= n) orient[k] = 0;
+    else if (n <= kWaveMaxLanesSide) orient[k] = 1;
+  }
+  // 1. score + argmax
+  std::vector<int> lds_all, lds_score_only;                       // positions k
+  for (size_t k = 0; k < qidx.size(); ++k) {
+    if (orient[k] < 0) lds_all.push_back((int)k);
+    else if (u8) lds_score_only.push_back((int)k);                // uint8 storage order: LDS kernel's order_key
+  }
+  auto run_lds = [&](const std::vector<int> &ks, bool trace) -> int {
+    if (ks.empty()) return 0;
+    std::vector<int> sub(ks.size());
+    for (size_t t = 0; t < ks.size(); ++t) sub[t] = qidx[ks[t]];
+    std::vector<Located> l2;
+    std::vector<TraceOut> t2;
+    int rc = exact_full_lds(ctx, ref, q, rg, p, sub, trace, l2, t2);
+    if (rc) return rc;
+    for (size_t t = 0; t < ks.size(); ++t) { loc[ks[t]] = l2[t]; tout[ks[t]] = t2[t]; }
+    return 0;
+  };
+  int rc = run_lds(lds_all, want_trace);
+  if (rc) return rc;
+  rc = run_lds(lds_score_only, false);
+  if (rc) return rc;
+  if (!u8) {
+    for (int o = 0; o < 2; ++o) {
+      std::vector<WaveJob> jobs;
+      std::vector<size_t> owner;
+      for (size_t k = 0; k < qidx.size(); ++k) {
+        if (orient[k] != o) continue;
+        WaveJob j;
+        j.q = qidx[k]; j.orient = o; j.s_lo = 0; j.nb = o == 0 ? (int32_t)n : q.len[qidx[k]]; j.track = true; j.dirs = false;
+        jobs.push_back(j); owner.push_back(k);
+      }
+      rc = run_wave(ctx, ref, q, rg, p, jobs);
+      if (rc) return rc;
+      for (size_t t = 0; t < jobs.size(); ++t) {
+        Located &L = loc[owner[t]];
+        L.score = jobs[t].best > 0 ? jobs[t].best : 0;
+        L.ix = jobs[t].ci; L.iy = jobs[t].cj;
+      }
+    }
+  }
+  // 2. traceback of the wave-eligible ones
+  if (want_trace) {
+    for (int o = 0; o < 2; ++o) {
+      std::vector<int> sub;
+      std::vector<Located> sl;
+      std::vector<size_t> owner;
+      for (size_t k = 0; k < qidx.size(); ++k)
+        if (orient[k] == o) { sub.push_back(qidx[k]); sl.push_back(loc[k]); owner.push_back(k); }
+      if (sub.empty()) continue;
+      std::vector<TraceOut> t2;
+      rc = wave_trace(ctx, ref, q, rg, p, o, sub, sl, t2);
+      if (rc) return rc;
+      for (size_t t = 0; t < sub.size(); ++t) tout[owner[t]] = t2[t];
     }
   }
   return 0;
@@ -1032,7 +1331,7 @@ void mi355_sw_destroy(mi355_sw_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   DevBuf *bufs[] = {&c->ref.bytes, &c->ref.codes, &c->batch.bytes, &c->batch.lens, &c->keys, &c->ranges, &c->stab,
-                    &c->batch.offs, &c->batch.sel, &c->ftab, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow};
+                    &c->batch.offs, &c->batch.sel, &c->ftab, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow, &c->wprobs};
   for (DevBuf *b : bufs) b->release();
   c->adhoc.release(); c->one.release();
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -1249,7 +1548,7 @@ int mi355_sw_last_timings(const mi355_sw_ctx *ctx, double out[6]) {
 
 void mi355_sw_free_result(mi355_sw_result *r) {
   if (!r) return;
-  free(r->cons_x); free(r->cons_y);
+  free(r->cons_x);                    // cons_y points into the same allocation
   r->cons_x = r->cons_y = nullptr; r->cons_len = 0;
 }
 

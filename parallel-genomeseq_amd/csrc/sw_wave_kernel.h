@@ -1,0 +1,255 @@
+// sw_wave_kernel.h — wavefront-in-registers exact kernel for SMALL problems (one side <= 16*R <= 512).
+//
+// Same register wavefront as sw_score_kernel.h (16 lanes = one problem, lane l owns R consecutive cells of the
+// short side, one DPP row_shr:1 per step), but in float32 cells, one problem per slot, identity scoring, and with
+// the two things the score kernel leaves to sw_exact_kernel.h:
+//   TRACK  the first maximum in the float engine's storage order (similaritymatrix.cpp:21-28: columns outer,
+//          rows inner, strict '>') -> (score, row, column);
+//   DIRS   one greedy traceback decision per cell (smithwaterman.cpp:51-72), 2 bits, laid out
+//          dirs[stream step][lane][W] dwords (W = 1 for R <= 16, else 2): every lane stores its R decisions of a
+//          step as one or two dwords, a slot stores 64*W contiguous bytes per step.
+// It serves (a) the many-small-alignments batch (src/mpi_sw_solve_uniprot.cpp:95-138 shape: each database
+// sequence x against one short query y) and (b) the traceback windows of the score-kernel path.
+//
+// ORIENT = 0: lanes hold rows of x (i), the stream runs over columns of y (j)   [short read, long window]
+// ORIENT = 1: lanes hold columns of y (j), the stream runs over rows of x (i)   [long sequence, short query]
+// U8 = true evaluates the uint8 engine's cell rule (similaritymatrix.cpp:75-81) on integer-valued floats.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sw_exact_kernel.h"   // kDir*
+
+namespace mi355sw {
+
+struct WaveProblem {
+  const uint8_t *a;      // sequence held on lanes: x (ORIENT 0) or y (ORIENT 1); na <= 16*R
+  const uint8_t *b;      // streamed sequence: window of y (ORIENT 0) or window of x (ORIENT 1)
+  int32_t na, nb;
+  int64_t b_offset;      // true (1-based) stream index = b_offset + t + 1 for stream position t
+  uint32_t *dirs;        // DIRS: [nb][16][W] packed decisions (2 bits per cell, cell r of a lane at bit 2*(r%16)), or null
+  float *best;           // TRACK: maximum (0 when no positive cell)
+  int64_t *cell;         // TRACK: [2] = row (into x), column (into y), 1-based, of the first maximum
+};
+
+struct WaveScoring {
+  float match, mismatch, gap;
+  float u8M, u8X, u8G;   // uint8 engine parameters as floats
+};
+
+constexpr int kWaveSeg = 64;
+constexpr int kWaveBuf = 16 + kWaveSeg;
+
+template <int R, int ORIENT, bool U8, bool TRACK, bool DIRS>
+__global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, int nprob, const WaveScoring sc) {
+  __shared__ __attribute__((aligned(16))) uint8_t win[16 * kWaveBuf];
+  const int tid = threadIdx.x;
+  const int l = tid & 15;
+  const int slot = tid >> 4;
+  const int pid = blockIdx.x * 16 + slot;
+  const bool active = pid < nprob;
+  WaveProblem P;
+  if (active) P = probs[pid];
+  else { P.a = nullptr; P.b = nullptr; P.na = 0; P.nb = 0; P.b_offset = 0; P.dirs = nullptr; P.best = nullptr; P.cell = nullptr; }
+  const int na = P.na, nb = P.nb;
+
+  // this lane's R characters of the short side (0xFFFF = padding, never equal to a byte)
+  uint32_t ca[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int ai = l * R + r;
+    ca[r] = (ai < na) ? (uint32_t)P.a[ai] : 0xFFFFu;
+  }
+
+  // stream window: 16 B history + 64 B segment per slot, refilled every 64 steps (as sw_score_kernel.h)
+  uint8_t *buf = win + slot * kWaveBuf;
+  uint32_t *buf32 = reinterpret_cast<uint32_t *>(buf);
+  const uint8_t *buf_lane = buf + 16 - l;
+  auto stage_load = [&](int seg) -> uint32_t {
+    const int c0 = seg * kWaveSeg + 4 * l;
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = c0 + k;
+      const uint32_t ch = (t < nb) ? (uint32_t)P.b[t] : 0u;
+      w |= ch << (8 * k);
+    }
+    return w;
+  };
+  // steps this wavefront needs: the longest of its four slots (+15 skew); wave-uniform
+  int steps = nb + 16;
+  steps = max(steps, __shfl_xor(steps, 16));
+  steps = max(steps, __shfl_xor(steps, 32));
+  const int nseg = (steps + kWaveSeg - 1) / kWaveSeg;
+
+  uint32_t nextc = stage_load(0);
+  if (l < 4) buf32[l] = 0u;
+  buf32[4 + l] = nextc;
+  nextc = stage_load(1);
+
+  float H[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) H[r] = 0.0f;
+  uint32_t up_prev = 0;
+  // TRACK state: ORIENT 0 -> one (best, step, row) per lane; ORIENT 1 -> one (best, step) per lane row
+  float tb0 = 0.0f;
+  int tt0 = 0, tr0 = 0;
+  float tbr[ORIENT == 1 && TRACK ? R : 1];
+  int ttr[ORIENT == 1 && TRACK ? R : 1];
+  if (ORIENT == 1 && TRACK) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) { tbr[r] = 0.0f; ttr[r] = 0; }
+  }
+  const float gpen = U8 ? sc.u8G : sc.gap;
+
+  for (int seg = 0; seg < nseg; ++seg) {
+#pragma unroll 4
+    for (int k = 0; k < kWaveSeg; ++k) {
+      const int t = seg * kWaveSeg + k - l;                        // this lane's stream position
+      // positions outside the stream compare unequal to every byte (bit 8 set)
+      const uint32_t cb = (uint32_t)buf_lane[k] | ((uint32_t)t >= (uint32_t)nb ? 0x100u : 0u);
+      const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(H[R - 1]), 0x111, 0xf, 0xf, true);
+      float diag = __uint_as_float(up_prev);
+      float north = __uint_as_float(up);                           // previous lane row, same step
+      up_prev = up;
+      constexpr int W = (R + 15) / 16;
+      uint32_t dpack[W];
+      if (DIRS) {
+#pragma unroll
+        for (int d = 0; d < W; ++d) dpack[d] = 0;
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float w = H[r];                                      // same lane row, previous step
+        const bool eq = ca[r] == cb;
+        float x;
+        if (U8) x = eq ? fminf(diag + sc.u8M, 255.0f) : fmaxf(diag - sc.u8X, 0.0f);
+        else x = diag + (eq ? sc.match : sc.mismatch);
+        const float tmx = fmaxf(w, north);
+        const float y = tmx - gpen;
+        const float h = fmaxf(fmaxf(x, y), 0.0f);
+        if (DIRS) {
+          // neighbours in the reference's terms: n1 = NW, n2 = W (same row of x, previous column of y), n3 = N
+          const float n1 = diag;
+          const float n2 = ORIENT == 0 ? w : north;
+          const float n3 = ORIENT == 0 ? north : w;
+          int dir;
+          if (n1 == 0.0f || n2 == 0.0f || n3 == 0.0f) dir = kDirStop;
+          else if (n1 >= n2 && n1 >= n3) dir = kDirNW;
+          else if (n2 >= n1 && n2 >= n3) dir = kDirW;
+          else dir = kDirN;
+          dpack[r >> 4] |= (uint32_t)dir << (2 * (r & 15));
+        }
+        if (TRACK) {
+          if (ORIENT == 0) { if (h > tb0) { tb0 = h; tt0 = t; tr0 = r; } }
+          else { if (h > tbr[r]) { tbr[r] = h; ttr[r] = t; } }
+        }
+        diag = w;
+        H[r] = h;
+        north = h;
+      }
+      if (DIRS) {
+        if (P.dirs != nullptr && t >= 0 && t < nb) {
+          uint32_t *dst = P.dirs + ((size_t)t * 16 + (size_t)l) * W;
+#pragma unroll
+          for (int d = 0; d < W; ++d) dst[d] = dpack[d];
+        }
+      }
+    }
+    const uint32_t hist = buf32[kWaveSeg / 4 + (l & 3)];
+    if (l < 4) buf32[l] = hist;
+    buf32[4 + l] = nextc;
+    nextc = stage_load(seg + 2);
+  }
+
+  if (TRACK) {
+    // per-lane winner in storage order (column of y first, then row of x), then across the 16 lanes
+    float bv;
+    long long bi, bj;
+    if (ORIENT == 0) {
+      bv = tb0; bi = (long long)l * R + tr0 + 1; bj = P.b_offset + tt0 + 1;
+    } else {
+      bv = 0.0f; bi = 0; bj = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r)                                  // ascending column: strict '>' keeps the first
+        if (tbr[r] > bv) { bv = tbr[r]; bj = (long long)l * R + r + 1; bi = P.b_offset + ttr[r] + 1; }
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+      const float ov = __shfl_xor(bv, off, 16);
+      const long long oi = __shfl_xor(bi, off, 16);
+      const long long oj = __shfl_xor(bj, off, 16);
+      if (ov > bv || (ov == bv && ov > 0.0f && (oj < bj || (oj == bj && oi < bi)))) { bv = ov; bi = oi; bj = oj; }
+    }
+    if (l == 0 && active) {
+      *P.best = bv;
+      P.cell[0] = bv > 0.0f ? bi : 0;
+      P.cell[1] = bv > 0.0f ? bj : 0;
+    }
+  }
+}
+
+// Greedy walk over sw_wave_kernel's decisions (smithwaterman.cpp:40-78).
+struct WaveWalk {
+  const uint8_t *x;        // full x
+  const uint8_t *y;        // full y (of the range)
+  const uint32_t *dirs;    // [nb][16][W] as WaveProblem::dirs
+  int32_t na, nb, orient;
+  int32_t R;               // rows per lane of the instance that wrote dirs
+  int64_t b_offset;        // as WaveProblem
+  int64_t start_i, start_j;  // true 1-based start cell (row of x, column of y)
+  int64_t exact_from;      // stream index (true, 1-based) from which cells are exact; 0 = all
+  int32_t cap;             // longest consensus the caller accepts
+  int64_t *out;            // [0] length, [1] pos, [2] status (0 ok, 1 window too small, 2 capacity)
+};
+
+// Two passes over the same decisions: WRITE = false measures (length, pos, status); the host then lays the
+// strings out back to back and WRITE = true emits them at cons + offs[p] (x) and cons + offs[p] + length (y),
+// so that only the bytes that exist cross PCIe.
+template <bool WRITE>
+__global__ void sw_wave_walk_kernel(const WaveWalk *probs, int n, char *cons, const int64_t *offs) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const WaveWalk W = probs[p];
+  char *cons_x = nullptr, *cons_y = nullptr;
+  if (WRITE) {
+    if (W.out[2] != 0) return;
+    cons_x = cons + offs[p];
+    cons_y = cons_x + W.out[0];
+  }
+  long long ix = W.start_i, iy = W.start_j;
+  int len = 0;
+  long long status = 0, pos = 0;
+  if (ix <= 0 || iy <= 0) { W.out[0] = 0; W.out[1] = 0; W.out[2] = 0; return; }
+  for (;;) {
+    const long long sidx = W.orient == 0 ? iy : ix;               // stream-side true index of this cell
+    const long long aidx = W.orient == 0 ? ix : iy;               // lane-side true index (1-based)
+    const long long t = sidx - W.b_offset - 1;
+    // the decision at (ix, iy) reads cells one step back along the stream: they must be exact and inside the window
+    if (t < 0 || t >= W.nb || aidx > W.na) { status = 1; break; }
+    if (W.exact_from > 0 && sidx - 1 < W.exact_from) { status = 1; break; }
+    if (len >= W.cap) { status = 2; break; }
+    const int lane = (int)((aidx - 1) / W.R), r = (int)((aidx - 1) % W.R);
+    const int wd = (W.R + 15) / 16;
+    const int dir = (int)((W.dirs[((size_t)t * 16 + (size_t)lane) * wd + (r >> 4)] >> (2 * (r & 15))) & 3u);
+    if (dir == kDirStop) {
+      if (WRITE) { cons_x[len] = (char)W.x[ix - 1]; cons_y[len] = (char)W.y[iy - 1]; }
+      ++len;
+      pos = iy;
+      break;
+    } else if (dir == kDirNW) {
+      if (WRITE) { cons_x[len] = (char)W.x[ix - 1]; cons_y[len] = (char)W.y[iy - 1]; }
+      ++len; --ix; --iy;
+    } else if (dir == kDirW) {
+      if (WRITE) { cons_x[len] = '-'; cons_y[len] = (char)W.y[iy - 1]; }
+      ++len; --iy;
+    } else {
+      if (WRITE) { cons_x[len] = (char)W.x[ix - 1]; cons_y[len] = '-'; }
+      ++len; --ix;
+    }
+  }
+  if (WRITE) return;
+  W.out[0] = len; W.out[1] = pos; W.out[2] = status;
+}
+
+}  // namespace mi355sw
