@@ -270,9 +270,15 @@ ScoreTable plan_table(const RefData &ref, const mi355_sw_params &p) {
   if (p.semantics == MI355_SW_U8SAT) {
     const U8Params u = u8_params(p);
     if (u.G < 1) { f.why = "gap penalty saturates to 0: no finite warm-up margin"; return f; }
+    f.ftab.assign((size_t)256 * nc, kPadScoreF);
     for (int a = 0; a < 256; ++a)
-      for (int c = 0; c < nc - 1; ++c) f.stab[(size_t)a * nc + c] = (int16_t)((uint8_t)a == ref.byte_of[c] ? u.M : -u.X);
+      for (int c = 0; c < nc - 1; ++c) {
+        const int v = (uint8_t)a == ref.byte_of[c] ? u.M : -u.X;
+        f.stab[(size_t)a * nc + c] = (int16_t)v;
+        f.ftab[(size_t)a * nc + c] = (float)v;
+      }
     f.gap = u.G; f.smax = u.M;
+    f.gapf = (float)u.G; f.smaxf = (float)u.M;
     f.integral = true;
   } else {
     const float g = p.gap;
@@ -316,7 +322,7 @@ std::vector<Bucket> make_buckets(const QueryBatch &q, const ScoreTable &t, const
     out.back().maxlen = std::max(out.back().maxlen, len);
   }
   for (Bucket &b : out) {
-    if (p.semantics == MI355_SW_U8SAT) b.sem = kSemU8;
+    if (p.semantics == MI355_SW_U8SAT) b.sem = b.count == 1 ? kSemF32U8 : kSemU8;   // lone query: one per register
     else {
       // packed 16-bit cells when scores are small integers and the score bound fits; float32 cells otherwise
       const bool fits = t.integral && (int64_t)t.smax * std::min<int64_t>(b.maxlen, std::max<int64_t>(n, 1)) + t.smax <= 32000;
@@ -325,8 +331,8 @@ std::vector<Bucket> make_buckets(const QueryBatch &q, const ScoreTable &t, const
       // (one query per slot, exact for integer scores below 2^24) sweeps it ~1.5x faster
       if (b.count == 1 && b.sem == kSemI16 && (double)t.smax * b.maxlen < 1.6e7) b.sem = kSemF32;
     }
-    const double smax = b.sem == kSemF32 ? (double)t.smaxf : (double)t.smax;
-    const double gap = b.sem == kSemF32 ? (double)t.gapf : (double)t.gap;
+    const double smax = sem_is_float(b.sem) ? (double)t.smaxf : (double)t.smax;
+    const double gap = sem_is_float(b.sem) ? (double)t.gapf : (double)t.gap;
     if (smax <= 0 || gap <= 0) b.warm = 0;
     else b.warm = (int64_t)b.maxlen + (int64_t)std::ceil(smax * b.maxlen / gap);
     b.warm = (b.warm + 63) / 64 * 64;
@@ -422,7 +428,7 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   const size_t nr = ranges.size();
   int64_t maxlen = 0;
   for (auto &r : ranges) maxlen = std::max(maxlen, r.hi - r.lo);
-  const size_t npairs = b.sem == kSemF32 ? (size_t)b.count : ((size_t)b.count + 1) / 2;   // queries per workgroup: 1 or 2
+  const size_t npairs = sem_is_float(b.sem) ? (size_t)b.count : ((size_t)b.count + 1) / 2;   // queries per workgroup: 1 or 2
   b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm);
   // report maxima per sub-chunk of >= 256 columns (>= query length, so that the uint8 storage order stays
   // within two neighbouring sub-chunks): that is what locate re-runs; the strip-mined instance reports per tile
@@ -450,15 +456,15 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   a.qfirst = b.first;
   a.qcount = b.count;
   a.nq = (int)q.nq;
-  a.stab = b.sem == kSemF32 ? ctx->ftab.p : ctx->stab.p;
+  a.stab = sem_is_float(b.sem) ? ctx->ftab.p : ctx->stab.p;
   a.ncodes = ref.ncodes;
-  if (b.sem == kSemF32) memcpy(&a.gap2, &t.gapf, 4);
+  if (sem_is_float(b.sem)) memcpy(&a.gap2, &t.gapf, 4);
   else a.gap2 = (uint32_t)t.gap * 0x00010001u;
   a.clamp2 = 255u * 0x00010001u;
   a.keys = ctx->keys.as<unsigned long long>();
 
   const int LS = lane_stride(b.R);
-  const int nqw = b.sem == kSemF32 ? 1 : 2;                         // queries per workgroup
+  const int nqw = sem_is_float(b.sem) ? 1 : 2;                      // queries per workgroup
   // keep single launches to a few seconds: split the bucket's pairs over several launches
   double range_cols = 0;
   for (auto &r : ranges) range_cols += (double)(r.hi - r.lo);
@@ -485,6 +491,7 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   int rc = b.sem == kSemU8 ? launch_score_R<kSemU8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
+           : b.sem == kSemF32U8 ? launch_score_R<kSemF32U8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
            : b.sem == kSemF32 ? launch_score_R<kSemF32>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
                               : launch_score_R<kSemI16>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a);
   if (rc) return fail(ctx, MI355_SW_ENOTSUP, "no score kernel instance for this R");
@@ -1185,7 +1192,7 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
         if (rc) return rc;
         for (int k = 0; k < b.count; ++k) {
           const int id = q.order[b.first + k];
-          qfast[id] = 1; qchunk[id] = b.sub_len; qwarm[id] = b.warm; qfloat[id] = b.sem == kSemF32;
+          qfast[id] = 1; qchunk[id] = b.sub_len; qwarm[id] = b.warm; qfloat[id] = sem_is_float(b.sem);
         }
       }
       std::vector<unsigned long long> keys;
@@ -1261,7 +1268,7 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
       if (!b.fast) continue;
       rc = score_launch(ctx, ref, q, sub, p, table, b);
       if (rc) return rc;
-      for (int k = 0; k < b.count; ++k) { qfast[q.order[b.first + k]] = 1; qfloat[q.order[b.first + k]] = b.sem == kSemF32; }
+      for (int k = 0; k < b.count; ++k) { qfast[q.order[b.first + k]] = 1; qfloat[q.order[b.first + k]] = sem_is_float(b.sem); }
     }
     std::vector<unsigned long long> keys;
     rc = score_fetch(ctx, nq * sub.size(), keys);

@@ -39,7 +39,10 @@ constexpr int kSemI16 = 0;             // Similarity_Matrix semantics on integer
 constexpr int kSemU8 = 1;              // Similarity_Matrix_Skewed semantics (saturate at 255), two queries per register
 constexpr int kSemF32 = 2;             // Similarity_Matrix semantics in float32 cells (any table, any positive gap),
                                        // one query per register: the general instance behind the packed ones
+constexpr int kSemF32U8 = 3;           // Similarity_Matrix_Skewed cell rule on integer-valued float32 cells, one query per
+                                       // register: a lone uint8-engine query (the packed instance would carry it twice)
 constexpr float kPadScoreF = -1.0e30f;
+__host__ __device__ constexpr bool sem_is_float(int sem) { return sem == kSemF32 || sem == kSemF32U8; }
 
 // LDS stride (dwords) between the profile rows of two adjacent lanes: a multiple of 4 (b128
 // alignment) that is ≡ 4 (mod 8), so that the sixteen 16-byte windows of a ds_read_b128 lane
@@ -98,17 +101,19 @@ template <int SEM> struct Cell {
   }
   static __device__ __forceinline__ T cell(T x, T y) { return __builtin_elementwise_max(x, y); }
 };
-template <> struct Cell<kSemF32> {
+template <int SEM> struct CellF {
   typedef float T;
   static constexpr int kQueries = 1;
   static __device__ __forceinline__ T from_bits(uint32_t v) { return __uint_as_float(v); }
   static __device__ __forceinline__ uint32_t bits(T v) { return __float_as_uint(v); }
-  static __device__ __forceinline__ T add(T d, T sc, uint32_t) { return d + sc; }
+  static __device__ __forceinline__ T add(T d, T sc, uint32_t) { return SEM == kSemF32U8 ? fminf(d + sc, 255.0f) : d + sc; }
   static __device__ __forceinline__ T vmax(T a, T b) { return fmaxf(a, b); }
   // max(w - g, n - g) == max(w, n) - g exactly (rounding is monotone): similaritymatrix.cpp:49-54
   static __device__ __forceinline__ T sub_gap(T t, uint32_t gap2) { return t - __uint_as_float(gap2); }
   static __device__ __forceinline__ T cell(T x, T y) { return fmaxf(fmaxf(x, y), 0.0f); }
 };
+template <> struct Cell<kSemF32> : CellF<kSemF32> {};
+template <> struct Cell<kSemF32U8> : CellF<kSemF32U8> {};
 
 // value of the lane above inside the 16-lane DPP row, 0 for the first lane (row H(0,.) = 0)
 __device__ __forceinline__ uint32_t row_shr1(uint32_t v) {
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
       const int ll = rem / R, r = rem - ll * R;
       const int i = row0 + (ll & (SL - 1)) * R + r;
       uint32_t e32;
-      if (SEM == kSemF32) {
+      if (sem_is_float(SEM)) {
         const float *ft = static_cast<const float *>(a.stab);
         e32 = __float_as_uint((i < mA) ? ft[(int)xA[i] * a.ncodes + c] : kPadScoreF);
       } else {
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
     if (ls == 0 && active) {
       const unsigned long long tag = 0xFFFFFFFFull - (unsigned long long)(chunk * subs_per_tile + sub);
       unsigned long long *k = a.keys + (size_t)range * a.nq;
-      if (SEM == kSemF32) {
+      if (sem_is_float(SEM)) {
         if (m32 > best_a) {                                         // non-negative floats order like their bits
           best_a = m32;
           atomicMax(k + qA, ((unsigned long long)m32 << 32) | tag);
