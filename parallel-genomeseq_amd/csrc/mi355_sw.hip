@@ -303,16 +303,21 @@ ScoreTable plan_table(const RefData &ref, const mi355_sw_params &p) {
   return f;
 }
 
-size_t profile_lds_bytes(int ncodes, int R) { return (size_t)ncodes * kSlotLanes * lane_stride(R) * 4; }
+size_t profile_lds_bytes(int ncodes, int R, int SL = 16) { return (size_t)ncodes * (size_t)std::max(16, SL) * lane_stride(R) * 4; }
 
 // Length classes of the batch: one bucket per kernel instance (R), plus one strip-mined bucket.
-std::vector<Bucket> make_buckets(const QueryBatch &q, const ScoreTable &t, const mi355_sw_params &p, int64_t n) {
+std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const ScoreTable &t, const mi355_sw_params &p, int64_t n) {
   std::vector<Bucket> out;
+  // queries beyond 512 rows: whole-wavefront tiles (64 lanes x R rows: one strip up to 2048 rows, 2048-row
+  // strips beyond) when the 64-position profile fits LDS, else 16-lane tiles in 512-row strips
+  const bool wide_ok = profile_lds_bytes(ref.ncodes, 32, 64) <= kProfileLdsMax && std::getenv("MI355_SW_NO_WIDE") == nullptr;
   for (size_t pos = 0; pos < q.nq; ++pos) {
     const int len = q.len[q.order[pos]];
-    const bool strips = len > kMaxRowsFast;
+    bool strips = false;
     int SL = 16, R = 32;
-    if (!strips) pick_shape(len, SL, R);
+    if (len <= kMaxRowsFast) pick_shape(len, SL, R);
+    else if (wide_ok) { SL = 64; R = len <= 1024 ? 16 : 32; strips = len > 2048; }
+    else strips = true;
     if (out.empty() || out.back().R != R || out.back().SL != SL || out.back().strips != strips) {
       Bucket b;
       b.first = (int)pos; b.R = R; b.SL = SL; b.strips = strips;
@@ -343,7 +348,7 @@ std::vector<Bucket> make_buckets(const QueryBatch &q, const ScoreTable &t, const
 // May this bucket's queries be swept by the score kernel over a reference range of n columns?
 bool bucket_fast_ok(const RefData &ref, const ScoreTable &t, const Bucket &b, int64_t n, const mi355_sw_params &p) {
   if (!t.ok || n < 1 || b.maxlen < 1) return false;
-  if (profile_lds_bytes(ref.ncodes, b.R) > kProfileLdsMax) return false;       // alphabet too large for this R
+  if (profile_lds_bytes(ref.ncodes, b.R, b.SL) > kProfileLdsMax) return false;  // alphabet too large for this shape
   // the uint8 engine's storage order is only bounded to a few tiles when the reference is the longer side;
   // shorter references take the whole-matrix path (which also holds the |x| == |y| quirk)
   if (p.semantics == MI355_SW_U8SAT && n <= (int64_t)b.maxlen + 1) return false;
@@ -370,8 +375,16 @@ void launch_score(K kernel, dim3 grid, size_t shmem, hipStream_t st, const Score
 template <int SEM>
 int launch_score_R(int R, int SL, bool strips, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
   if (strips) {
-    if (R != 32 || SL != 16) return -1;
-    launch_score(sw_score_kernel<32, SEM, true>, grid, shmem, st, a);
+    if (R != 32) return -1;
+    if (SL == 64) launch_score(sw_score_kernel<32, SEM, true, 64>, grid, shmem, st, a);
+    else if (SL == 16) launch_score(sw_score_kernel<32, SEM, true, 16>, grid, shmem, st, a);
+    else return -1;
+    return 0;
+  }
+  if (SL == 64) {
+    if (R == 16) launch_score(sw_score_kernel<16, SEM, false, 64>, grid, shmem, st, a);
+    else if (R == 32) launch_score(sw_score_kernel<32, SEM, false, 64>, grid, shmem, st, a);
+    else return -1;
     return 0;
   }
   if (SL == 8) {
@@ -390,7 +403,7 @@ int launch_score_R(int R, int SL, bool strips, dim3 grid, size_t shmem, hipStrea
   return -1;
 }
 
-int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm) {
+int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int SL = 16) {
   int64_t cl = 65536;
   while (cl < 8 * warm) cl *= 2;                 // long queries: keep the warm-up redundancy bounded
   // fill the chip: 256 CUs x 32 waves x 4 slots; shrink tiles while they stay >> warm-up
@@ -398,8 +411,9 @@ int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm) {
          (double)npairs * (double)((max_range_len + cl - 1) / cl) < 65536.0) cl /= 2;
   // few tiles (one long query): filling the SIMDs beats the warm-up redundancy down to cl == warm
   // (measured, 10 kbp x 250 Mbp: 1.17 s at 131 k columns, 0.58 s at 32 k; profiles/r01_config5*.log)
+  const double few = SL == 64 ? 1536.0 : 8192.0;                   // a 64-lane tile is a wavefront of its own
   while (cl / 2 >= std::max<int64_t>(warm, 2048) &&
-         (double)npairs * (double)((max_range_len + cl - 1) / cl) < 8192.0) cl /= 2;
+         (double)npairs * (double)((max_range_len + cl - 1) / cl) < few) cl /= 2;
   if (const char *e = std::getenv("MI355_SW_CHUNK")) { const long v = std::atol(e); if (v >= 256) cl = v / 64 * 64; }   // tuning aid
   return cl;
 }
@@ -429,12 +443,13 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   int64_t maxlen = 0;
   for (auto &r : ranges) maxlen = std::max(maxlen, r.hi - r.lo);
   const size_t npairs = sem_is_float(b.sem) ? (size_t)b.count : ((size_t)b.count + 1) / 2;   // queries per workgroup: 1 or 2
-  b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm);
+  b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm, b.SL);
   // report maxima per sub-chunk of >= 256 columns (>= query length, so that the uint8 storage order stays
   // within two neighbouring sub-chunks): that is what locate re-runs; the strip-mined instance reports per tile
   b.sub_len = 256;
   while (b.sub_len < b.maxlen) b.sub_len *= 2;
-  if (b.strips || b.sub_len > b.chunk_len || b.chunk_len % b.sub_len != 0) b.sub_len = b.chunk_len;
+  if (b.strips) while (b.chunk_len / b.sub_len > 64) b.sub_len *= 2;      // the strip-mined instances keep <= 64 sub-chunk maxima in LDS
+  if (b.sub_len > b.chunk_len || b.chunk_len % b.sub_len != 0) b.sub_len = b.chunk_len;
   const int64_t cpr = (maxlen + b.chunk_len - 1) / b.chunk_len;
   const int nslot = 256 / b.SL;                                     // tiles per workgroup
   const int64_t cgroups = (cpr + nslot - 1) / nslot;
@@ -463,7 +478,6 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   a.clamp2 = 255u * 0x00010001u;
   a.keys = ctx->keys.as<unsigned long long>();
 
-  const int LS = lane_stride(b.R);
   const int nqw = sem_is_float(b.sem) ? 1 : 2;                      // queries per workgroup
   // keep single launches to a few seconds: split the bucket's pairs over several launches
   double range_cols = 0;
@@ -474,20 +488,20 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   const size_t pn = std::min(pairs_per_launch, npairs - p0);
   a.qfirst = b.first + (int)(p0 * nqw);
   a.qcount = std::min(b.count - (int)(p0 * nqw), (int)(pn * nqw));
-  size_t shmem = (size_t)ref.ncodes * kSlotLanes * LS * 4 + (size_t)nslot * kCodeBuf;
+  size_t shmem = profile_lds_bytes(ref.ncodes, b.R, b.SL) + (size_t)nslot * codebuf_bytes(b.SL);
   dim3 grid((unsigned)(pn * cgroups), (unsigned)nr);
   a.brow = nullptr;
   a.brow_stride = 0;
   if (b.strips) {
-    const int64_t nseg = (a.warm + b.chunk_len + kSlotLanes + kSeg - 1) / kSeg;
-    a.brow_stride = (nseg + 3) * kSeg + 32;
+    const int64_t nseg = (a.warm + b.chunk_len + b.SL + kSeg - 1) / kSeg;
+    a.brow_stride = (nseg + 3) * kSeg + kBrowFront + 32;
     const size_t slots = (size_t)grid.x * grid.y * nslot;
     const size_t bytes = slots * 2 * (size_t)a.brow_stride * 4;
     if (bytes > ((size_t)64 << 30)) return fail(ctx, MI355_SW_ENOTSUP, "strip-mined sweep needs more than 64 GiB of boundary scratch");
     if (ctx->brow.ensure(bytes)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(strip boundary rows) failed");
     HIPCHK(ctx, hipMemsetAsync(ctx->brow.p, 0, bytes, ctx->stream));
     a.brow = ctx->brow.as<uint32_t>();
-    shmem += (size_t)2 * nslot * kSeg * 4;
+    shmem += (size_t)2 * nslot * kSeg * 4 + (size_t)nslot * 64 * 4;   // boundary windows + per-sub-chunk maxima
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   int rc = b.sem == kSemU8 ? launch_score_R<kSemU8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
@@ -1133,8 +1147,8 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
       }
     }
     for (int t = 0; t < nc; ++t) {
-      // lanes lag by up to 15 columns: the end of the previous sub-chunk is reported with this one
-      const int64_t own_lo = std::max<int64_t>(0, cand[t] * chunk_len - 15);   // range-relative, 0-based
+      // lanes lag by up to 63 columns (whole-wavefront tiles): the end of the previous sub-chunk is reported with this one
+      const int64_t own_lo = std::max<int64_t>(0, cand[t] * chunk_len - 63);   // range-relative, 0-based
       const int64_t own_hi = std::min((cand[t] + 1) * chunk_len, n);
       const int64_t wl = std::max<int64_t>(0, own_lo - warm);
       ExactJob j;
@@ -1177,7 +1191,7 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
   std::vector<TraceOut> tout(nq);
   if (n >= 1 && nq > 0) {
     const ScoreTable table = plan_table(ref, p);
-    std::vector<Bucket> buckets = make_buckets(q, table, p, n);
+    std::vector<Bucket> buckets = make_buckets(ref, q, table, p, n);
     std::vector<char> qfast(nq, 0), qfloat(nq, 0);
     std::vector<int64_t> qchunk(nq, 0), qwarm(nq, 0);
     bool any_fast = false;
@@ -1250,7 +1264,7 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   const ScoreTable table = plan_table(ref, p);
   int64_t maxn = 0;
   for (auto &r : ranges) maxn = std::max(maxn, r.hi - r.lo);
-  std::vector<Bucket> buckets = make_buckets(q, table, p, maxn);
+  std::vector<Bucket> buckets = make_buckets(ref, q, table, p, maxn);
   std::vector<char> qfast(nq, 0), qfloat(nq, 0);
   for (Bucket &b : buckets) {
     b.fast = true;

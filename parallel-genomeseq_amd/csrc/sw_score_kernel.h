@@ -32,8 +32,10 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kSlotLanes = 16;         // lanes of a DPP row; a tile ("slot") takes 16 or 8 of them
 constexpr int kSeg = 64;               // steps between two refills of the code window
-constexpr int kHist = 16;              // bytes of history kept in front of a segment
-constexpr int kCodeBuf = kHist + kSeg; // bytes per slot
+// bytes of history kept in front of a segment (>= lanes per slot - 1), and the per-slot window size
+__host__ __device__ constexpr int hist_bytes(int SL) { return SL > 16 ? SL : 16; }
+__host__ __device__ constexpr int codebuf_bytes(int SL) { return hist_bytes(SL) + kSeg; }
+constexpr int kBrowFront = 64;         // dwords of front padding of a strip boundary row (>= lanes per slot)
 constexpr int kPadScore = -16384;      // substitution score of padding rows / columns
 constexpr int kSemI16 = 0;             // Similarity_Matrix semantics on integer scores, two queries per register
 constexpr int kSemU8 = 1;              // Similarity_Matrix_Skewed semantics (saturate at 255), two queries per register
@@ -128,17 +130,21 @@ __device__ __forceinline__ uint32_t row_shr1(uint32_t v) {
 // DPP `old` operand of lane 0, where the single-strip kernel gets the zero border row.
 template <int R, int SEM, bool STRIPS = false, int SL = 16>
 __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
-  static_assert(SL == 16 || SL == 8, "a slot is a whole or half DPP row");
-  static_assert(!(STRIPS && SL != 16), "the strip-mined instance uses whole DPP rows");
+  static_assert(SL == 64 || SL == 16 || SL == 8, "a slot is a whole wavefront, a DPP row or half a DPP row");
+  static_assert(!(STRIPS && SL == 8), "the strip-mined instances use whole DPP rows or whole wavefronts");
   constexpr int LS = lane_stride(R);
   constexpr int NQ4 = (R + 3) / 4;
   constexpr int NSLOT = 256 / SL;                                  // tiles per workgroup
   constexpr int CPL = kSeg / SL;                                   // reference codes fetched per lane per segment
+  constexpr int PL = SL > 16 ? SL : 16;                            // lane positions of the profile
+  constexpr int HIST = hist_bytes(SL);
+  constexpr int CB = codebuf_bytes(SL);
+  constexpr int VPL = kSeg / SL >= 4 ? 4 : 1;                      // boundary-row values moved per lane per segment
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  uint32_t *prof = smem;                                           // [ncodes][16 lane positions][LS]
-  uint8_t *codebuf = reinterpret_cast<uint8_t *>(smem + a.ncodes * 16 * LS);
+  uint32_t *prof = smem;                                           // [ncodes][PL lane positions][LS]
+  uint8_t *codebuf = reinterpret_cast<uint8_t *>(smem + a.ncodes * PL * LS);
   // STRIPS: [NSLOT][64] boundary-in window, then [NSLOT][64] boundary-out staging
-  uint32_t *bwin = reinterpret_cast<uint32_t *>(codebuf + NSLOT * kCodeBuf);
+  uint32_t *bwin = reinterpret_cast<uint32_t *>(codebuf + NSLOT * CB);
 
   const int tid = threadIdx.x;
   const int ls = tid & (SL - 1);                                   // lane within the slot
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   auto build_profile = [&](int row0) {
     const uint8_t *xA = a.qbytes + a.qoff[qA];
     const uint8_t *xB = a.qbytes + a.qoff[qB];
-    const int per_code = 16 * R;
+    const int per_code = PL * R;
     for (int e = tid; e < a.ncodes * per_code; e += 256) {
       const int c = e / per_code;
       const int rem = e - c * per_code;
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
         const int sb = (i < mB) ? st[(int)xB[i] * a.ncodes + c] : kPadScore;
         e32 = (uint32_t)(uint16_t)sa | ((uint32_t)(uint16_t)sb << 16);
       }
-      prof[(c * 16 + ll) * LS + r] = e32;
+      prof[(c * PL + ll) * LS + r] = e32;
     }
   };
   build_profile(0);
@@ -193,40 +199,64 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   const uint32_t pad = (uint32_t)(a.ncodes - 1);
   const uint32_t pad4 = pad * 0x01010101u;
 
-  // codes of stream positions seg*64 + CPL*ls .. +CPL-1 (pad outside [rlo, own_hi)), CPL/4 dwords
-  struct Codes { uint32_t w[CPL / 4]; };
+  // codes of stream positions seg*64 + CPL*ls .. +CPL-1 (pad outside [rlo, own_hi)): CPL/4 dwords, or one
+  // byte per lane when the slot is a whole wavefront
+  struct Codes { uint32_t w[CPL >= 4 ? CPL / 4 : 1]; };
   auto stage_load = [&](int seg) -> Codes {
     Codes out;
     const int64_t c0 = s0 + (int64_t)seg * kSeg + CPL * ls;
+    if (CPL >= 4) {
 #pragma unroll
-    for (int d = 0; d < CPL / 4; ++d) {
-      uint32_t w = 0;
+      for (int d = 0; d < CPL / 4; ++d) {
+        uint32_t w = 0;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int64_t col = c0 + 4 * d + b;
-        const bool ok = active && col >= rlo && col < own_hi;
-        const uint32_t code = ok ? (uint32_t)a.refcodes[col] : pad;
-        w |= code << (8 * b);
+        for (int b = 0; b < 4; ++b) {
+          const int64_t col = c0 + 4 * d + b;
+          const bool ok = active && col >= rlo && col < own_hi;
+          const uint32_t code = ok ? (uint32_t)a.refcodes[col] : pad;
+          w |= code << (8 * b);
+        }
+        out.w[d] = w;
       }
-      out.w[d] = w;
+    } else {
+      const bool ok = active && c0 >= rlo && c0 < own_hi;
+      out.w[0] = ok ? (uint32_t)a.refcodes[c0] : pad;
     }
     return out;
   };
 
-  uint8_t *buf = codebuf + slot * kCodeBuf;
+  uint8_t *buf = codebuf + slot * CB;
   uint32_t *buf32 = reinterpret_cast<uint32_t *>(buf);
-  const uint8_t *buf_lane = buf + kHist - ls;                      // + k = code of step k
-  const uint32_t *prof_lane = prof + (tid & 15) * LS;
+  const uint8_t *buf_lane = buf + HIST - ls;                       // + k = code of step k
+  const uint32_t *prof_lane = prof + (tid & (PL - 1)) * LS;
   auto window_put = [&](const Codes &c) {
+    if (CPL >= 4) {
 #pragma unroll
-    for (int d = 0; d < CPL / 4; ++d) buf32[kHist / 4 + (CPL / 4) * ls + d] = c.w[d];
+      for (int d = 0; d < CPL / 4; ++d) buf32[HIST / 4 + (CPL / 4) * ls + d] = c.w[d];
+    } else {
+      buf[HIST + ls] = (uint8_t)c.w[0];
+    }
+  };
+  // first fill: history = padding; later: the last HIST bytes of the window move to its front
+  auto window_init = [&]() {
+    if (SL == 64) buf[ls] = (uint8_t)pad;
+    else if (ls < HIST / 4) buf32[ls] = pad4;
+  };
+  auto window_slide = [&]() {
+    if (SL == 64) { const uint8_t h = buf[kSeg + ls]; buf[ls] = h; }
+    else { const uint32_t h = buf32[kSeg / 4 + (ls & 3)]; if (ls < HIST / 4) buf32[ls] = h; }
+  };
+  // value of the lane above: DPP inside the row (16/8 lanes) or across the wavefront (64 lanes)
+  auto shift_in = [&](uint32_t v, uint32_t border) -> uint32_t {
+    if (SL == 64) return (uint32_t)__builtin_amdgcn_update_dpp((int)border, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)border, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
   };
 
   const int64_t total_steps = a.warm + a.chunk_len + SL;           // + SL-1 skew, + 1 max-fold drain
   const int nseg = (int)((total_steps + kSeg - 1) / kSeg);
 
   T mx = C::from_bits(0u);
-  const int code_stride = 16 * LS;                                 // dwords per reference code
+  const int code_stride = PL * LS;                                 // dwords per reference code
   const int strip_rows = SL * R;
   const int mmax = mA > mB ? mA : mB;
   const int nstrips = STRIPS ? (mmax + strip_rows - 1) / strip_rows : 1;
@@ -241,13 +271,16 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   // columns of a sub-chunk are reported with the next one; the host widens its search accordingly.
   const int64_t subs_per_tile = a.chunk_len / a.sub_len;
   uint32_t best_a = 0, best_b = 0;                                 // this tile's best published value per query
-  auto publish = [&](int64_t sub) {
+  auto slot_max = [&]() -> uint32_t {                              // maximum of mx over the slot's lanes
     uint32_t m32 = C::bits(mx);
 #pragma unroll
     for (int off = SL / 2; off >= 1; off >>= 1) {
       const uint32_t o = (uint32_t)__shfl_xor((int)m32, off, SL);
       m32 = C::bits(C::vmax(C::from_bits(m32), C::from_bits(o)));
     }
+    return m32;
+  };
+  auto publish_value = [&](int64_t sub, uint32_t m32) {
     // Only a sub-chunk that strictly beats the tile's earlier ones can become the query's (max, first
     // sub-chunk) key, so all others skip the atomic (a tile publishes O(log) times, not once per sub-chunk).
     if (ls == 0 && active) {
@@ -264,13 +297,27 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
         if (hasB && vb > best_b) { best_b = vb; atomicMax(k + qB, ((unsigned long long)vb << 32) | tag); }
       }
     }
+  };
+  auto publish = [&](int64_t sub) {
+    publish_value(sub, slot_max());
     mx = C::from_bits(0u);
   };
+  // STRIPS: a sub-chunk's maximum accumulates over all strips in LDS before it can be published
+  uint32_t *submax = bwin + 2 * NSLOT * kSeg + slot * 64;
+  auto fold_sub = [&](int64_t sub) {
+    const uint32_t m32 = slot_max();
+    if (ls == 0) submax[sub] = C::bits(C::vmax(C::from_bits(submax[sub]), C::from_bits(m32)));
+    mx = C::from_bits(0u);
+  };
+  if (STRIPS) {
+    for (int e = ls; e < 64; e += SL) submax[e] = 0u;
+  }
   const int segs_per_sub = (int)(a.sub_len / kSeg);
   const int warm_segs = (int)(a.warm / kSeg);
   int64_t sub = 0;
 
   for (int strip = 0; strip < nstrips; ++strip) {
+    if (STRIPS) sub = 0;
     if (STRIPS && strip > 0) {
       // the boundary row written by this tile's own lanes in the previous strip is re-read below:
       // drain the stores, invalidate this CU's L1 (it may hold the row's lines from two strips ago)
@@ -278,20 +325,27 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
       __syncthreads();                                             // everyone done with the old profile
       build_profile(strip * strip_rows);
     }
-    const uint32_t *bin_g = STRIPS ? brow0 + (size_t)(strip & 1) * a.brow_stride + 16 : nullptr;
-    uint32_t *bout_g = STRIPS ? brow0 + (size_t)((strip + 1) & 1) * a.brow_stride + 16 : nullptr;
+    const uint32_t *bin_g = STRIPS ? brow0 + (size_t)(strip & 1) * a.brow_stride + kBrowFront : nullptr;
+    uint32_t *bout_g = STRIPS ? brow0 + (size_t)((strip + 1) & 1) * a.brow_stride + kBrowFront : nullptr;
     const bool rd = STRIPS && strip > 0, wr = STRIPS && strip + 1 < nstrips;
-    auto bin_load = [&](int seg) -> uint4 {                       // boundary values of stream positions seg*64+4*ls..+3
-      return rd ? *reinterpret_cast<const uint4 *>(bin_g + (size_t)seg * kSeg + 4 * ls) : make_uint4(0, 0, 0, 0);
+    // boundary values of stream positions seg*64 + VPL*ls .. +VPL-1
+    auto bin_load = [&](int seg) -> uint4 {
+      if (!rd) return make_uint4(0, 0, 0, 0);
+      if (VPL == 4) return *reinterpret_cast<const uint4 *>(bin_g + (size_t)seg * kSeg + 4 * ls);
+      return make_uint4(bin_g[(size_t)seg * kSeg + ls], 0, 0, 0);
+    };
+    auto bin_put = [&](const uint4 &v) {
+      if (VPL == 4) *reinterpret_cast<uint4 *>(bin_w + 4 * ls) = v;
+      else bin_w[ls] = v.x;
     };
 
     Codes nextcodes = stage_load(0);
-    if (ls < kHist / 4) buf32[ls] = pad4;
+    window_init();
     window_put(nextcodes);
     nextcodes = stage_load(1);
     uint4 nextb = make_uint4(0, 0, 0, 0);
     if (STRIPS) {
-      *reinterpret_cast<uint4 *>(bin_w + 4 * ls) = bin_load(0);
+      bin_put(bin_load(0));
       nextb = bin_load(1);
     }
     __syncthreads();                                               // profile + first window ready
@@ -315,9 +369,9 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
         uint32_t up;                                               // H(i0-1, j) of the lane above
         if (STRIPS) {
           // lane 0 takes the previous strip's bottom row through the DPP `old` operand
-          up = (uint32_t)__builtin_amdgcn_update_dpp((int)bin_w[k], (int)C::bits(H[R - 1]), 0x111, 0xf, 0xf, false);
+          up = shift_in(C::bits(H[R - 1]), bin_w[k]);
         } else {
-          up = row_shr1(C::bits(H[R - 1]));
+          up = shift_in(C::bits(H[R - 1]), 0u);                    // zero border row H(0, .)
           if (SL == 8) up &= first_lane_zero;                      // lane 8 of the DPP row starts another tile
         }
         T diag = C::from_bits(up_prev);                            // H(i0-1, j-1)
@@ -340,30 +394,44 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
           if (ls == SL - 1) bout_w[k] = C::bits(H[R - 1]);         // bottom row at stream position seg*64+k-(SL-1)
         }
       }
-      // slide the code window: keep the last 16 bytes as history, append the prefetched segment
-      const uint32_t hist = buf32[kSeg / 4 + (ls & 3)];
-      if (ls < kHist / 4) buf32[ls] = hist;
+      // slide the code window: keep the last HIST bytes as history, append the prefetched segment
+      window_slide();
       window_put(nextcodes);
       nextcodes = stage_load(seg + 2);
-      if (!STRIPS) {
+      {
         // lane 0 has just finished a sub-chunk (and it is not the tile's last): report and restart the maximum
         const int done = seg + 1 - warm_segs;
-        if (done > 0 && done % segs_per_sub == 0 && done / segs_per_sub < subs_per_tile) publish(sub++);
+        if (done > 0 && done % segs_per_sub == 0 && done / segs_per_sub < subs_per_tile) {
+          if (STRIPS) fold_sub(sub++); else publish(sub++);
+        }
       }
       if (STRIPS) {
         if (wr) {
           // flush 64 bottom-row values: positions seg*64 - (SL-1) + (0..63)
-          uint32_t *g = bout_g + (int64_t)seg * kSeg - (SL - 1) + 4 * ls;
-          const uint4 v = *reinterpret_cast<const uint4 *>(bout_w + 4 * ls);
-          g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
+          if (VPL == 4) {
+            uint32_t *g = bout_g + (int64_t)seg * kSeg - (SL - 1) + 4 * ls;
+            const uint4 v = *reinterpret_cast<const uint4 *>(bout_w + 4 * ls);
+            g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
+          } else {
+            bout_g[(int64_t)seg * kSeg - (SL - 1) + ls] = bout_w[ls];
+          }
         }
-        *reinterpret_cast<uint4 *>(bin_w + 4 * ls) = nextb;
+        bin_put(nextb);
         nextb = bin_load(seg + 2);
       }
     }
+    if (STRIPS) fold_sub(sub);                                     // this strip's last (or only) sub-chunk
   }
 
-  publish(sub);                                                    // the tile's last (or only) sub-chunk
+  if (STRIPS) {
+    // (the last sub-chunk of every strip was folded at the end of the strip loop body below)
+    for (int64_t k2 = 0; k2 < subs_per_tile; ++k2) {
+      const uint32_t v = submax[k2];                               // written by lane 0 of this slot, same wavefront
+      publish_value(k2, v);
+    }
+  } else {
+    publish(sub);                                                  // the tile's last (or only) sub-chunk
+  }
 }
 
 }  // namespace mi355sw
