@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
     uint32_t up_prev = 0;
 
     for (int seg = 0; seg < nseg; ++seg) {
-#pragma unroll 8
+#pragma unroll 4
       for (int k = 0; k < kSeg; ++k) {
         const uint32_t c = buf_lane[k];
         const uint4 *pp = reinterpret_cast<const uint4 *>(prof_lane + c * code_stride);
