@@ -260,7 +260,8 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   const int strip_rows = SL * R;
   const int mmax = mA > mB ? mA : mB;
   const int nstrips = STRIPS ? (mmax + strip_rows - 1) / strip_rows : 1;
-  const uint32_t first_lane_zero = ls == 0 ? 0u : 0xFFFFFFFFu;     // SL = 8: zero border row for lane 0 of the slot
+  uint32_t first_lane_zero = ls == 0 ? 0u : 0xFFFFFFFFu;           // SL = 8: zero border row for lane 0 of the slot
+  asm volatile("" : "+v"(first_lane_zero));                        // keep it a plain v_and_b32 (2 cycles), not a v_cndmask (4)
   // STRIPS: this tile's ping-pong boundary rows (global), and its LDS windows
   const size_t tile_id = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NSLOT + slot;
   uint32_t *brow0 = STRIPS ? a.brow + tile_id * 2 * (size_t)a.brow_stride : nullptr;
@@ -371,7 +372,9 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
           // lane 0 takes the previous strip's bottom row through the DPP `old` operand
           up = shift_in(C::bits(H[R - 1]), bin_w[k]);
         } else {
-          up = shift_in(C::bits(H[R - 1]), 0u);                    // zero border row H(0, .)
+          // zero border row H(0, .): bound_ctrl supplies it (no `old` operand to set up)
+          if (SL == 64) up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C::bits(H[R - 1]), 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+          else up = row_shr1(C::bits(H[R - 1]));
           if (SL == 8) up &= first_lane_zero;                      // lane 8 of the DPP row starts another tile
         }
         T diag = C::from_bits(up_prev);                            // H(i0-1, j-1)
