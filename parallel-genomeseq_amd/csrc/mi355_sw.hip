@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -32,6 +33,18 @@ constexpr size_t kProfileLdsMax = 120 * 1024;  // LDS budget of the query profil
 constexpr int kMaxRowsFast = 512;             // 16 lanes x R <= 32 rows in one strip; longer queries are strip-mined
 constexpr size_t kDirsBudget = 3ull << 30;    // bytes of traceback decisions per exact launch
 constexpr size_t kExactLdsMax = 159 * 1024;    // dynamic part; the wide instance adds < 1 KiB of static LDS
+
+// MI355_SW_TRACE=1: wall-clock of the host-side phases of every call on stderr (diagnostic)
+struct HostTrace {
+  const char *name;
+  std::chrono::steady_clock::time_point t0;
+  explicit HostTrace(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
+  ~HostTrace() {
+    static const bool on = std::getenv("MI355_SW_TRACE") != nullptr;
+    if (on) std::fprintf(stderr, "[mi355_sw] %-28s %9.3f ms\n", name,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+};
 
 struct DevBuf {
   void *p = nullptr;
@@ -137,6 +150,7 @@ unsigned long long host_order_key(int sem, int64_t i, int64_t j, int64_t m, int6
 }
 
 int upload_reference(mi355_sw_ctx *ctx, RefData &r, const char *y, size_t ny) {
+  HostTrace trace_("upload_reference");
   bool present[256] = {false};
   const uint8_t *u = reinterpret_cast<const uint8_t *>(y);
   for (size_t k = 0; k < ny; ++k) present[u[k]] = true;
@@ -186,6 +200,7 @@ int adhoc_reference(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData *
 }
 
 int upload_queries(mi355_sw_ctx *ctx, QueryBatch &q, size_t n, const char *const *xs, const size_t *nxs) {
+  HostTrace trace_("upload_queries");
   q.nq = n;
   q.len.resize(n);
   q.off.resize(n);
@@ -439,6 +454,7 @@ int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range>
 // One score-kernel launch: bucket b over all ranges.  Device time is added to ctx->timings[0].
 int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const std::vector<Range> &ranges,
                  const mi355_sw_params &p, const ScoreTable &t, Bucket &b) {
+  HostTrace trace_("score_launch");
   const size_t nr = ranges.size();
   int64_t maxlen = 0;
   for (auto &r : ranges) maxlen = std::max(maxlen, r.hi - r.lo);
@@ -733,6 +749,7 @@ void launch_wave_R(int orient, bool u8, bool track, bool dirs, unsigned blocks, 
 // One launch: all jobs share orientation and flags; lanes side <= 512.
 int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg, const mi355_sw_params &p,
              std::vector<WaveJob> &jobs) {
+  HostTrace trace_("run_wave");
   const size_t n = jobs.size();
   if (n == 0) return 0;
   const int orient = jobs[0].orient;
@@ -789,6 +806,7 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
 // the streamed side, grown on demand; then the greedy walk.  orient as WaveJob.
 int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg, const mi355_sw_params &p,
                int orient, const std::vector<int> &qidx, const std::vector<Located> &loc, std::vector<TraceOut> &tout) {
+  HostTrace trace_("wave_trace");
   const int64_t nref = rg.hi - rg.lo;
   tout.assign(qidx.size(), TraceOut());
   std::vector<size_t> todo;
@@ -1039,6 +1057,7 @@ int exact_full_lds(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, c
 int exact_full(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
                const mi355_sw_params &p, const std::vector<int> &qidx, bool want_trace,
                std::vector<Located> &loc, std::vector<TraceOut> &tout) {
+  HostTrace trace_("exact_full");
   const int64_t n = rg.hi - rg.lo;
   loc.assign(qidx.size(), Located());
   tout.assign(qidx.size(), TraceOut());
@@ -1117,6 +1136,7 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
                 const mi355_sw_params &p, const std::vector<char> &qfast, const std::vector<int64_t> &qchunk,
                 const std::vector<int64_t> &qwarm, const std::vector<char> &qfloat, const unsigned long long *keys,
                 std::vector<Located> &loc) {
+  HostTrace trace_("locate_fast");
   const size_t nq = q.nq;
   const int64_t n = rg.hi - rg.lo;
   std::vector<ExactJob> jobs;
@@ -1183,6 +1203,7 @@ float elapsed_us(mi355_sw_ctx *ctx, hipEvent_t a, hipEvent_t b) {
 // All queries of `q` against one range of the reference.
 int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
                 const mi355_sw_params &p, int flags, mi355_sw_result *outs) {
+  HostTrace trace_("align_range");
   const bool want_trace = !(flags & MI355_SW_SCORE_ONLY);
   const size_t nq = q.nq;
   const int64_t n = rg.hi - rg.lo;
@@ -1248,6 +1269,7 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
   ctx->timings[3] += elapsed_us(ctx, ctx->ev[4], ctx->ev[5]);
+  HostTrace trace_results("set_results");
   for (size_t k = 0; k < nq; ++k) {
     set_result(outs[k], loc[k].score, loc[k].ix, loc[k].iy, (want_trace && loc[k].score > 0) ? &tout[k] : nullptr);
     outs[k].timings_us[0] = (float)(ctx->timings[0] > 0 ? ctx->timings[0] : ctx->timings[3]);
