@@ -432,3 +432,21 @@ def test_fuzz_batches_and_splits(ctx, oracle, pgs):
         got = ctx.align_split(q, ref, npiece, ratio, sm, la, ma, mi, g)
         assert got["piece"] == exp["piece"]
         _cmp(got, {k: exp[k] for k in ("score", "pos", "cons_x", "cons_y")}, "fuzz split t=%d" % t)
+
+
+def test_error_codes(ctx, pgs):
+    """Error behaviour through the C-ABI: inputs outside kernel coverage fail loudly (no silent fallback), the
+    reference's constructor asserts map to MI355_SW_ERANGE, bad arguments to MI355_SW_EINVAL."""
+    ref = pgs.synth.dna(5, 30_000_000)
+    q = ref[1000:1150].tobytes()
+    with pytest.raises(pgs.MI355Error) as e:
+        ctx.align(q, ref, 0, 3.0, -3.0, 0.0)                       # zero gap penalty: no finite warm-up margin, matrix too large
+    assert e.value.code == -95 and "coverage" in str(e.value)
+    with pytest.raises(pgs.MI355Error) as e:
+        ctx.align_split("A" * 100, "C" * 120, 4, 2.0)               # overlap > piece length (plocalaligner.cpp:52)
+    assert e.value.code == -34
+    with pytest.raises(pgs.MI355Error) as e:
+        ctx.align(q, ref, 7)                                        # unknown semantics
+    assert e.value.code == -22
+    # small problems with the same "unsupported" scoring still run (whole-matrix path)
+    assert ctx.align("GGTTGACTA", "TGTTACGG", 0, 3.0, -3.0, 0.0)["score"] > 0
