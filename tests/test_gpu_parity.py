@@ -450,3 +450,16 @@ def test_error_codes(ctx, pgs):
     assert e.value.code == -22
     # small problems with the same "unsupported" scoring still run (whole-matrix path)
     assert ctx.align("GGTTGACTA", "TGTTACGG", 0, 3.0, -3.0, 0.0)["score"] > 0
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+def test_long_query_pairs(ctx, oracle, pgs, sem):
+    """Several long queries per length class, so that the packed (two queries per register) instances run on
+    whole-wavefront tiles: one strip (<= 2048 rows) and strip-mined (> 2048 rows), odd counts included."""
+    ref = pgs.synth.dna(91, 90_000)
+    refb = ref.tobytes()
+    qs = []
+    for k, m in enumerate((900, 1000, 1024, 1800, 2048, 2000, 2500, 3000, 2600)):
+        qs.append(pgs.synth.read_from_ref(ref, 1200 + k, m, sub_rate=0.03, indel_rate=0.006)[0].tobytes())
+    for q, got in zip(qs, ctx.align_batch(qs, refb, semantics=sem)):
+        _cmp(got, oracle.align(q, refb, sem), "long pairs sem=%d |q|=%d" % (sem, len(q)))
