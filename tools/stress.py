@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Randomised differential stress run: the HIP path (C-ABI) against the CPU oracle for a time budget.
+Covers single alignments, ragged batches and the split aligner over a wide range of shapes, alphabets and
+scorings.  Usage: python tools/stress.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g  # noqa: E402
+
+pgs = g._load_package()
+from oracle import binding as ob  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+rng = np.random.default_rng(seed)
+ctx = pgs.Context(0)
+KEYS = ("score", "pos", "end_x", "end_y", "cons_x", "cons_y")
+ALPH = [b"ACGT", b"ACGT", b"ACGT", b"AC", b"ACGTN", b"ACDEFGHIKLMNPQRSTVWY", bytes(range(65, 65 + 26))]
+SC = [(3.0, -3.0, 2.0)] * 5 + [(2.0, -1.0, 1.0), (5.0, -4.0, 3.0), (1.0, -1.0, 1.0), (10.0, -2.0, 4.0), (3.5, -2.25, 1.5),
+                               (4.0, -6.0, 3.0), (1.0, -3.0, 5.0), (7.0, -7.0, 1.0), (255.0, -200.0, 100.0), (0.5, -0.25, 0.25)]
+
+
+def rseq(n, alpha):
+    a = np.frombuffer(alpha, dtype=np.uint8)
+    return a[rng.integers(0, len(a), size=n)].tobytes()
+
+
+def mutate(s, alpha, rate):
+    b = bytearray(s)
+    a = np.frombuffer(alpha, dtype=np.uint8)
+    out = bytearray()
+    for ch in b:
+        u = rng.random()
+        if u < rate / 4:
+            continue
+        if u < rate / 2:
+            out.append(int(a[rng.integers(0, len(a))]))
+        out.append(int(a[rng.integers(0, len(a))]) if rng.random() < rate else ch)
+    return bytes(out) or bytes(b[:1])
+
+
+def plant(ref, m, alpha):
+    n = len(ref)
+    if n > m + 2 and rng.random() < 0.7:
+        o = int(rng.integers(0, n - m))
+        return mutate(ref[o:o + m], alpha, float(rng.choice([0.0, 0.02, 0.08, 0.2])))[:max(1, m)]
+    return rseq(m, alpha)
+
+
+t0 = time.time()
+ncase = nbad = 0
+while time.time() - t0 < budget:
+    alpha = ALPH[int(rng.integers(0, len(ALPH)))]
+    kind = int(rng.integers(0, 10))
+    ma, mi, gp = SC[int(rng.integers(0, len(SC)))]
+    sem = int(rng.integers(0, 2))
+    if kind <= 5:       # single alignment, oracle cost bounded to ~3e8 cells
+        m = int(rng.choice([1, 5, 33, 64, 100, 150, 152, 153, 250, 400, 512, 513, 1000, 2048, 2049, 3000, 6000]))
+        nmax = max(2, int(3e8 // max(m, 1)))
+        n = int(min(nmax, rng.choice([3, 150, 900, 1024, 5000, 40000, 300000, 2000000])))
+        ref = rseq(n, alpha)
+        q = plant(ref, m, alpha)
+        exp = ob.align(q, ref, sem, ma, mi, gp)
+        got = ctx.align(q, ref, sem, ma, mi, gp)
+        bad = [k for k in KEYS if got[k] != exp[k]]
+        if bad:
+            nbad += 1
+            print("MISMATCH single m=%d n=%d sem=%d sc=%s alpha=%d keys=%s got=%s exp=%s" %
+                  (len(q), n, sem, (ma, mi, gp), len(alpha), bad, {k: got[k] for k in bad[:2]}, {k: exp[k] for k in bad[:2]}), flush=True)
+        ncase += 1
+    elif kind <= 7:     # ragged batch
+        n = int(rng.choice([1500, 20000, 150000]))
+        ref = rseq(n, alpha)
+        qs = [plant(ref, int(rng.choice([0, 1, 20, 100, 150, 151, 300, 600, 1100, 2300])), alpha) if rng.random() > 0.05 else b""
+              for _ in range(int(rng.integers(1, 24)))]
+        res = ctx.align_batch(qs, ref, semantics=sem, match=ma, mismatch=mi, gap=gp)
+        for q, got in zip(qs, res):
+            exp = ob.align(q, ref, sem, ma, mi, gp)
+            bad = [k for k in KEYS if got[k] != exp[k]]
+            if bad:
+                nbad += 1
+                print("MISMATCH batch |q|=%d n=%d sem=%d sc=%s keys=%s" % (len(q), n, sem, (ma, mi, gp), bad), flush=True)
+            ncase += 1
+    else:               # split aligner
+        n = int(rng.choice([3000, 30000, 120000]))
+        m = int(rng.choice([20, 150, 400, 1200]))
+        ref = rseq(n, alpha)
+        q = plant(ref, m, alpha)
+        npiece = int(rng.choice([1, 2, 3, 7, 17]))
+        ratio = float(rng.choice([2.0, 1.0, 1.5]))
+        sm, la = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        if ob.make_string_range(npiece, len(q), n, ratio) is None:
+            continue
+        exp = ob.align_split(q, ref, npiece, ratio, sm, la, ma, mi, gp)
+        got = ctx.align_split(q, ref, npiece, ratio, sm, la, ma, mi, gp)
+        bad = [k for k in ("score", "pos", "cons_x", "cons_y", "piece") if got[k] != exp[k]]
+        if bad:
+            nbad += 1
+            print("MISMATCH split m=%d n=%d npiece=%d sm=%d la=%d sc=%s keys=%s" % (len(q), n, npiece, sm, la, (ma, mi, gp), bad), flush=True)
+        ncase += 1
+print("stress: %d cases in %.0f s, %d mismatches (seed %d)" % (ncase, time.time() - t0, nbad, seed), flush=True)
+ctx.close()
+sys.exit(1 if nbad else 0)
