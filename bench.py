@@ -143,7 +143,7 @@ def main():
         local_rank = local_rank % max(1, torch.cuda.device_count())   # rehearsal on fewer GPUs than ranks
     torch.cuda.set_device(local_rank)
     cdev = "cuda" if args.dist_backend == "nccl" else "cpu"
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:          # under torch.distributed.run even one rank joins a group
         import torch.distributed as dist
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
