@@ -463,3 +463,32 @@ def test_long_query_pairs(ctx, oracle, pgs, sem):
         qs.append(pgs.synth.read_from_ref(ref, 1200 + k, m, sub_rate=0.03, indel_rate=0.006)[0].tobytes())
     for q, got in zip(qs, ctx.align_batch(qs, refb, semantics=sem)):
         _cmp(got, oracle.align(q, refb, sem), "long pairs sem=%d |q|=%d" % (sem, len(q)))
+
+
+def test_reference_longer_than_2g_columns(ctx, pgs, oracle):
+    """Maximum sizes: a 2.2 Gbp reference (column indices beyond 2^31).  Reads cut near the far end must be
+    found at their 64-bit columns; a window around each hit is re-aligned by the oracle and the consensus and
+    start position must agree after shifting by the window offset."""
+    n = 2_200_000_000
+    ref = np.empty(n, dtype=np.uint8)
+    step = 100_000_000
+    for k in range(0, n, step):                               # chunked: keeps host temporaries small
+        ref[k:k + step] = pgs.synth.dna(1000 + k // step, min(step, n - k))
+    offs = [n - 150, 2_147_483_648 - 75, 2_147_483_648 + 3, 2_190_000_123, 17]
+    reads = []
+    for k, o in enumerate(offs):
+        r = ref[o:o + 150].copy()
+        if k >= 2:
+            r[40 + k] = ord("A") if r[40 + k] != ord("A") else ord("C")     # one substitution
+        reads.append(r.tobytes())
+    ctx.set_reference(ref)
+    ctx.batch_upload(reads)
+    for sem in (0, 1):
+        res = ctx.batch_run(semantics=sem)
+        for o, q, r in zip(offs, reads, res):
+            lo = max(0, o - 600)
+            exp = oracle.align(q, ref[lo:min(n, o + 750)].tobytes(), sem)
+            assert r["score"] == exp["score"] and r["end_x"] == exp["end_x"], (sem, o)
+            assert r["end_y"] == exp["end_y"] + lo and r["pos"] == exp["pos"] + lo, (sem, o, r["end_y"], r["pos"])
+            assert r["cons_x"] == exp["cons_x"] and r["cons_y"] == exp["cons_y"], (sem, o)
+    ctx.set_reference(b"ACGT")                                 # release the 2.2 GB device copy
