@@ -24,6 +24,7 @@
 #include "sw_exact_kernel.h"
 #include "sw_score_kernel.h"
 #include "sw_wave_kernel.h"
+#include "sw_strip_kernel.h"
 
 using namespace mi355sw;
 
@@ -602,10 +603,24 @@ int run_exact(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   if (ctx->probs.ensure(n * sizeof(ExactProblem)) || ctx->outs_f.ensure(n * 4) || ctx->outs_i.ensure(n * 16) ||
       (dirs_total && ctx->dirs.ensure(dirs_total)))
     return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(exact scratch) failed");
+  // few problems with long diagonals: sixteen wavefronts per problem; the others one wavefront each
+  std::vector<size_t> slot(n);                     // position of job lo + k in the problem array: wide ones first
+  size_t nwide = 0, lds_narrow = 0;
+  {
+    std::vector<size_t> wide_k, narrow_k;
+    for (size_t k = 0; k < n; ++k)
+      (std::min<int>(q.len[jobs[lo + k].q], jobs[lo + k].nw) >= 1024 ? wide_k : narrow_k).push_back(k);
+    if (wide_k.size() > 2048) { narrow_k.insert(narrow_k.end(), wide_k.begin(), wide_k.end()); wide_k.clear(); }
+    nwide = wide_k.size();
+    lds_narrow = 0;
+    for (size_t k : narrow_k) lds_narrow = std::max(lds_narrow, exact_lds_bytes(q.len[jobs[lo + k].q], jobs[lo + k].nw));
+    for (size_t t = 0; t < wide_k.size(); ++t) slot[wide_k[t]] = t;
+    for (size_t t = 0; t < narrow_k.size(); ++t) slot[narrow_k[t]] = nwide + t;
+  }
   std::vector<ExactProblem> pr(n);
   for (size_t k = 0; k < n; ++k) {
     const ExactJob &j = jobs[lo + k];
-    ExactProblem &e = pr[k];
+    ExactProblem &e = pr[slot[k]];
     e.x = q.bytes.as<uint8_t>() + q.off[j.q];
     e.y = ref.bytes.as<uint8_t>() + j.ylo;
     e.m = q.len[j.q];
@@ -617,24 +632,22 @@ int run_exact(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
     e.target = j.target;
     e.dirs = j.want_dirs ? ctx->dirs.as<uint8_t>() + j.dirs_off : nullptr;
     e.hout = hout;
-    e.best = ctx->outs_f.as<float>() + k;
-    e.cell = ctx->outs_i.as<int64_t>() + 2 * k;
+    e.best = ctx->outs_f.as<float>() + slot[k];
+    e.cell = ctx->outs_i.as<int64_t>() + 2 * slot[k];
   }
   HIPCHK(ctx, hipMemcpyAsync(ctx->probs.p, pr.data(), n * sizeof(ExactProblem), hipMemcpyHostToDevice, ctx->stream));
   bool lut_up = false;
   int rc = 0;
   const ExactScoring sc = make_scoring(ctx, p, lut_up, rc);
   if (rc) return fail(ctx, rc, "scoring table upload failed");
-  // few problems with long diagonals: sixteen wavefronts per problem; otherwise one wavefront each
-  int mindiag = 1 << 30;
-  for (size_t k = lo; k < hi; ++k) mindiag = std::min(mindiag, std::min<int>(q.len[jobs[k].q], jobs[k].nw));
-  const bool wide = n <= 2048 && mindiag >= 1024;
+  const ExactProblem *dp = ctx->probs.as<ExactProblem>();
+  const size_t nnarrow = n - nwide;
   if (p.semantics == MI355_SW_U8SAT) {
-    if (wide) hipLaunchKernelGGL((sw_exact_kernel<1, 1024>), dim3((unsigned)n), dim3(1024), lds, ctx->stream, ctx->probs.as<ExactProblem>(), sc);
-    else hipLaunchKernelGGL((sw_exact_kernel<1, 64>), dim3((unsigned)n), dim3(64), lds, ctx->stream, ctx->probs.as<ExactProblem>(), sc);
+    if (nwide) hipLaunchKernelGGL((sw_exact_kernel<1, 1024>), dim3((unsigned)nwide), dim3(1024), lds, ctx->stream, dp, sc);
+    if (nnarrow) hipLaunchKernelGGL((sw_exact_kernel<1, 64>), dim3((unsigned)nnarrow), dim3(64), lds_narrow, ctx->stream, dp + nwide, sc);
   } else {
-    if (wide) hipLaunchKernelGGL((sw_exact_kernel<0, 1024>), dim3((unsigned)n), dim3(1024), lds, ctx->stream, ctx->probs.as<ExactProblem>(), sc);
-    else hipLaunchKernelGGL((sw_exact_kernel<0, 64>), dim3((unsigned)n), dim3(64), lds, ctx->stream, ctx->probs.as<ExactProblem>(), sc);
+    if (nwide) hipLaunchKernelGGL((sw_exact_kernel<0, 1024>), dim3((unsigned)nwide), dim3(1024), lds, ctx->stream, dp, sc);
+    if (nnarrow) hipLaunchKernelGGL((sw_exact_kernel<0, 64>), dim3((unsigned)nnarrow), dim3(64), lds_narrow, ctx->stream, dp + nwide, sc);
   }
   HIPCHK(ctx, hipGetLastError());
   std::vector<float> bf(n);
@@ -642,7 +655,7 @@ int run_exact(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   HIPCHK(ctx, hipMemcpyAsync(bf.data(), ctx->outs_f.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ci.data(), ctx->outs_i.p, n * 16, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  for (size_t k = 0; k < n; ++k) { jobs[lo + k].best = bf[k]; jobs[lo + k].ci = ci[2 * k]; jobs[lo + k].cj = ci[2 * k + 1]; }
+  for (size_t k = 0; k < n; ++k) { jobs[lo + k].best = bf[slot[k]]; jobs[lo + k].ci = ci[2 * slot[k]]; jobs[lo + k].cj = ci[2 * slot[k] + 1]; }
   return 0;
 }
 
@@ -654,7 +667,8 @@ struct TraceOut {
 // Walk over decisions of jobs[lo,hi) (all with want_dirs), starting at (start_i, local nw...).
 int run_walk(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const std::vector<ExactJob> &jobs,
              size_t lo, size_t hi, const std::vector<std::pair<int32_t, int32_t>> &starts,
-             const std::vector<int32_t> &exact_lo, std::vector<TraceOut> &outs, std::vector<int> &status) {
+             const std::vector<int32_t> &exact_lo, std::vector<TraceOut> &outs, std::vector<int> &status,
+             float need_slope = 0.0f) {
   const size_t n = hi - lo;
   if (n == 0) return 0;
   std::vector<WalkProblem> wp(n);
@@ -679,6 +693,7 @@ int run_walk(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const s
     w.m = q.len[j.q]; w.nw = j.nw;
     w.start_i = starts[k].first; w.start_jl = starts[k].second;
     w.exact_lo = exact_lo[k];
+    w.need_slope = need_slope;
     w.col_offset = j.col_offset;
     w.cons_x = ctx->cons.as<char>() + coff[k];
     w.cons_y = w.cons_x + cap;
@@ -802,10 +817,67 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
   return 0;
 }
 
+// Rows per lane of the strip kernel instance for a query of `na` rows (<= 8 wavefronts x 64 lanes x R rows),
+// and the wavefronts it occupies.
+constexpr int kStripMaxRows = 64 * kStripMaxWaves * 16;
+int strip_R(int na) { return na <= 64 * kStripMaxWaves * 10 ? 10 : 16; }
+int strip_waves(int na, int R) { return std::max(1, (na + 64 * R - 1) / (64 * R)); }
+size_t strip_dirs_bytes(int64_t nb, int nw, int R) { return (size_t)nb * 64 * (size_t)nw * (size_t)((R + 15) / 16) * 4 + 64; }
+
+// Decisions of long queries (ORIENT 0 windows) by the pipelined strip kernel: one workgroup per job.
+int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg, const mi355_sw_params &p,
+              std::vector<WaveJob> &jobs, int R) {
+  HostTrace trace_("run_strip");
+  const size_t n = jobs.size();
+  if (n == 0) return 0;
+  size_t dirs_total = 0;
+  int nwmax = 1;
+  for (WaveJob &j : jobs) {
+    const int nw = strip_waves(q.len[j.q], R);
+    if (nw > kStripMaxWaves) return fail(ctx, MI355_SW_EINVAL, "internal: strip kernel query too long");
+    nwmax = std::max(nwmax, nw);
+    j.dirs_off = dirs_total;
+    dirs_total += strip_dirs_bytes(j.nb, nw, R);
+  }
+  if (ctx->wprobs.ensure(n * sizeof(StripProblem)) || ctx->outs_i.ensure(n * 16) || ctx->dirs.ensure(dirs_total))
+    return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(strip scratch) failed");
+  std::vector<StripProblem> pr(n);
+  for (size_t k = 0; k < n; ++k) {
+    const WaveJob &j = jobs[k];
+    StripProblem &s = pr[k];
+    s.a = q.bytes.as<uint8_t>() + q.off[j.q];
+    s.na = q.len[j.q];
+    s.b = ref.bytes.as<uint8_t>() + rg.lo + j.s_lo;
+    s.nb = j.nb;
+    s.nw = strip_waves(q.len[j.q], R);
+    s.dirs = reinterpret_cast<uint32_t *>(ctx->dirs.as<uint8_t>() + j.dirs_off);
+    s.status = ctx->outs_i.as<int32_t>() + k;
+  }
+  HIPCHK(ctx, hipMemsetAsync(ctx->outs_i.p, 0, n * 4, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->wprobs.p, pr.data(), n * sizeof(StripProblem), hipMemcpyHostToDevice, ctx->stream));
+  WaveScoring sc;
+  sc.match = p.match; sc.mismatch = p.mismatch; sc.gap = p.gap;
+  const U8Params u = u8_params(p);
+  sc.u8M = (float)u.M; sc.u8X = (float)u.X; sc.u8G = (float)u.G;
+  const bool u8 = p.semantics == MI355_SW_U8SAT;
+  const StripProblem *dp = ctx->wprobs.as<StripProblem>();
+  const dim3 grid((unsigned)n), block((unsigned)(64 * nwmax));
+  if (R == 10) { if (u8) hipLaunchKernelGGL((sw_strip_kernel<10, true>), grid, block, 0, ctx->stream, dp, sc); else hipLaunchKernelGGL((sw_strip_kernel<10, false>), grid, block, 0, ctx->stream, dp, sc); }
+  else { if (u8) hipLaunchKernelGGL((sw_strip_kernel<16, true>), grid, block, 0, ctx->stream, dp, sc); else hipLaunchKernelGGL((sw_strip_kernel<16, false>), grid, block, 0, ctx->stream, dp, sc); }
+  HIPCHK(ctx, hipGetLastError());
+  std::vector<int32_t> st(n);
+  HIPCHK(ctx, hipMemcpyAsync(st.data(), ctx->outs_i.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t k = 0; k < n; ++k)
+    if (st[k] != 0) return fail(ctx, MI355_SW_ENODEV, "internal: strip pipeline wait expired");
+  return 0;
+}
+
 // Traceback of located alignments with the wave kernel: decisions over a window that ends at the argmax along
 // the streamed side, grown on demand; then the greedy walk.  orient as WaveJob.
 int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg, const mi355_sw_params &p,
-               int orient, const std::vector<int> &qidx, const std::vector<Located> &loc, std::vector<TraceOut> &tout) {
+               int orient, const std::vector<int> &qidx, const std::vector<Located> &loc, std::vector<TraceOut> &tout,
+               bool strips = false /* long queries: pipelined strip kernel (orient 0 only) */) {
   HostTrace trace_("wave_trace");
   const int64_t nref = rg.hi - rg.lo;
   tout.assign(qidx.size(), TraceOut());
@@ -816,10 +888,15 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
   double smax, g;
   if (p.semantics == MI355_SW_U8SAT) { const U8Params u = u8_params(p); smax = u.M; g = u.G; }
   else { smax = p.match; g = p.gap; }
+  // ... and a cell whose lane-side index is a (its path is confined to a rows / columns) is exact a + ceil(a*smax/g)
+  // positions into the window: the window needs that margin at the argmax plus room for the walk's excursions
+  // along the stream; the walk kernel checks every cell it visits
+  const float slope = g > 0 ? (float)(smax / g) : 0.0f;
+  auto lane_need = [&](int64_t a) { return a + (int64_t)std::ceil((double)a * (double)slope) + 2; };
   std::vector<int64_t> budget(qidx.size()), warm(qidx.size());
   for (size_t k : todo) {
     const int64_t na = orient == 0 ? q.len[qidx[k]] : nref;
-    budget[k] = 2 * na + 64;
+    budget[k] = na / 8 + 64;
     warm[k] = g > 0 ? na + (int64_t)std::ceil(smax * (double)na / g) : (int64_t)1 << 40;
   }
   while (!todo.empty()) {
@@ -834,10 +911,11 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         const int qi = qidx[k];
         const int64_t na = orient == 0 ? q.len[qi] : nref;
         const int64_t s_end = orient == 0 ? loc[k].iy : loc[k].ix;   // 1-based stream index of the argmax
-        const int64_t wl = std::max<int64_t>(0, s_end - (budget[k] + warm[k]));
+        const int64_t a_end = orient == 0 ? loc[k].ix : loc[k].iy;   // lane-side index of the argmax
+        const int64_t wl = std::max<int64_t>(0, s_end - (budget[k] + std::min(warm[k], lane_need(a_end))));
         const int64_t nb = s_end - wl;
-        const size_t need = wave_dirs_bytes(nb, 32);               // upper bound whatever instance the group gets
-        (void)na;
+        const size_t need = strips ? strip_dirs_bytes(nb, strip_waves((int)na, 10), 10)
+                                   : wave_dirs_bytes(nb, 32);      // upper bound whatever instance the group gets
         if (need > kDirsBudget) return fail(ctx, MI355_SW_ENOTSUP, "traceback window exceeds the device scratch budget");
         if (!jobs.empty() && bytes + need > kDirsBudget) break;
         WaveJob j;
@@ -846,11 +924,11 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         bytes += need;
         ++pos;
       }
-      int rc = run_wave(ctx, ref, q, rg, p, jobs);
-      if (rc) return rc;
       int gmax = 0;
       for (const WaveJob &j : jobs) gmax = std::max(gmax, orient == 0 ? q.len[j.q] : (int)nref);
-      const int groupR = wave_R(gmax);                              // the instance run_wave picked for this group
+      const int groupR = strips ? strip_R(gmax) : wave_R(gmax);     // the instance this group runs on
+      int rc = strips ? run_strip(ctx, ref, q, rg, p, jobs, groupR) : run_wave(ctx, ref, q, rg, p, jobs);
+      if (rc) return rc;
       // walk: measure, lay out, write (only the bytes that exist are copied back)
       const size_t n = jobs.size();
       std::vector<WaveWalk> wp(n);
@@ -870,6 +948,8 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         w.nb = j.nb;
         w.orient = orient;
         w.R = groupR;
+        w.lanes = strips ? 64 * strip_waves(na, groupR) : 16;
+        w.need_slope = slope;
         w.b_offset = j.s_lo;
         w.start_i = loc[k].ix; w.start_j = loc[k].iy;
         w.exact_from = j.s_lo == 0 ? 0 : j.s_lo + warm[k];
@@ -928,9 +1008,14 @@ void set_result(mi355_sw_result &r, float score, int64_t ix, int64_t iy, const T
 
 // Traceback for located alignments of one range: windows left of the argmax, grown on demand.
 int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
-                  const mi355_sw_params &p, const std::vector<int64_t> &qwarm,
+                  const mi355_sw_params &p, const std::vector<int64_t> &qwarm, const ScoreTable &table,
                   const std::vector<int> &qidx, const std::vector<Located> &loc, std::vector<TraceOut> &tout) {
   tout.assign(qidx.size(), TraceOut());
+  // A cell in row i is exact once it lies i + ceil(i * smax / g) columns into a window (the bound of DESIGN.md
+  // §3.3 for a path that can only use rows 1..i), so the window needs that margin at the argmax row plus room
+  // for the horizontal excursions of the walk; the walk kernel checks every cell it visits against the bound.
+  const float slope = table.gapf > 0 ? table.smaxf / table.gapf : 0.0f;
+  auto row_need = [&](int64_t i) { return i + (int64_t)std::ceil((double)i * (double)slope) + 2; };
   std::vector<size_t> todo;
   // short reads with identity scoring: decisions by the register-wavefront kernel (lanes = rows of x)
   if (wave_scoring_ok(p) && std::getenv("MI355_SW_NO_WAVE") == nullptr) {
@@ -945,12 +1030,26 @@ int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, co
       if (rc) return rc;
       for (size_t t = 0; t < sub.size(); ++t) tout[owner[t]] = t2[t];
     }
-    for (size_t k = 0; k < qidx.size(); ++k) if (loc[k].score > 0 && q.len[qidx[k]] > kWaveMaxLanesSide) todo.push_back(k);
+    // long queries: the pipelined strip kernel
+    sub.clear(); sl.clear(); owner.clear();
+    const bool strip_ok = std::getenv("MI355_SW_NO_STRIP") == nullptr;
+    for (size_t k = 0; k < qidx.size(); ++k) {
+      const int len = q.len[qidx[k]];
+      if (!(loc[k].score > 0) || len <= kWaveMaxLanesSide) continue;
+      if (strip_ok && len <= kStripMaxRows) { sub.push_back(qidx[k]); sl.push_back(loc[k]); owner.push_back(k); }
+      else todo.push_back(k);
+    }
+    if (!sub.empty()) {
+      std::vector<TraceOut> t2;
+      int rc = wave_trace(ctx, ref, q, rg, p, 0, sub, sl, t2, true);
+      if (rc) return rc;
+      for (size_t t = 0; t < sub.size(); ++t) tout[owner[t]] = t2[t];
+    }
   } else {
     for (size_t k = 0; k < qidx.size(); ++k) if (loc[k].score > 0) todo.push_back(k);
   }
   std::vector<int64_t> budget(qidx.size());
-  for (size_t k : todo) budget[k] = 2 * (int64_t)q.len[qidx[k]] + 64;
+  for (size_t k : todo) budget[k] = (int64_t)q.len[qidx[k]] / 8 + 64;
   while (!todo.empty()) {
     // build jobs in memory-bounded groups
     std::vector<size_t> next;
@@ -966,7 +1065,7 @@ int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, co
         const int qi = qidx[k];
         const int64_t iy = loc[k].iy;
         const int64_t warm = qwarm[qi];
-        int64_t wl = iy - (budget[k] + warm);           // range-relative 0-based start of window
+        int64_t wl = iy - (budget[k] + row_need(loc[k].ix));   // range-relative 0-based start of window
         if (wl < 0) wl = 0;
         const int64_t nw = iy - wl;
         const size_t need = dirs_bytes(q.len[qi], nw) + 16;
@@ -987,7 +1086,7 @@ int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, co
       if (rc) return rc;
       std::vector<TraceOut> outs;
       std::vector<int> st;
-      rc = run_walk(ctx, ref, q, jobs, 0, jobs.size(), starts, exlo, outs, st);
+      rc = run_walk(ctx, ref, q, jobs, 0, jobs.size(), starts, exlo, outs, st, slope);
       if (rc) return rc;
       for (size_t t = 0; t < jobs.size(); ++t) {
         const size_t k = owner[t];
@@ -1135,21 +1234,36 @@ int exact_full(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
 int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
                 const mi355_sw_params &p, const std::vector<char> &qfast, const std::vector<int64_t> &qchunk,
                 const std::vector<int64_t> &qwarm, const std::vector<char> &qfloat, const unsigned long long *keys,
-                std::vector<Located> &loc) {
+                const ScoreTable &table, std::vector<Located> &loc) {
   HostTrace trace_("locate_fast");
   const size_t nq = q.nq;
   const int64_t n = rg.hi - rg.lo;
   std::vector<ExactJob> jobs;
+  auto key_score = [&](size_t k) {
+    float score;
+    if (qfloat[k]) { const uint32_t bits = (uint32_t)(keys[k] >> 32); memcpy(&score, &bits, 4); }
+    else score = (float)(int)(keys[k] >> 32);
+    return score;
+  };
+  // long queries are few and each re-run occupies one workgroup: cut their sub-chunk into pieces (each with its
+  // own margin) so that the idle CUs share the work
+  size_t nlong = 0;                       // workgroups the long queries' sub-chunks need before cutting
+  for (size_t k = 0; k < nq; ++k)
+    if (qfast[k] && q.len[k] > 512 && key_score(k) > 0) nlong += p.semantics == MI355_SW_U8SAT ? 5 : 1;
   for (size_t k = 0; k < nq; ++k) {
     if (!qfast[k]) continue;
     const unsigned long long key = keys[k];
-    float score;
-    if (qfloat[k]) { const uint32_t bits = (uint32_t)(key >> 32); memcpy(&score, &bits, 4); }
-    else score = (float)(int)(key >> 32);
+    const float score = key_score(k);
     if (!(score > 0)) continue;
     const int64_t chunk_len = qchunk[k];           // sub-chunk granularity of this query's bucket
     const int64_t nchunks = (n + chunk_len - 1) / chunk_len;
-    const int64_t warm = qwarm[k];
+    // only cells equal to the known maximum compete: a path that reaches `score` within |x| diagonal steps can
+    // afford fewer gap columns than the general margin allows (DESIGN.md §3.3 with the score subtracted)
+    int64_t warm = qwarm[k];
+    if (table.gapf > 0) {
+      const double spare = std::max(0.0, (double)table.smaxf * (double)q.len[k] - (double)score);
+      warm = std::min<int64_t>(warm, (int64_t)q.len[k] + (int64_t)std::ceil(spare / (double)table.gapf) + 2);
+    }
     const int64_t first = (int64_t)(0xFFFFFFFFull - (key & 0xFFFFFFFFull));
     loc[k].score = score;
     int64_t cand[5];
@@ -1168,13 +1282,19 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
     }
     for (int t = 0; t < nc; ++t) {
       // lanes lag by up to 63 columns (whole-wavefront tiles): the end of the previous sub-chunk is reported with this one
-      const int64_t own_lo = std::max<int64_t>(0, cand[t] * chunk_len - 63);   // range-relative, 0-based
-      const int64_t own_hi = std::min((cand[t] + 1) * chunk_len, n);
-      const int64_t wl = std::max<int64_t>(0, own_lo - warm);
-      ExactJob j;
-      j.q = (int)k; j.ylo = rg.lo + wl; j.nw = (int32_t)(own_hi - wl); j.col_offset = wl; j.full_n = n;
-      j.own_lo = (int32_t)(own_lo - wl + 1); j.quirk = 0; j.target = score; j.want_dirs = false;
-      jobs.push_back(j);
+      const int64_t sub_lo = std::max<int64_t>(0, cand[t] * chunk_len - 63);   // range-relative, 0-based
+      const int64_t sub_hi = std::min((cand[t] + 1) * chunk_len, n);
+      int64_t pieces = 1;
+      if (q.len[k] > 512) pieces = std::max<int64_t>(1, std::min<int64_t>((sub_hi - sub_lo) / 256, 224 / (int64_t)nlong));   // one 1024-thread workgroup per CU
+      const int64_t plen = (sub_hi - sub_lo + pieces - 1) / pieces;
+      for (int64_t own_lo = sub_lo; own_lo < sub_hi; own_lo += plen) {
+        const int64_t own_hi = std::min(own_lo + plen, sub_hi);
+        const int64_t wl = std::max<int64_t>(0, own_lo - warm);
+        ExactJob j;
+        j.q = (int)k; j.ylo = rg.lo + wl; j.nw = (int32_t)(own_hi - wl); j.col_offset = wl; j.full_n = n;
+        j.own_lo = (int32_t)(own_lo - wl + 1); j.quirk = 0; j.target = score; j.want_dirs = false;
+        jobs.push_back(j);
+      }
     }
   }
   for (size_t lo = 0; lo < jobs.size(); lo += 65536) {
@@ -1234,7 +1354,7 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
       rc = score_fetch(ctx, nq, keys);
       if (rc) return rc;
       HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-      rc = locate_fast(ctx, ref, q, rg, p, qfast, qchunk, qwarm, qfloat, keys.data(), loc);
+      rc = locate_fast(ctx, ref, q, rg, p, qfast, qchunk, qwarm, qfloat, keys.data(), table, loc);
       if (rc) return rc;
       HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
       ctx->timings[1] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
@@ -1244,7 +1364,7 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
         for (size_t k = 0; k < nq; ++k) if (qfast[k]) { fq.push_back((int)k); floc.push_back(loc[k]); }
         std::vector<TraceOut> ft;
         HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-        rc = trace_located(ctx, ref, q, rg, p, qwarm, fq, floc, ft);
+        rc = trace_located(ctx, ref, q, rg, p, qwarm, table, fq, floc, ft);
         if (rc) return rc;
         HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
         ctx->timings[2] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);

@@ -177,6 +177,8 @@ struct WalkProblem {
   int32_t m, nw;
   int32_t start_i, start_jl;
   int32_t exact_lo;       // decisions at local columns < exact_lo read inexact cells (0 = all exact)
+  float need_slope;       // > 0: row i is already exact from local column i + ceil(i * need_slope) + 2 on (a path
+                          // ending in row i has at most i diagonal steps: DESIGN.md §3.3 with m := i)
   int64_t col_offset;
   char *cons_x;           // capacity cap
   char *cons_y;
@@ -196,7 +198,14 @@ __global__ void sw_walk_kernel(const WalkProblem *probs, int n) {
   if (ix <= 0 || jl <= 0) { W.out[0] = 0; W.out[1] = 0; W.out[2] = 0; return; }
   for (;;) {
     // the decision at (ix, jl) looks at columns jl-1 and jl: both must be exact
-    if (jl - 1 < W.exact_lo && W.exact_lo > 0) { status = 1; break; }
+    if (W.exact_lo > 0) {
+      int need = W.exact_lo;
+      if (W.need_slope > 0.0f) {
+        const int rn = ix + (int)ceilf((float)ix * W.need_slope) + 2;
+        need = rn < need ? rn : need;
+      }
+      if (jl - 1 < need) { status = 1; break; }
+    }
     if (len >= W.cap) { status = 2; break; }
     const int d = ix + jl;
     const int ilo = d - W.nw > 1 ? d - W.nw : 1;

@@ -193,12 +193,15 @@ __global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, 
 struct WaveWalk {
   const uint8_t *x;        // full x
   const uint8_t *y;        // full y (of the range)
-  const uint32_t *dirs;    // [nb][16][W] as WaveProblem::dirs
+  const uint32_t *dirs;    // [nb][lanes][W] as WaveProblem::dirs (lanes = 16) or StripProblem::dirs (64 per wavefront)
   int32_t na, nb, orient;
   int32_t R;               // rows per lane of the instance that wrote dirs
+  int32_t lanes;           // lanes that share one stream position in dirs
+  float need_slope;        // > 0: a cell with lane-side index a is already exact a + ceil(a * need_slope) + 2 stream
+                           // positions into the window (DESIGN.md §3.3 for a path confined to a rows/columns)
   int64_t b_offset;        // as WaveProblem
   int64_t start_i, start_j;  // true 1-based start cell (row of x, column of y)
-  int64_t exact_from;      // stream index (true, 1-based) from which cells are exact; 0 = all
+  int64_t exact_from;      // stream index (true, 1-based) from which every cell is exact; 0 = all
   int32_t cap;             // longest consensus the caller accepts
   int64_t *out;            // [0] length, [1] pos, [2] status (0 ok, 1 window too small, 2 capacity)
 };
@@ -227,11 +230,18 @@ __global__ void sw_wave_walk_kernel(const WaveWalk *probs, int n, char *cons, co
     const long long t = sidx - W.b_offset - 1;
     // the decision at (ix, iy) reads cells one step back along the stream: they must be exact and inside the window
     if (t < 0 || t >= W.nb || aidx > W.na) { status = 1; break; }
-    if (W.exact_from > 0 && sidx - 1 < W.exact_from) { status = 1; break; }
+    if (W.exact_from > 0) {
+      long long need = W.exact_from;
+      if (W.need_slope > 0.0f) {
+        const long long rn = W.b_offset + aidx + (long long)ceilf((float)aidx * W.need_slope) + 2;
+        need = rn < need ? rn : need;
+      }
+      if (sidx - 1 < need) { status = 1; break; }
+    }
     if (len >= W.cap) { status = 2; break; }
     const int lane = (int)((aidx - 1) / W.R), r = (int)((aidx - 1) % W.R);
     const int wd = (W.R + 15) / 16;
-    const int dir = (int)((W.dirs[((size_t)t * 16 + (size_t)lane) * wd + (r >> 4)] >> (2 * (r & 15))) & 3u);
+    const int dir = (int)((W.dirs[((size_t)t * (size_t)W.lanes + (size_t)lane) * wd + (r >> 4)] >> (2 * (r & 15))) & 3u);
     if (dir == kDirStop) {
       if (WRITE) { cons_x[len] = (char)W.x[ix - 1]; cons_y[len] = (char)W.y[iy - 1]; }
       ++len;
