@@ -32,7 +32,7 @@ namespace {
 
 constexpr size_t kProfileLdsMax = 120 * 1024;  // LDS budget of the query profile (ncodes x 16 lanes x stride x 4 B)
 constexpr int kMaxRowsFast = 512;             // 16 lanes x R <= 32 rows in one strip; longer queries are strip-mined
-constexpr size_t kDirsBudget = 3ull << 30;    // bytes of traceback decisions per exact launch
+constexpr size_t kDirsBudget = 16ull << 30;    // bytes of traceback decisions per exact launch
 constexpr size_t kExactLdsMax = 159 * 1024;    // dynamic part; the wide instance adds < 1 KiB of static LDS
 
 // MI355_SW_TRACE=1: wall-clock of the host-side phases of every call on stderr (diagnostic)
@@ -742,6 +742,8 @@ struct WaveJob {
   int64_t s_lo;           // stream window start (0-based, range-relative), nb positions
   int32_t nb;
   bool track, dirs;
+  float target = 0;       // strip kernel, track: only cells equal to target compete ...
+  int32_t own_lo = 0;     // ... at stream positions >= own_lo (0-based)
   // results
   float best = 0;
   int64_t ci = 0, cj = 0;
@@ -817,29 +819,43 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
   return 0;
 }
 
-// Rows per lane of the strip kernel instance for a query of `na` rows (<= 8 wavefronts x 64 lanes x R rows),
-// and the wavefronts it occupies.
-constexpr int kStripMaxRows = 64 * kStripMaxWaves * 16;
+// Rows per lane of the strip kernel instance for a query of `na` rows, and its strips of 64*R rows (sixteen run
+// concurrently; longer queries take several rounds).
 int strip_R(int na) { return na <= 64 * kStripMaxWaves * 10 ? 10 : 16; }
-int strip_waves(int na, int R) { return std::max(1, (na + 64 * R - 1) / (64 * R)); }
-size_t strip_dirs_bytes(int64_t nb, int nw, int R) { return (size_t)nb * 64 * (size_t)nw * (size_t)((R + 15) / 16) * 4 + 64; }
+int strip_count(int na, int R) { return std::max(1, (na + 64 * R - 1) / (64 * R)); }
+size_t strip_dirs_bytes(int64_t nb, int nstrips, int R) { return (size_t)nb * 64 * (size_t)nstrips * (size_t)((R + 15) / 16) * 4 + 64; }
 
-// Decisions of long queries (ORIENT 0 windows) by the pipelined strip kernel: one workgroup per job.
+template <int R>
+void launch_strip(bool u8, bool track, dim3 grid, dim3 block, hipStream_t st, const StripProblem *dp, const WaveScoring &sc) {
+  if (track) {
+    if (u8) hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripTrack>), grid, block, 0, st, dp, sc);
+    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripTrack>), grid, block, 0, st, dp, sc);
+  } else {
+    if (u8) hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripDirs>), grid, block, 0, st, dp, sc);
+    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripDirs>), grid, block, 0, st, dp, sc);
+  }
+}
+
+// Long queries (ORIENT 0 windows) on the pipelined strip kernel, one workgroup per job: traceback decisions
+// (jobs[.].dirs) or the first cell equal to jobs[.].target in storage order (jobs[.].track -> ci, cj; ci = 0: none).
 int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg, const mi355_sw_params &p,
               std::vector<WaveJob> &jobs, int R) {
   HostTrace trace_("run_strip");
   const size_t n = jobs.size();
   if (n == 0) return 0;
-  size_t dirs_total = 0;
+  const bool track = jobs[0].track;
+  size_t dirs_total = 0, gtotal = 0;
   int nwmax = 1;
-  for (WaveJob &j : jobs) {
-    const int nw = strip_waves(q.len[j.q], R);
-    if (nw > kStripMaxWaves) return fail(ctx, MI355_SW_EINVAL, "internal: strip kernel query too long");
-    nwmax = std::max(nwmax, nw);
-    j.dirs_off = dirs_total;
-    dirs_total += strip_dirs_bytes(j.nb, nw, R);
+  std::vector<size_t> goff(n, 0);
+  for (size_t k = 0; k < n; ++k) {
+    WaveJob &j = jobs[k];
+    const int ns = strip_count(q.len[j.q], R);
+    nwmax = std::max(nwmax, std::min(ns, kStripMaxWaves));
+    if (!track) { j.dirs_off = dirs_total; dirs_total += strip_dirs_bytes(j.nb, ns, R); }
+    if (ns > kStripMaxWaves) { goff[k] = gtotal; gtotal += 2 * ((size_t)j.nb + 192); }
   }
-  if (ctx->wprobs.ensure(n * sizeof(StripProblem)) || ctx->outs_i.ensure(n * 16) || ctx->dirs.ensure(dirs_total))
+  if (ctx->wprobs.ensure(n * sizeof(StripProblem)) || ctx->outs_i.ensure(n * 16) || ctx->outs_f.ensure(n * 4) ||
+      (dirs_total && ctx->dirs.ensure(dirs_total)) || (gtotal && ctx->brow.ensure(gtotal * 4)))
     return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(strip scratch) failed");
   std::vector<StripProblem> pr(n);
   for (size_t k = 0; k < n; ++k) {
@@ -849,11 +865,19 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
     s.na = q.len[j.q];
     s.b = ref.bytes.as<uint8_t>() + rg.lo + j.s_lo;
     s.nb = j.nb;
-    s.nw = strip_waves(q.len[j.q], R);
-    s.dirs = reinterpret_cast<uint32_t *>(ctx->dirs.as<uint8_t>() + j.dirs_off);
-    s.status = ctx->outs_i.as<int32_t>() + k;
+    s.nstrips = strip_count(q.len[j.q], R);
+    s.nw = std::min(s.nstrips, kStripMaxWaves);
+    s.gbound = s.nstrips > kStripMaxWaves ? ctx->brow.as<float>() + goff[k] : nullptr;
+    s.gstride = (int64_t)j.nb + 192;
+    s.dirs = track ? nullptr : reinterpret_cast<uint32_t *>(ctx->dirs.as<uint8_t>() + j.dirs_off);
+    s.target = j.target;
+    s.own_lo = j.own_lo;
+    s.col_offset = j.s_lo;
+    s.full_n = rg.hi - rg.lo;
+    s.cell = ctx->outs_i.as<int64_t>() + 2 * k;
+    s.status = ctx->outs_f.as<int32_t>() + k;
   }
-  HIPCHK(ctx, hipMemsetAsync(ctx->outs_i.p, 0, n * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->outs_f.p, 0, n * 4, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ctx->wprobs.p, pr.data(), n * sizeof(StripProblem), hipMemcpyHostToDevice, ctx->stream));
   WaveScoring sc;
   sc.match = p.match; sc.mismatch = p.mismatch; sc.gap = p.gap;
@@ -862,14 +886,18 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   const bool u8 = p.semantics == MI355_SW_U8SAT;
   const StripProblem *dp = ctx->wprobs.as<StripProblem>();
   const dim3 grid((unsigned)n), block((unsigned)(64 * nwmax));
-  if (R == 10) { if (u8) hipLaunchKernelGGL((sw_strip_kernel<10, true>), grid, block, 0, ctx->stream, dp, sc); else hipLaunchKernelGGL((sw_strip_kernel<10, false>), grid, block, 0, ctx->stream, dp, sc); }
-  else { if (u8) hipLaunchKernelGGL((sw_strip_kernel<16, true>), grid, block, 0, ctx->stream, dp, sc); else hipLaunchKernelGGL((sw_strip_kernel<16, false>), grid, block, 0, ctx->stream, dp, sc); }
+  if (R == 10) launch_strip<10>(u8, track, grid, block, ctx->stream, dp, sc);
+  else launch_strip<16>(u8, track, grid, block, ctx->stream, dp, sc);
   HIPCHK(ctx, hipGetLastError());
   std::vector<int32_t> st(n);
-  HIPCHK(ctx, hipMemcpyAsync(st.data(), ctx->outs_i.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<int64_t> ci(2 * n);
+  HIPCHK(ctx, hipMemcpyAsync(st.data(), ctx->outs_f.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (track) HIPCHK(ctx, hipMemcpyAsync(ci.data(), ctx->outs_i.p, n * 16, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  for (size_t k = 0; k < n; ++k)
+  for (size_t k = 0; k < n; ++k) {
     if (st[k] != 0) return fail(ctx, MI355_SW_ENODEV, "internal: strip pipeline wait expired");
+    if (track) { jobs[k].ci = ci[2 * k]; jobs[k].cj = ci[2 * k + 1]; jobs[k].best = ci[2 * k] > 0 ? jobs[k].target : -1.0f; }
+  }
   return 0;
 }
 
@@ -914,7 +942,7 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         const int64_t a_end = orient == 0 ? loc[k].ix : loc[k].iy;   // lane-side index of the argmax
         const int64_t wl = std::max<int64_t>(0, s_end - (budget[k] + std::min(warm[k], lane_need(a_end))));
         const int64_t nb = s_end - wl;
-        const size_t need = strips ? strip_dirs_bytes(nb, strip_waves((int)na, 10), 10)
+        const size_t need = strips ? strip_dirs_bytes(nb, strip_count((int)na, 10), 10)
                                    : wave_dirs_bytes(nb, 32);      // upper bound whatever instance the group gets
         if (need > kDirsBudget) return fail(ctx, MI355_SW_ENOTSUP, "traceback window exceeds the device scratch budget");
         if (!jobs.empty() && bytes + need > kDirsBudget) break;
@@ -948,7 +976,7 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         w.nb = j.nb;
         w.orient = orient;
         w.R = groupR;
-        w.lanes = strips ? 64 * strip_waves(na, groupR) : 16;
+        w.lanes = strips ? 64 * strip_count(na, groupR) : 16;
         w.need_slope = slope;
         w.b_offset = j.s_lo;
         w.start_i = loc[k].ix; w.start_j = loc[k].iy;
@@ -1036,7 +1064,7 @@ int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, co
     for (size_t k = 0; k < qidx.size(); ++k) {
       const int len = q.len[qidx[k]];
       if (!(loc[k].score > 0) || len <= kWaveMaxLanesSide) continue;
-      if (strip_ok && len <= kStripMaxRows) { sub.push_back(qidx[k]); sl.push_back(loc[k]); owner.push_back(k); }
+      if (strip_ok) { sub.push_back(qidx[k]); sl.push_back(loc[k]); owner.push_back(k); }
       else todo.push_back(k);
     }
     if (!sub.empty()) {
@@ -1239,6 +1267,8 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
   const size_t nq = q.nq;
   const int64_t n = rg.hi - rg.lo;
   std::vector<ExactJob> jobs;
+  std::vector<WaveJob> sjobs;                  // long queries with identity scoring: pipelined strip kernel
+  const bool strip_ok = wave_scoring_ok(p) && std::getenv("MI355_SW_NO_STRIP") == nullptr;
   auto key_score = [&](size_t k) {
     float score;
     if (qfloat[k]) { const uint32_t bits = (uint32_t)(keys[k] >> 32); memcpy(&score, &bits, 4); }
@@ -1290,6 +1320,13 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
       for (int64_t own_lo = sub_lo; own_lo < sub_hi; own_lo += plen) {
         const int64_t own_hi = std::min(own_lo + plen, sub_hi);
         const int64_t wl = std::max<int64_t>(0, own_lo - warm);
+        if (strip_ok && q.len[k] > kWaveMaxLanesSide) {
+          WaveJob sj;
+          sj.q = (int)k; sj.orient = 0; sj.s_lo = wl; sj.nb = (int32_t)(own_hi - wl); sj.track = true; sj.dirs = false;
+          sj.target = score; sj.own_lo = (int32_t)(own_lo - wl);
+          sjobs.push_back(sj);
+          continue;
+        }
         ExactJob j;
         j.q = (int)k; j.ylo = rg.lo + wl; j.nw = (int32_t)(own_hi - wl); j.col_offset = wl; j.full_n = n;
         j.own_lo = (int32_t)(own_lo - wl + 1); j.quirk = 0; j.target = score; j.want_dirs = false;
@@ -1306,6 +1343,23 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
     if (j.best != j.target) continue;
     const unsigned long long kk = host_order_key(p.semantics, j.ci, j.cj, q.len[j.q], n);
     if (kk < bestkey[j.q]) { bestkey[j.q] = kk; loc[j.q].ix = j.ci; loc[j.q].iy = j.cj; }
+  }
+  if (!sjobs.empty()) {
+    // one launch per kernel instance (rows per lane)
+    for (int R : {10, 16}) {
+      std::vector<WaveJob> group;
+      for (const WaveJob &j : sjobs) if (strip_R(q.len[j.q]) == R) group.push_back(j);
+      for (size_t lo = 0; lo < group.size(); lo += 4096) {
+        std::vector<WaveJob> part(group.begin() + lo, group.begin() + std::min(group.size(), lo + 4096));
+        int rc = run_strip(ctx, ref, q, rg, p, part, R);
+        if (rc) return rc;
+        for (const WaveJob &j : part) {
+          if (j.ci <= 0) continue;
+          const unsigned long long kk = host_order_key(p.semantics, j.ci, j.cj, q.len[j.q], n);
+          if (kk < bestkey[j.q]) { bestkey[j.q] = kk; loc[j.q].ix = j.ci; loc[j.q].iy = j.cj; }
+        }
+      }
+    }
   }
   for (size_t k = 0; k < nq; ++k)
     if (qfast[k] && loc[k].score > 0 && bestkey[k] == ~0ull)

@@ -1,28 +1,33 @@
-// sw_strip_kernel.h — traceback decisions for ONE LONG query: the wavefronts of a workgroup form a pipeline.
+// sw_strip_kernel.h — exact sweep of ONE LONG query over a window: the wavefronts of a workgroup form a pipeline.
 //
 // The register wavefront of sw_wave_kernel.h (ORIENT 0: lanes hold rows of x, the stream runs over a window of
-// y) with whole-wavefront strips: wavefront w of the workgroup owns rows [w*64*R, (w+1)*64*R) of x — lane l its
-// R consecutive rows — and sweeps the window one column per step.  The bottom row of strip w enters strip w+1
-// through an LDS ring (lane 63 stores one value per step, lane 0 of the next wavefront picks it up through the
-// DPP `old` operand, where the single-strip kernels get the zero border row), so the strips run concurrently,
-// each two 64-column segments behind the one above it.  This is the multi-wavefront cooperative sweep of one
-// alignment (what the reference's fine-grained OpenMP variants attempt, similaritymatrix.cpp:118-245), kept
-// inside one workgroup so that all participants are resident by construction.
+// y) with whole-wavefront strips: strip s owns rows [s*64*R, (s+1)*64*R) of x — lane l its R consecutive rows —
+// and sweeps the window one column per step.  Wavefront w of the workgroup runs strips w, w + nw, w + 2*nw, ...
+// (one per round).  The bottom row of a strip enters the next strip through an LDS ring (lane 63 stores one
+// value per step, lane 0 of the next wavefront picks it up through the DPP `old` operand, where the single-strip
+// kernels get the zero border row), so the strips of a round run concurrently, each two 64-column segments
+// behind the one above it; the last wavefront of a round hands its bottom row to wavefront 0 of the next round
+// through a global scratch row.  This is the multi-wavefront cooperative sweep of one alignment (what the
+// reference's fine-grained OpenMP variants attempt, similaritymatrix.cpp:118-245), kept inside one workgroup so
+// that all participants are resident by construction.
 //
-// Flow control: per strip a count of produced and of consumed boundary positions, published with release
-// stores once per segment and polled with acquire loads; a strip waits for input (positions of the coming
-// segment) and for ring space (the strip below must have consumed what is about to be overwritten).  The waits
-// cannot form a cycle (a producer blocks only when >= kStripRing-64 positions ahead, a consumer only when < 128
-// behind), every wavefront runs the same number of segments, and every wait is bounded: on expiry the workgroup
-// raises `status` and drains.
+// Flow control: per wavefront a count of produced and of consumed boundary positions (monotonic over rounds),
+// published with release stores once per segment and polled with acquire loads; a strip waits for input
+// (positions of the coming segment) and for ring space (the strip below must have consumed what is about to be
+// overwritten).  The waits cannot form a cycle (a producer blocks only when >= kStripRing-64 positions ahead, a
+// consumer only when < 128 behind), every wavefront runs the same number of segments per round, and every wait
+// is bounded: on expiry the workgroup raises `status` and drains.
 //
-// Output: one greedy traceback decision per cell (smithwaterman.cpp:51-72), 2 bits, laid out
-// dirs[stream position][lane of the workgroup][W] dwords (W = 1 for R <= 16, else 2), the layout of
-// sw_wave_kernel.h with 64*nw lanes instead of 16; sw_wave_walk_kernel reads both.
+// MODE kStripDirs : one greedy traceback decision per cell (smithwaterman.cpp:51-72), 2 bits, laid out
+//                   dirs[stream position][64 * strip + lane][W] dwords (W = 1 for R <= 16) — the layout of
+//                   sw_wave_kernel.h with 64*nstrips lanes instead of 16; sw_wave_walk_kernel reads both.
+// MODE kStripTrack: the first cell in the engine's storage order (order_key<>, sw_exact_kernel.h) among the cells
+//                   equal to `target` at stream positions >= own_lo (the locate step of DESIGN.md §4).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "sw_exact_kernel.h"  // order_key
 #include "sw_wave_kernel.h"   // WaveScoring, kDir*
 
 namespace mi355sw {
@@ -31,21 +36,33 @@ struct StripProblem {
   const uint8_t *a;      // x (rows)
   const uint8_t *b;      // window of y: stream position t is b[t]
   int32_t na, nb;
-  int32_t nw;            // wavefronts that hold rows (ceil(na / (64*R))), <= blockDim.x / 64
-  uint32_t *dirs;        // [nb][64*nw][W]
+  int32_t nstrips;       // ceil(na / (64*R))
+  int32_t nw;            // wavefronts that take part: min(nstrips, blockDim.x / 64)
+  float *gbound;         // 2 x gstride floats: bottom rows that cross rounds (null when nstrips <= nw)
+  int64_t gstride;
+  uint32_t *dirs;        // kStripDirs: [nb][64*nstrips][W]
+  // kStripTrack
+  float target;
+  int32_t own_lo;        // first stream position (0-based) that competes
+  int64_t col_offset;    // true column of stream position t = col_offset + t + 1
+  int64_t full_n;        // |y| of the full problem (uint8 storage order)
+  int64_t *cell;         // [2] row, true column of the first cell equal to target; row 0 when none
   int32_t *status;       // 0 = complete, 1 = a pipeline wait expired (result unusable)
 };
 
+enum : int { kStripDirs = 0, kStripTrack = 1 };
 constexpr int kStripRing = 512;          // boundary positions held per strip (8 segments)
 constexpr int kStripMaxWaves = 16;
 constexpr int kStripSpinLimit = 1 << 22; // polls (with s_sleep) before a wait is declared dead
 
-template <int R, bool U8>
+template <int R, bool U8, int MODE>
 __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const StripProblem *probs, const WaveScoring sc) {
-  __shared__ float ring[kStripMaxWaves][kStripRing];
-  __shared__ int produced[kStripMaxWaves], consumed[kStripMaxWaves + 1];
+  __shared__ float ring[kStripMaxWaves + 1][kStripRing];            // [w] = output of wavefront w; [kStripMaxWaves] = round input of wavefront 0
+  __shared__ long long produced[kStripMaxWaves], consumed[kStripMaxWaves + 1];
   __shared__ int dead;
   __shared__ __attribute__((aligned(16))) uint8_t win[kStripMaxWaves][128];
+  __shared__ unsigned long long wkey[kStripMaxWaves];
+  __shared__ long long wi[kStripMaxWaves], wj[kStripMaxWaves];
   const StripProblem P = probs[blockIdx.x];
   const int tid = threadIdx.x;
   const int w = tid >> 6, l = tid & 63;
@@ -54,42 +71,20 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
   if (tid == 0) dead = 0;
   __syncthreads();
   const int nw = P.nw;
-  if (w >= nw) return;                                   // spare wavefronts of a launch shared with longer queries
   const int na = P.na, nb = P.nb;
-  const int LT = 64 * nw;
+  const int nstrips = P.nstrips;
+  const int LT = 64 * nstrips;
   constexpr int W = (R + 15) / 16;
-
-  uint32_t ca[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int ai = (w * 64 + l) * R + r;
-    ca[r] = (ai < na) ? (uint32_t)P.a[ai] : 0xFFFFu;    // padding rows never match
-  }
-
-  // stream window of this wavefront: 64 B of history, then the current 64-column segment
-  uint8_t *buf = win[w];
-  const uint8_t *buf_lane = buf + 64 - l;                // + k = byte of stream position seg*64 + k - l
-  auto stage_load = [&](int seg) -> uint32_t {
-    const int t = seg * 64 + l;
-    return (t < nb) ? (uint32_t)P.b[t] : 0u;
-  };
   const int nseg = (nb + 64 + 63) / 64;                  // lane 63 reaches stream position nb - 1
-  uint32_t nextc = stage_load(0);
-  buf[l] = 0;
-  buf[64 + l] = (uint8_t)nextc;
-  nextc = stage_load(1);
-
-  float H[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) H[r] = 0.0f;
-  uint32_t up_prev = 0;
+  const long long NBP = (long long)nseg * 64;            // counter units per round
+  const int rounds = (nstrips + nw - 1) / nw;
   const float gpen = U8 ? sc.u8G : sc.gap;
-  const float *rin = ring[w > 0 ? w - 1 : 0];
-  float *rout = ring[w];
-  const bool has_in = w > 0, has_out = w + 1 < nw;
   bool ok = true;
 
-  auto wait_for = [&](int *counter, int need) {
+  unsigned long long bkey = ~0ull;                       // kStripTrack: this lane's first competing cell
+  long long bi = 0, bj = 0;
+
+  auto wait_for = [&](long long *counter, long long need) {
     int spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
       if (__hip_atomic_load(&dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 || ++spins > kStripSpinLimit) {
@@ -101,71 +96,162 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
     }
   };
 
-  for (int seg = 0; seg < nseg && ok; ++seg) {
-    // input: boundary positions seg*64 .. seg*64+63 (the strip above finishes them during ITS segment seg+1)
-    if (has_in) {
-      const int need = (seg + 1) * 64 < nb ? (seg + 1) * 64 : nb;
-      wait_for(&produced[w - 1], need);
-    }
-    // ring space: this segment stores positions <= seg*64, over the slots of positions <= seg*64 - kStripRing
-    if (has_out) wait_for(&consumed[w + 1], seg * 64 - kStripRing + 64);
-    if (!ok) break;
-#pragma unroll 2
-    for (int k = 0; k < 64; ++k) {
-      const int t0 = seg * 64 + k;                                     // lane 0's stream position
-      const int t = t0 - l;
-      const uint32_t cb = (uint32_t)buf_lane[k] | ((uint32_t)t >= (uint32_t)nb ? 0x100u : 0u);
-      const float bnd = has_in ? rin[t0 & (kStripRing - 1)] : 0.0f;    // H(first row of the strip - 1, column t0)
-      const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(bnd), (int)__float_as_uint(H[R - 1]),
-                                                                0x138 /*wave_shr:1*/, 0xf, 0xf, false);
-      float diag = __uint_as_float(up_prev);
-      float north = __uint_as_float(up);
-      up_prev = up;
-      uint32_t dpack[W];
+  uint8_t *buf = win[w < kStripMaxWaves ? w : 0];
+  const uint8_t *buf_lane = buf + 64 - l;                // + k = byte of stream position seg*64 + k - l
+  auto stage_load = [&](int seg) -> uint32_t {
+    const int t = seg * 64 + l;
+    return (t < nb) ? (uint32_t)P.b[t] : 0u;
+  };
+
+  for (int round = 0; round < rounds && ok && w < nw; ++round) {
+    const int s = round * nw + w;                        // this wavefront's strip in this round
+    if (s >= nstrips) break;
+    const long long base = (long long)round * NBP;
+    const bool has_in = s > 0, has_out = s + 1 < nstrips;
+    const bool in_global = has_in && w == 0;             // from the last wavefront of the previous round
+    const bool out_global = has_out && w == nw - 1;      // to wavefront 0 of the next round
+    const float *rin = ring[in_global ? kStripMaxWaves : (w > 0 ? w - 1 : 0)];
+    float *rstage = ring[kStripMaxWaves];
+    float *rout = ring[w];
+    const float *gin = in_global ? P.gbound + (size_t)((round + 1) & 1) * (size_t)P.gstride : nullptr;
+    float *gout = out_global ? P.gbound + (size_t)(round & 1) * (size_t)P.gstride : nullptr;
+
+    uint32_t ca[R];
 #pragma unroll
-      for (int d = 0; d < W; ++d) dpack[d] = 0;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float wv = H[r];
-        const bool eq = ca[r] == cb;
-        float x;
-        if (U8) x = eq ? fminf(diag + sc.u8M, 255.0f) : fmaxf(diag - sc.u8X, 0.0f);
-        else x = diag + (eq ? sc.match : sc.mismatch);
-        const float y = fmaxf(wv, north) - gpen;
-        const float h = fmaxf(fmaxf(x, y), 0.0f);
-        // smithwaterman.cpp:51,59,66,72 at this cell: n1 = NW, n2 = W, n3 = N
-        int dir;
-        if (diag == 0.0f || wv == 0.0f || north == 0.0f) dir = kDirStop;
-        else if (diag >= wv && diag >= north) dir = kDirNW;
-        else if (wv >= diag && wv >= north) dir = kDirW;
-        else dir = kDirN;
-        dpack[r >> 4] |= (uint32_t)dir << (2 * (r & 15));
-        diag = wv;
-        H[r] = h;
-        north = h;
-      }
-      if (has_out && l == 63 && t >= 0) rout[t & (kStripRing - 1)] = H[R - 1];
-      if (t >= 0 && t < nb) {
-        uint32_t *dst = P.dirs + ((size_t)t * LT + (size_t)(w * 64 + l)) * W;
-#pragma unroll
-        for (int d = 0; d < W; ++d) dst[d] = dpack[d];
-      }
+    for (int r = 0; r < R; ++r) {
+      const int ai = (s * 64 + l) * R + r;
+      ca[r] = (ai < na) ? (uint32_t)P.a[ai] : 0xFFFFu;  // padding rows never match
     }
-    // lane 63 has stored positions <= seg*64; this wavefront has read positions <= seg*64 + 63
-    if (l == 0) {
-      if (has_out) __hip_atomic_store(&produced[w], seg * 64 + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_store(&consumed[w], (seg + 1) * 64, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    const uint8_t hist = buf[64 + l];
-    buf[l] = hist;
+    // stream window of this wavefront: 64 B of history, then the current 64-column segment
+    uint32_t nextc = stage_load(0);
+    buf[l] = 0;
     buf[64 + l] = (uint8_t)nextc;
-    nextc = stage_load(seg + 2);
+    nextc = stage_load(1);
+
+    float H[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) H[r] = 0.0f;
+    uint32_t up_prev = 0;
+
+    for (int seg = 0; seg < nseg && ok; ++seg) {
+      // input: boundary positions seg*64 .. seg*64+63 (the strip above finishes them during ITS segment seg+1)
+      if (has_in) {
+        const long long need = (seg + 1) * 64 < nb ? (seg + 1) * 64 : nb;
+        if (in_global) {
+          wait_for(&produced[nw - 1], base - NBP + need);
+          if (ok) { const int t = seg * 64 + l; rstage[t & (kStripRing - 1)] = t < nb ? __hip_atomic_load(gin + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f; }
+        } else {
+          wait_for(&produced[w - 1], base + need);
+        }
+      }
+      // ring space: this segment stores positions <= seg*64, over the slots of positions <= seg*64 - kStripRing
+      if (has_out && !out_global) wait_for(&consumed[w + 1], base + seg * 64 - kStripRing + 64);
+      if (!ok) break;
+#pragma unroll 2
+      for (int k = 0; k < 64; ++k) {
+        const int t0 = seg * 64 + k;                                     // lane 0's stream position
+        const int t = t0 - l;
+        const uint32_t cb = (uint32_t)buf_lane[k] | ((uint32_t)t >= (uint32_t)nb ? 0x100u : 0u);
+        const float bnd = has_in ? rin[t0 & (kStripRing - 1)] : 0.0f;    // H(first row of the strip - 1, column t0)
+        const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(bnd), (int)__float_as_uint(H[R - 1]),
+                                                                  0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+        float diag = __uint_as_float(up_prev);
+        float north = __uint_as_float(up);
+        up_prev = up;
+        uint32_t dpack[W];
+#pragma unroll
+        for (int d = 0; d < W; ++d) dpack[d] = 0;
+        bool hit = false;                                                // kStripTrack: some cell of this step equals target
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float wv = H[r];
+          const bool eq = ca[r] == cb;
+          float x;
+          if (U8) x = eq ? fminf(diag + sc.u8M, 255.0f) : fmaxf(diag - sc.u8X, 0.0f);
+          else x = diag + (eq ? sc.match : sc.mismatch);
+          const float tmx = fmaxf(wv, north);
+          const float h = fmaxf(fmaxf(x, tmx - gpen), 0.0f);
+          if (MODE == kStripDirs) {
+            // smithwaterman.cpp:51,59,66,72 at this cell (n1 = NW = diag, n2 = W = wv, n3 = N = north): stop when a
+            // neighbour is 0, else NW if it is >= both others, else W if it is >= N, else N
+            const float lowest = fminf(fminf(diag, wv), north);
+            const int dir = lowest == 0.0f ? kDirStop : (diag >= tmx ? kDirNW : (wv >= north ? kDirW : kDirN));
+            dpack[r >> 4] |= (uint32_t)dir << (2 * (r & 15));
+          } else {
+            hit |= h == P.target;
+          }
+          diag = wv;
+          H[r] = h;
+          north = h;
+        }
+        if (MODE == kStripTrack) {
+          // rare path, out of the recurrence: which rows, and where they stand in the storage order
+          if (hit && t >= P.own_lo && t < nb) {
+            const long long j = P.col_offset + t + 1;
+            uint32_t rows = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) rows |= (H[r] == P.target ? 1u : 0u) << r;
+            while (rows) {
+              const int r = __builtin_ctz(rows);
+              rows &= rows - 1;
+              const long long i = (long long)(s * 64 + l) * R + r + 1;
+              if (i <= na) {
+                const unsigned long long key = U8 ? order_key<1>(i, j, na, P.full_n) : order_key<0>(i, j, na, P.full_n);
+                if (key < bkey) { bkey = key; bi = i; bj = j; }
+              }
+            }
+          }
+        }
+        if (has_out && l == 63 && t >= 0) rout[t & (kStripRing - 1)] = H[R - 1];
+        if (MODE == kStripDirs) {
+          if (t >= 0 && t < nb) {
+            uint32_t *dst = P.dirs + ((size_t)t * LT + (size_t)(s * 64 + l)) * W;
+#pragma unroll
+            for (int d = 0; d < W; ++d) dst[d] = dpack[d];
+          }
+        }
+      }
+      // lane 63 has stored positions <= seg*64; this wavefront has read positions <= seg*64 + 63
+      if (out_global) {
+        const int t = seg * 64 - 63 + l;
+        if (t >= 0 && t < nb) __hip_atomic_store(gout + t, rout[t & (kStripRing - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (l == 0) {
+        if (has_out) __hip_atomic_store(&produced[w], base + seg * 64 + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&consumed[w], base + (seg + 1) * 64, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      const uint8_t hist = buf[64 + l];
+      buf[l] = hist;
+      buf[64 + l] = (uint8_t)nextc;
+      nextc = stage_load(seg + 2);
+    }
+    if (l == 0 && ok) {
+      // the whole round of this strip is done: releases every wait of this round on this wavefront
+      __hip_atomic_store(&produced[w], base + NBP, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(&consumed[w], base + NBP, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
   }
-  if (l == 0) {
-    // whatever happens next, nobody may wait on this wavefront any more
-    __hip_atomic_store(&produced[w], 0x7FFFFFFF, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_store(&consumed[w], 0x7FFFFFFF, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (l == 0 && w < nw) {
+    // whatever happened, nobody may wait on this wavefront any more
+    __hip_atomic_store(&produced[w], 0x7FFFFFFFFFFFFFFFll, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&consumed[w], 0x7FFFFFFFFFFFFFFFll, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (!ok) *P.status = 1;
+  }
+  if (MODE == kStripTrack) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned long long ok2 = __shfl_xor(bkey, off);
+      const long long oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
+      if (ok2 < bkey) { bkey = ok2; bi = oi; bj = oj; }
+    }
+    if (l == 0) { wkey[w] = bkey; wi[w] = bi; wj[w] = bj; }
+    __syncthreads();                                                     // every wavefront gets here: all waits are bounded
+    if (tid == 0) {
+      for (int k = 1; k < (int)(blockDim.x >> 6); ++k)
+        if (wkey[k] < bkey) { bkey = wkey[k]; bi = wi[k]; bj = wj[k]; }
+      P.cell[0] = bkey != ~0ull ? bi : 0;
+      P.cell[1] = bkey != ~0ull ? bj : 0;
+    }
   }
 }
 

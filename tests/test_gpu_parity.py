@@ -492,3 +492,14 @@ def test_reference_longer_than_2g_columns(ctx, pgs, oracle):
             assert r["end_y"] == exp["end_y"] + lo and r["pos"] == exp["pos"] + lo, (sem, o, r["end_y"], r["pos"])
             assert r["cons_x"] == exp["cons_x"] and r["cons_y"] == exp["cons_y"], (sem, o)
     ctx.set_reference(b"ACGT")                                 # release the 2.2 GB device copy
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+def test_very_long_queries_strip_rounds(ctx, oracle, pgs, sem):
+    """Queries beyond one round of the pipelined strip kernel (16 wavefronts x 64 lanes x 16 rows = 16 384 rows):
+    locate and traceback hand bottom rows from round to round through global memory."""
+    ref = pgs.synth.dna(311, 45_000)
+    refb = ref.tobytes()
+    for k, m in enumerate((13_000, 20_000)):
+        q = pgs.synth.read_from_ref(ref, 320 + k, m, sub_rate=0.02, indel_rate=0.004)[0].tobytes()
+        _cmp(ctx.align(q, refb, sem), oracle.align(q, refb, sem), "very long sem=%d |q|=%d" % (sem, m))
