@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <memory>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "parseq/localaligner.h"
 #include "parseq/plocalaligner.h"
@@ -84,6 +86,37 @@ int main() {
     EXPECT(la->getConsensus_x() == std::string_view("GTTGCATGCA"));
     auto r = _make_string_range(4, 10, 100, 2.0f);
     EXPECT(r.size() == 4 && r[1].first == 20 && r[1].second == 60 && r[3].second == 100);
+  }
+  {  // independent aligner objects on concurrent host threads (how plocalaligner.cpp:110-115 runs its pieces):
+     // every thread gets its own engine context; results must equal the serial ones
+    std::string ref;
+    unsigned long long st = 88172645463325252ull;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    for (int k = 0; k < 60000; ++k) ref.push_back("ACGT"[rnd() & 3]);
+    std::vector<std::string> reads;
+    for (int k = 0; k < 24; ++k) {
+      std::string r = ref.substr(rnd() % (ref.size() - 200), 100 + rnd() % 100);
+      r[r.size() / 2] = 'A';
+      reads.push_back(r);
+    }
+    struct Out { float score; unsigned pos; std::string cx, cy; };
+    auto run = [&](size_t k) {
+      SWAligner<Similarity_Matrix> la(reads[k], ref);
+      la.calculateScore();
+      return Out{la.getScore(), la.getPos(), std::string(la.getConsensus_x()), std::string(la.getConsensus_y())};
+    };
+    std::vector<Out> serial;
+    for (size_t k = 0; k < reads.size(); ++k) serial.push_back(run(k));
+    std::vector<Out> par(reads.size());
+    std::vector<std::thread> th;
+    for (int t = 0; t < 4; ++t)
+      th.emplace_back([&, t]() { for (size_t k = t; k < reads.size(); k += 4) par[k] = run(k); });
+    for (auto &x : th) x.join();
+    for (size_t k = 0; k < reads.size(); ++k) {
+      EXPECT(serial[k].score > 200);
+      EXPECT(par[k].score == serial[k].score && par[k].pos == serial[k].pos);
+      EXPECT(par[k].cx == serial[k].cx && par[k].cy == serial[k].cy);
+    }
   }
   std::printf("ALL OK\n");
   return 0;
