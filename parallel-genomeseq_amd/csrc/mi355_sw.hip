@@ -250,6 +250,7 @@ struct Bucket {
   int SL = 16;                // lanes per tile: 16, or 8 where 8*R rows fit the reads more tightly
   int sem = kSemI16;          // kernel instance: kSemI16 / kSemU8 packed pairs, kSemF32 one query per slot
   bool strips = false;        // queries longer than one 512-row strip
+  bool twin = false;          // lone long query: two tiles of it per packed register (sw_score_kernel TWIN)
   int64_t warm = 0;           // exactness margin in columns
   bool fast = false;          // swept by the score kernel (else whole-matrix exact path)
   int64_t chunk_len = 0;      // own columns per tile
@@ -319,7 +320,9 @@ ScoreTable plan_table(const RefData &ref, const mi355_sw_params &p) {
   return f;
 }
 
-size_t profile_lds_bytes(int ncodes, int R, int SL = 16) { return (size_t)ncodes * (size_t)std::max(16, SL) * lane_stride(R) * 4; }
+size_t profile_lds_bytes(int ncodes, int R, int SL = 16, bool twin = false) {
+  return (size_t)ncodes * (size_t)std::max(16, SL) * lane_stride(twin ? R / 2 : R) * 4;
+}
 
 // Length classes of the batch: one bucket per kernel instance (R), plus one strip-mined bucket.
 std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const ScoreTable &t, const mi355_sw_params &p, int64_t n) {
@@ -343,14 +346,21 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
     out.back().maxlen = std::max(out.back().maxlen, len);
   }
   for (Bucket &b : out) {
-    if (p.semantics == MI355_SW_U8SAT) b.sem = b.count == 1 ? kSemF32U8 : kSemU8;   // lone query: one per register
-    else {
+    const bool twin_ok = b.count == 1 && b.SL == 64 && std::getenv("MI355_SW_NO_TWIN") == nullptr;
+    if (p.semantics == MI355_SW_U8SAT) {
+      // lone query: two of its tiles per packed register on whole-wavefront tiles, else one query per register
+      b.twin = twin_ok;
+      b.sem = b.count == 1 && !b.twin ? kSemF32U8 : kSemU8;
+    } else {
       // packed 16-bit cells when scores are small integers and the score bound fits; float32 cells otherwise
       const bool fits = t.integral && (int64_t)t.smax * std::min<int64_t>(b.maxlen, std::max<int64_t>(n, 1)) + t.smax <= 32000;
       b.sem = fits ? kSemI16 : kSemF32;
       // a lone query would fill both halves of every packed register with itself; the float32 instance
       // (one query per slot, exact for integer scores below 2^24) sweeps it ~1.5x faster
-      if (b.count == 1 && b.sem == kSemI16 && (double)t.smax * b.maxlen < 1.6e7) b.sem = kSemF32;
+      if (b.count == 1 && b.sem == kSemI16) {
+        if (twin_ok) b.twin = true;                               // long lone query: two of its tiles per register
+        else if ((double)t.smax * b.maxlen < 1.6e7) b.sem = kSemF32;
+      }
     }
     const double smax = sem_is_float(b.sem) ? (double)t.smaxf : (double)t.smax;
     const double gap = sem_is_float(b.sem) ? (double)t.gapf : (double)t.gap;
@@ -389,6 +399,19 @@ void launch_score(K kernel, dim3 grid, size_t shmem, hipStream_t st, const Score
 }
 
 template <int SEM>
+int launch_score_twin(int R, bool strips, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
+  if (strips) {
+    if (R != 32) return -1;
+    launch_score(sw_score_kernel<32, SEM, true, 64, true>, grid, shmem, st, a);
+    return 0;
+  }
+  if (R == 16) launch_score(sw_score_kernel<16, SEM, false, 64, true>, grid, shmem, st, a);
+  else if (R == 32) launch_score(sw_score_kernel<32, SEM, false, 64, true>, grid, shmem, st, a);
+  else return -1;
+  return 0;
+}
+
+template <int SEM>
 int launch_score_R(int R, int SL, bool strips, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
   if (strips) {
     if (R != 32) return -1;
@@ -419,7 +442,7 @@ int launch_score_R(int R, int SL, bool strips, dim3 grid, size_t shmem, hipStrea
   return -1;
 }
 
-int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int SL = 16) {
+int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int SL = 16, bool twin = false) {
   int64_t cl = 65536;
   while (cl < 8 * warm) cl *= 2;                 // long queries: keep the warm-up redundancy bounded
   // fill the chip: 256 CUs x 32 waves x 4 slots; shrink tiles while they stay >> warm-up
@@ -427,7 +450,7 @@ int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int S
          (double)npairs * (double)((max_range_len + cl - 1) / cl) < 65536.0) cl /= 2;
   // few tiles (one long query): filling the SIMDs beats the warm-up redundancy down to cl == warm
   // (measured, 10 kbp x 250 Mbp: 1.17 s at 131 k columns, 0.58 s at 32 k; profiles/r01_config5*.log)
-  const double few = SL == 64 ? 1536.0 : 8192.0;                   // a 64-lane tile is a wavefront of its own
+  const double few = (SL == 64 ? 1536.0 : 8192.0) * (twin ? 2.0 : 1.0);   // a 64-lane tile is a wavefront of its own (two tiles with twin)
   while (cl / 2 >= std::max<int64_t>(warm, 2048) &&
          (double)npairs * (double)((max_range_len + cl - 1) / cl) < few) cl /= 2;
   if (const char *e = std::getenv("MI355_SW_CHUNK")) { const long v = std::atol(e); if (v >= 256) cl = v / 64 * 64; }   // tuning aid
@@ -459,8 +482,8 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   const size_t nr = ranges.size();
   int64_t maxlen = 0;
   for (auto &r : ranges) maxlen = std::max(maxlen, r.hi - r.lo);
-  const size_t npairs = sem_is_float(b.sem) ? (size_t)b.count : ((size_t)b.count + 1) / 2;   // queries per workgroup: 1 or 2
-  b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm, b.SL);
+  const size_t npairs = (sem_is_float(b.sem) || b.twin) ? (size_t)b.count : ((size_t)b.count + 1) / 2;   // queries per workgroup: 1 or 2
+  b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm, b.SL, b.twin);
   // report maxima per sub-chunk of >= 256 columns (>= query length, so that the uint8 storage order stays
   // within two neighbouring sub-chunks): that is what locate re-runs; the strip-mined instance reports per tile
   b.sub_len = 256;
@@ -468,8 +491,8 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   if (b.strips) while (b.chunk_len / b.sub_len > 64) b.sub_len *= 2;      // the strip-mined instances keep <= 64 sub-chunk maxima in LDS
   if (b.sub_len > b.chunk_len || b.chunk_len % b.sub_len != 0) b.sub_len = b.chunk_len;
   const int64_t cpr = (maxlen + b.chunk_len - 1) / b.chunk_len;
-  const int nslot = 256 / b.SL;                                     // tiles per workgroup
-  const int64_t cgroups = (cpr + nslot - 1) / nslot;
+  const int nslot = 256 / b.SL;                                     // tiles (twin: tile pairs) per workgroup
+  const int64_t cgroups = ((b.twin ? (cpr + 1) / 2 : cpr) + nslot - 1) / nslot;
   if ((double)npairs * (double)cgroups > 2.0e9) return fail(ctx, MI355_SW_ENOTSUP, "grid too large");
 
   ScoreArgs a;
@@ -495,7 +518,7 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   a.clamp2 = 255u * 0x00010001u;
   a.keys = ctx->keys.as<unsigned long long>();
 
-  const int nqw = sem_is_float(b.sem) ? 1 : 2;                      // queries per workgroup
+  const int nqw = (sem_is_float(b.sem) || b.twin) ? 1 : 2;          // queries per workgroup
   // keep single launches to a few seconds: split the bucket's pairs over several launches
   double range_cols = 0;
   for (auto &r : ranges) range_cols += (double)(r.hi - r.lo);
@@ -505,7 +528,7 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   const size_t pn = std::min(pairs_per_launch, npairs - p0);
   a.qfirst = b.first + (int)(p0 * nqw);
   a.qcount = std::min(b.count - (int)(p0 * nqw), (int)(pn * nqw));
-  size_t shmem = profile_lds_bytes(ref.ncodes, b.R, b.SL) + (size_t)nslot * codebuf_bytes(b.SL);
+  size_t shmem = profile_lds_bytes(ref.ncodes, b.R, b.SL, b.twin) + (size_t)(b.twin ? 2 : 1) * nslot * codebuf_bytes(b.SL);
   dim3 grid((unsigned)(pn * cgroups), (unsigned)nr);
   a.brow = nullptr;
   a.brow_stride = 0;
@@ -521,7 +544,9 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     shmem += (size_t)2 * nslot * kSeg * 4 + (size_t)nslot * 64 * 4;   // boundary windows + per-sub-chunk maxima
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  int rc = b.sem == kSemU8 ? launch_score_R<kSemU8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
+  int rc = b.twin ? (b.sem == kSemU8 ? launch_score_twin<kSemU8>(b.R, b.strips, grid, shmem, ctx->stream, a)
+                                     : launch_score_twin<kSemI16>(b.R, b.strips, grid, shmem, ctx->stream, a))
+           : b.sem == kSemU8 ? launch_score_R<kSemU8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
            : b.sem == kSemF32U8 ? launch_score_R<kSemF32U8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
            : b.sem == kSemF32 ? launch_score_R<kSemF32>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
                               : launch_score_R<kSemI16>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a);

@@ -128,12 +128,16 @@ __device__ __forceinline__ uint32_t row_shr1(uint32_t v) {
 // STRIPS = true : the query is swept in strips of SL*R rows; the bottom row of strip s over the tile's
 // columns goes through a per-tile global scratch row (L2-resident) and enters strip s+1 through the
 // DPP `old` operand of lane 0, where the single-strip kernel gets the zero border row.
-template <int R, int SEM, bool STRIPS = false, int SL = 16>
+// TWIN = true (packed instances, SL = 64): ONE query per workgroup; the two halves of every register hold two
+// neighbouring TILES of it (chunks 2T and 2T+1).  The halves then see different reference codes, so the profile
+// holds 16-bit scores and a step reads it twice (once per code); one v_perm_b32 per row merges the two reads.
+template <int R, int SEM, bool STRIPS = false, int SL = 16, bool TWIN = false>
 __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   static_assert(SL == 64 || SL == 16 || SL == 8, "a slot is a whole wavefront, a DPP row or half a DPP row");
   static_assert(!(STRIPS && SL == 8), "the strip-mined instances use whole DPP rows or whole wavefronts");
-  constexpr int LS = lane_stride(R);
-  constexpr int NQ4 = (R + 3) / 4;
+  static_assert(!TWIN || (SL == 64 && !sem_is_float(SEM) && R % 2 == 0), "twin tiles: packed cells on whole-wavefront tiles");
+  constexpr int LS = TWIN ? lane_stride(R / 2) : lane_stride(R);    // dwords between the profile rows of adjacent lanes
+  constexpr int NQ4 = TWIN ? (R / 2 + 3) / 4 : (R + 3) / 4;
   constexpr int NSLOT = 256 / SL;                                  // tiles per workgroup
   constexpr int CPL = kSeg / SL;                                   // reference codes fetched per lane per segment
   constexpr int PL = SL > 16 ? SL : 16;                            // lane positions of the profile
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   uint32_t *prof = smem;                                           // [ncodes][PL lane positions][LS]
   uint8_t *codebuf = reinterpret_cast<uint8_t *>(smem + a.ncodes * PL * LS);
   // STRIPS: [NSLOT][64] boundary-in window, then [NSLOT][64] boundary-out staging
-  uint32_t *bwin = reinterpret_cast<uint32_t *>(codebuf + NSLOT * CB);
+  uint32_t *bwin = reinterpret_cast<uint32_t *>(codebuf + (TWIN ? 2 : 1) * NSLOT * CB);
 
   const int tid = threadIdx.x;
   const int ls = tid & (SL - 1);                                   // lane within the slot
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   const int range = blockIdx.y;
   typedef Cell<SEM> C;
   typedef typename C::T T;
-  constexpr int NQ = C::kQueries;                                  // queries per workgroup ("pair")
+  constexpr int NQ = TWIN ? 1 : C::kQueries;                       // queries per workgroup ("pair")
   const bool hasB = NQ == 2 && (2 * pair + 1) < a.qcount;
   const int qA = a.qsel[a.qfirst + NQ * pair];
   const int qB = hasB ? a.qsel[a.qfirst + 2 * pair + 1] : qA;
@@ -174,6 +178,12 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
       const int ll = rem / R, r = rem - ll * R;
       const int i = row0 + (ll & (SL - 1)) * R + r;
       uint32_t e32;
+      if (TWIN) {
+        const int16_t *st = static_cast<const int16_t *>(a.stab);
+        const int sa = (i < mA) ? st[(int)xA[i] * a.ncodes + c] : kPadScore;
+        reinterpret_cast<uint16_t *>(prof)[((c * PL + ll) * LS) * 2 + r] = (uint16_t)sa;
+        continue;
+      }
       if (sem_is_float(SEM)) {
         const float *ft = static_cast<const float *>(a.stab);
         e32 = __float_as_uint((i < mA) ? ft[(int)xA[i] * a.ncodes + c] : kPadScoreF);
@@ -191,20 +201,25 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   // ---- this slot's tile -------------------------------------------------------------------
   const int64_t rlo = a.range_lo[range], rhi = a.range_hi[range];
   const int64_t nchunks = (rhi - rlo + a.chunk_len - 1) / a.chunk_len;
-  const int64_t chunk = (int64_t)cg * NSLOT + slot;
+  const int64_t chunk = ((int64_t)cg * NSLOT + slot) * (TWIN ? 2 : 1);   // TWIN: chunk and chunk + 1
   const bool active = chunk < nchunks;
   const int64_t own_lo = rlo + chunk * a.chunk_len;
   const int64_t own_hi = (own_lo + a.chunk_len < rhi) ? own_lo + a.chunk_len : rhi;
   const int64_t s0 = own_lo - a.warm;                 // reference index of stream position 0
+  const bool active2 = TWIN && chunk + 1 < nchunks;   // the tile in the high halves
+  const int64_t own_lo2 = own_lo + a.chunk_len;
+  const int64_t own_hi2 = (own_lo2 + a.chunk_len < rhi) ? own_lo2 + a.chunk_len : rhi;
   const uint32_t pad = (uint32_t)(a.ncodes - 1);
   const uint32_t pad4 = pad * 0x01010101u;
 
   // codes of stream positions seg*64 + CPL*ls .. +CPL-1 (pad outside [rlo, own_hi)): CPL/4 dwords, or one
   // byte per lane when the slot is a whole wavefront
   struct Codes { uint32_t w[CPL >= 4 ? CPL / 4 : 1]; };
-  auto stage_load = [&](int seg) -> Codes {
+  auto stage_load = [&](int seg, bool second = false) -> Codes {
     Codes out;
-    const int64_t c0 = s0 + (int64_t)seg * kSeg + CPL * ls;
+    const bool act = second ? active2 : active;
+    const int64_t hi = second ? own_hi2 : own_hi;
+    const int64_t c0 = s0 + (second ? a.chunk_len : 0) + (int64_t)seg * kSeg + CPL * ls;
     if (CPL >= 4) {
 #pragma unroll
       for (int d = 0; d < CPL / 4; ++d) {
@@ -212,14 +227,14 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           const int64_t col = c0 + 4 * d + b;
-          const bool ok = active && col >= rlo && col < own_hi;
+          const bool ok = act && col >= rlo && col < hi;
           const uint32_t code = ok ? (uint32_t)a.refcodes[col] : pad;
           w |= code << (8 * b);
         }
         out.w[d] = w;
       }
     } else {
-      const bool ok = active && c0 >= rlo && c0 < own_hi;
+      const bool ok = act && c0 >= rlo && c0 < hi;
       out.w[0] = ok ? (uint32_t)a.refcodes[c0] : pad;
     }
     return out;
@@ -228,6 +243,8 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   uint8_t *buf = codebuf + slot * CB;
   uint32_t *buf32 = reinterpret_cast<uint32_t *>(buf);
   const uint8_t *buf_lane = buf + HIST - ls;                       // + k = code of step k
+  uint8_t *buf2 = codebuf + (NSLOT + slot) * CB;                   // TWIN: window of the second tile
+  const uint8_t *buf2_lane = buf2 + HIST - ls;
   const uint32_t *prof_lane = prof + (tid & (PL - 1)) * LS;
   auto window_put = [&](const Codes &c) {
     if (CPL >= 4) {
@@ -239,11 +256,14 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   };
   // first fill: history = padding; later: the last HIST bytes of the window move to its front
   auto window_init = [&]() {
-    if (SL == 64) buf[ls] = (uint8_t)pad;
+    if (SL == 64) { buf[ls] = (uint8_t)pad; if (TWIN) buf2[ls] = (uint8_t)pad; }
     else if (ls < HIST / 4) buf32[ls] = pad4;
   };
   auto window_slide = [&]() {
-    if (SL == 64) { const uint8_t h = buf[kSeg + ls]; buf[ls] = h; }
+    if (SL == 64) {
+      const uint8_t h = buf[kSeg + ls]; buf[ls] = h;
+      if (TWIN) { const uint8_t h2 = buf2[kSeg + ls]; buf2[ls] = h2; }
+    }
     else { const uint32_t h = buf32[kSeg / 4 + (ls & 3)]; if (ls < HIST / 4) buf32[ls] = h; }
   };
   // value of the lane above: DPP inside the row (16/8 lanes) or across the wavefront (64 lanes)
@@ -296,6 +316,10 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
         const uint32_t va = m32 & 0xFFFFu, vb = m32 >> 16;
         if (va > best_a) { best_a = va; atomicMax(k + qA, ((unsigned long long)va << 32) | tag); }
         if (hasB && vb > best_b) { best_b = vb; atomicMax(k + qB, ((unsigned long long)vb << 32) | tag); }
+        if (TWIN && active2 && vb > best_b) {                        // the second tile of the same query
+          best_b = vb;
+          atomicMax(k + qA, ((unsigned long long)vb << 32) | (tag - (unsigned long long)subs_per_tile));
+        }
       }
     }
   };
@@ -341,9 +365,14 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
     };
 
     Codes nextcodes = stage_load(0);
+    Codes nextcodes2 = nextcodes;
     window_init();
     window_put(nextcodes);
     nextcodes = stage_load(1);
+    if (TWIN) {
+      buf2[HIST + ls] = (uint8_t)stage_load(0, true).w[0];
+      nextcodes2 = stage_load(1, true);
+    }
     uint4 nextb = make_uint4(0, 0, 0, 0);
     if (STRIPS) {
       bin_put(bin_load(0));
@@ -361,11 +390,26 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
       for (int k = 0; k < kSeg; ++k) {
         const uint32_t c = buf_lane[k];
         const uint4 *pp = reinterpret_cast<const uint4 *>(prof_lane + c * code_stride);
-        uint32_t p[NQ4 * 4];
+        uint32_t p[TWIN ? R : NQ4 * 4];
+        if (TWIN) {
+          // 16-bit scores of this lane's rows for the two tiles' codes, merged row by row: low half = first tile
+          const uint4 *pp2 = reinterpret_cast<const uint4 *>(prof_lane + (uint32_t)buf2_lane[k] * code_stride);
+          uint32_t d1[NQ4 * 4], d2[NQ4 * 4];
 #pragma unroll
-        for (int q = 0; q < NQ4; ++q) {
-          const uint4 v = pp[q];
-          p[4 * q + 0] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+          for (int q = 0; q < NQ4; ++q) {
+            const uint4 v = pp[q], u = pp2[q];
+            d1[4 * q + 0] = v.x; d1[4 * q + 1] = v.y; d1[4 * q + 2] = v.z; d1[4 * q + 3] = v.w;
+            d2[4 * q + 0] = u.x; d2[4 * q + 1] = u.y; d2[4 * q + 2] = u.z; d2[4 * q + 3] = u.w;
+          }
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            p[r] = __builtin_amdgcn_perm(d2[r >> 1], d1[r >> 1], (r & 1) ? 0x07060302u : 0x05040100u);
+        } else {
+#pragma unroll
+          for (int q = 0; q < NQ4; ++q) {
+            const uint4 v = pp[q];
+            p[4 * q + 0] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+          }
         }
         uint32_t up;                                               // H(i0-1, j) of the lane above
         if (STRIPS) {
@@ -401,6 +445,10 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
       window_slide();
       window_put(nextcodes);
       nextcodes = stage_load(seg + 2);
+      if (TWIN) {
+        buf2[HIST + ls] = (uint8_t)nextcodes2.w[0];
+        nextcodes2 = stage_load(seg + 2, true);
+      }
       {
         // lane 0 has just finished a sub-chunk (and it is not the tile's last): report and restart the maximum
         const int done = seg + 1 - warm_segs;

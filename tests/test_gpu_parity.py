@@ -434,22 +434,27 @@ def test_fuzz_batches_and_splits(ctx, oracle, pgs):
         _cmp(got, {k: exp[k] for k in ("score", "pos", "cons_x", "cons_y")}, "fuzz split t=%d" % t)
 
 
-def test_error_codes(ctx, pgs):
+def test_error_codes(ctx, pgs, oracle):
     """Error behaviour through the C-ABI: inputs outside kernel coverage fail loudly (no silent fallback), the
     reference's constructor asserts map to MI355_SW_ERANGE, bad arguments to MI355_SW_EINVAL."""
-    ref = pgs.synth.dna(5, 30_000_000)
+    ref = pgs.synth.dna(5, 3_000_000)
     q = ref[1000:1150].tobytes()
+    big = pgs.synth.dna(6, 120_000_000)
     with pytest.raises(pgs.MI355Error) as e:
-        ctx.align(q, ref, 0, 3.0, -3.0, 0.0)                       # zero gap penalty: no finite warm-up margin, matrix too large
-    assert e.value.code == -95 and "coverage" in str(e.value)
+        ctx.align(q, big, 0, 3.0, -3.0, 0.0)                        # zero gap penalty: no finite warm-up margin, and the
+    assert e.value.code == -95 and "coverage" in str(e.value)      # whole matrix exceeds the 16 GB decision scratch
+    del big
     with pytest.raises(pgs.MI355Error) as e:
         ctx.align_split("A" * 100, "C" * 120, 4, 2.0)               # overlap > piece length (plocalaligner.cpp:52)
     assert e.value.code == -34
     with pytest.raises(pgs.MI355Error) as e:
         ctx.align(q, ref, 7)                                        # unknown semantics
     assert e.value.code == -22
-    # small problems with the same "unsupported" scoring still run (whole-matrix path)
+    # a zero gap penalty has no finite warm-up margin: such problems run on the whole matrix while it fits the
+    # scratch budget, and still match the oracle
     assert ctx.align("GGTTGACTA", "TGTTACGG", 0, 3.0, -3.0, 0.0)["score"] > 0
+    sub = ref[:120_000].tobytes()
+    _cmp(ctx.align(q, sub, 0, 3.0, -3.0, 0.0), oracle.align(q, sub, 0, 3.0, -3.0, 0.0), "zero gap, whole matrix")
 
 
 @pytest.mark.parametrize("sem", [0, 1])
