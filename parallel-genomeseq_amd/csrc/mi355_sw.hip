@@ -264,9 +264,9 @@ int pick_R(int maxlen) {
   return 0;
 }
 
-// 8-lane tiles: instances for the common short-read lengths (<= 104, 128, 152, 208, 256 rows)
+// 8-lane tiles: instances for the common short-read lengths (<= 56, 80, 104, 128, 152, 208, 256 rows)
 int pick_R8(int maxlen) {
-  static const int rs[] = {13, 16, 19, 26, 32};
+  static const int rs[] = {7, 10, 13, 16, 19, 26, 32};
   const int need = (maxlen + 7) / 8;
   for (int r : rs) if (r >= need) return r;
   return 0;
@@ -275,7 +275,7 @@ int pick_R8(int maxlen) {
 // (SL, R) with the fewest padded rows; ties go to 8 lanes (fewer per-step overhead ops per cell)
 void pick_shape(int len, int &SL, int &R) {
   SL = 16; R = len < 1 ? 2 : pick_R(len);
-  const int r8 = len < 64 ? 0 : pick_R8(len);
+  const int r8 = len < 36 ? 0 : pick_R8(len);
   if (r8 && 8 * r8 <= 16 * R) { SL = 8; R = r8; }
   if (const char *e = std::getenv("MI355_SW_SLOT")) { if (std::atoi(e) == 16) { SL = 16; R = len < 1 ? 2 : pick_R(len); } }   // tuning aid
 }
@@ -429,7 +429,7 @@ int launch_score_R(int R, int SL, bool strips, dim3 grid, size_t shmem, hipStrea
   if (SL == 8) {
     switch (R) {
 #define CASE_R8(r) case r: launch_score(sw_score_kernel<r, SEM, false, 8>, grid, shmem, st, a); return 0;
-      CASE_R8(13) CASE_R8(16) CASE_R8(19) CASE_R8(26) CASE_R8(32)
+      CASE_R8(7) CASE_R8(10) CASE_R8(13) CASE_R8(16) CASE_R8(19) CASE_R8(26) CASE_R8(32)
 #undef CASE_R8
     }
     return -1;
