@@ -851,21 +851,39 @@ int strip_count(int na, int R) { return std::max(1, (na + 64 * R - 1) / (64 * R)
 size_t strip_dirs_bytes(int64_t nb, int nstrips, int R) { return (size_t)nb * 64 * (size_t)nstrips * (size_t)((R + 15) / 16) * 4 + 64; }
 
 template <int R>
-void launch_strip(bool u8, bool track, dim3 grid, dim3 block, hipStream_t st, const StripProblem *dp, const WaveScoring &sc) {
+void launch_strip(bool u8, bool track, dim3 grid, dim3 block, hipStream_t st, const StripProblem *dp, const WaveScoring &sc,
+                  const float *gtab, int ncodes) {
+  if (gtab) {                                   // table scoring (float engine): tab[257][ncodes] in dynamic LDS
+    const size_t lds = (size_t)257 * ncodes * 4;
+    if (track) hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripTrack, true>), grid, block, lds, st, dp, sc, gtab, ncodes);
+    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripDirs, true>), grid, block, lds, st, dp, sc, gtab, ncodes);
+    return;
+  }
   if (track) {
-    if (u8) hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripTrack>), grid, block, 0, st, dp, sc);
-    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripTrack>), grid, block, 0, st, dp, sc);
+    if (u8) hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripTrack>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0);
+    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripTrack>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0);
   } else {
-    if (u8) hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripDirs>), grid, block, 0, st, dp, sc);
-    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripDirs>), grid, block, 0, st, dp, sc);
+    if (u8) hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripDirs>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0);
+    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripDirs>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0);
   }
 }
 
 // Long queries (ORIENT 0 windows) on the pipelined strip kernel, one workgroup per job: traceback decisions
 // (jobs[.].dirs) or the first cell equal to jobs[.].target in storage order (jobs[.].track -> ci, cj; ci = 0: none).
+// The score table of general (non-identity) float scoring the strip kernel can hold in LDS next to its rings.
+bool strip_table_ok(const RefData &ref, const mi355_sw_params &p) {
+  return p.semantics == MI355_SW_F32 && (size_t)257 * ref.ncodes * 4 <= 96 * 1024;
+}
+// Which long queries the strip kernel takes: identity scoring in both engines, any table in the float engine.
+bool strip_scoring_ok(const RefData &ref, const mi355_sw_params &p) {
+  if (std::getenv("MI355_SW_NO_STRIP") != nullptr) return false;
+  return wave_scoring_ok(p) || strip_table_ok(ref, p);
+}
+
 int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg, const mi355_sw_params &p,
               std::vector<WaveJob> &jobs, int R) {
   HostTrace trace_("run_strip");
+  const bool use_table = !wave_scoring_ok(p);            // ctx->ftab holds plan_table()'s [256][ncodes] (score_begin)
   const size_t n = jobs.size();
   if (n == 0) return 0;
   const bool track = jobs[0].track;
@@ -888,7 +906,7 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
     StripProblem &s = pr[k];
     s.a = q.bytes.as<uint8_t>() + q.off[j.q];
     s.na = q.len[j.q];
-    s.b = ref.bytes.as<uint8_t>() + rg.lo + j.s_lo;
+    s.b = (use_table ? ref.codes.as<uint8_t>() : ref.bytes.as<uint8_t>()) + rg.lo + j.s_lo;
     s.nb = j.nb;
     s.nstrips = strip_count(q.len[j.q], R);
     s.nw = std::min(s.nstrips, kStripMaxWaves);
@@ -911,8 +929,16 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   const bool u8 = p.semantics == MI355_SW_U8SAT;
   const StripProblem *dp = ctx->wprobs.as<StripProblem>();
   const dim3 grid((unsigned)n), block((unsigned)(64 * nwmax));
-  if (R == 10) launch_strip<10>(u8, track, grid, block, ctx->stream, dp, sc);
-  else launch_strip<16>(u8, track, grid, block, ctx->stream, dp, sc);
+  const float *gtab = use_table ? ctx->ftab.as<float>() : nullptr;
+  if (use_table && (size_t)257 * ref.ncodes * 4 > 48 * 1024) {
+    const int lds = 257 * ref.ncodes * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<10, false, kStripTrack, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<10, false, kStripDirs, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<16, false, kStripTrack, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<16, false, kStripDirs, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  }
+  if (R == 10) launch_strip<10>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes);
+  else launch_strip<16>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes);
   HIPCHK(ctx, hipGetLastError());
   std::vector<int32_t> st(n);
   std::vector<int64_t> ci(2 * n);
@@ -930,7 +956,8 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
 // the streamed side, grown on demand; then the greedy walk.  orient as WaveJob.
 int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg, const mi355_sw_params &p,
                int orient, const std::vector<int> &qidx, const std::vector<Located> &loc, std::vector<TraceOut> &tout,
-               bool strips = false /* long queries: pipelined strip kernel (orient 0 only) */) {
+               bool strips = false /* long queries: pipelined strip kernel (orient 0 only) */,
+               const ScoreTable *table = nullptr /* strips with table scoring: its smax / gap bound the margins */) {
   HostTrace trace_("wave_trace");
   const int64_t nref = rg.hi - rg.lo;
   tout.assign(qidx.size(), TraceOut());
@@ -940,6 +967,7 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
   // na + smax*na/g stream positions (DESIGN.md §3.3 with the roles of the two sequences as given)
   double smax, g;
   if (p.semantics == MI355_SW_U8SAT) { const U8Params u = u8_params(p); smax = u.M; g = u.G; }
+  else if (table != nullptr && table->ok) { smax = table->smaxf; g = table->gapf; }
   else { smax = p.match; g = p.gap; }
   // ... and a cell whose lane-side index is a (its path is confined to a rows / columns) is exact a + ceil(a*smax/g)
   // positions into the window: the window needs that margin at the argmax plus room for the walk's excursions
@@ -1070,36 +1098,26 @@ int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, co
   const float slope = table.gapf > 0 ? table.smaxf / table.gapf : 0.0f;
   auto row_need = [&](int64_t i) { return i + (int64_t)std::ceil((double)i * (double)slope) + 2; };
   std::vector<size_t> todo;
-  // short reads with identity scoring: decisions by the register-wavefront kernel (lanes = rows of x)
-  if (wave_scoring_ok(p) && std::getenv("MI355_SW_NO_WAVE") == nullptr) {
+  // short reads with identity scoring: decisions by the register-wavefront kernel (lanes = rows of x);
+  // long queries (identity scoring, or any table in the float engine): the pipelined strip kernel
+  const bool wave_ok = wave_scoring_ok(p) && std::getenv("MI355_SW_NO_WAVE") == nullptr;
+  const bool strip_ok = strip_scoring_ok(ref, p);
+  for (int pass = 0; pass < 2; ++pass) {
     std::vector<int> sub;
     std::vector<Located> sl;
     std::vector<size_t> owner;
-    for (size_t k = 0; k < qidx.size(); ++k)
-      if (loc[k].score > 0 && q.len[qidx[k]] <= kWaveMaxLanesSide) { sub.push_back(qidx[k]); sl.push_back(loc[k]); owner.push_back(k); }
-    if (!sub.empty()) {
-      std::vector<TraceOut> t2;
-      int rc = wave_trace(ctx, ref, q, rg, p, 0, sub, sl, t2);
-      if (rc) return rc;
-      for (size_t t = 0; t < sub.size(); ++t) tout[owner[t]] = t2[t];
-    }
-    // long queries: the pipelined strip kernel
-    sub.clear(); sl.clear(); owner.clear();
-    const bool strip_ok = std::getenv("MI355_SW_NO_STRIP") == nullptr;
     for (size_t k = 0; k < qidx.size(); ++k) {
-      const int len = q.len[qidx[k]];
-      if (!(loc[k].score > 0) || len <= kWaveMaxLanesSide) continue;
-      if (strip_ok) { sub.push_back(qidx[k]); sl.push_back(loc[k]); owner.push_back(k); }
+      if (!(loc[k].score > 0)) continue;
+      const bool is_long = q.len[qidx[k]] > kWaveMaxLanesSide;
+      if (is_long != (pass == 1)) continue;
+      if (is_long ? strip_ok : wave_ok) { sub.push_back(qidx[k]); sl.push_back(loc[k]); owner.push_back(k); }
       else todo.push_back(k);
     }
-    if (!sub.empty()) {
-      std::vector<TraceOut> t2;
-      int rc = wave_trace(ctx, ref, q, rg, p, 0, sub, sl, t2, true);
-      if (rc) return rc;
-      for (size_t t = 0; t < sub.size(); ++t) tout[owner[t]] = t2[t];
-    }
-  } else {
-    for (size_t k = 0; k < qidx.size(); ++k) if (loc[k].score > 0) todo.push_back(k);
+    if (sub.empty()) continue;
+    std::vector<TraceOut> t2;
+    int rc = wave_trace(ctx, ref, q, rg, p, 0, sub, sl, t2, pass == 1, &table);
+    if (rc) return rc;
+    for (size_t t = 0; t < sub.size(); ++t) tout[owner[t]] = t2[t];
   }
   std::vector<int64_t> budget(qidx.size());
   for (size_t k : todo) budget[k] = (int64_t)q.len[qidx[k]] / 8 + 64;
@@ -1293,7 +1311,7 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
   const int64_t n = rg.hi - rg.lo;
   std::vector<ExactJob> jobs;
   std::vector<WaveJob> sjobs;                  // long queries with identity scoring: pipelined strip kernel
-  const bool strip_ok = wave_scoring_ok(p) && std::getenv("MI355_SW_NO_STRIP") == nullptr;
+  const bool strip_ok = strip_scoring_ok(ref, p);
   auto key_score = [&](size_t k) {
     float score;
     if (qfloat[k]) { const uint32_t bits = (uint32_t)(keys[k] >> 32); memcpy(&score, &bits, 4); }

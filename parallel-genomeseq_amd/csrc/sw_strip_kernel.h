@@ -55,8 +55,13 @@ constexpr int kStripRing = 512;          // boundary positions held per strip (8
 constexpr int kStripMaxWaves = 16;
 constexpr int kStripSpinLimit = 1 << 22; // polls (with s_sleep) before a wait is declared dead
 
-template <int R, bool U8, int MODE>
-__global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const StripProblem *probs, const WaveScoring sc) {
+// LUT = true (float engine): scores come from a table tab[257][ncodes] in dynamic LDS (row = query byte, row 256 =
+// padding row; column = reference code, column ncodes-1 = padding) and the stream is the window of reference
+// CODES; LUT = false: identity scoring on raw bytes, no table.
+template <int R, bool U8, int MODE, bool LUT = false>
+__global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const StripProblem *probs, const WaveScoring sc,
+                                                                       const float *gtab = nullptr, int ncodes = 0) {
+  extern __shared__ float tab[];
   __shared__ float ring[kStripMaxWaves + 1][kStripRing];            // [w] = output of wavefront w; [kStripMaxWaves] = round input of wavefront 0
   __shared__ long long produced[kStripMaxWaves], consumed[kStripMaxWaves + 1];
   __shared__ int dead;
@@ -69,6 +74,9 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
   if (tid < kStripMaxWaves) produced[tid] = 0;
   if (tid <= kStripMaxWaves) consumed[tid] = 0;
   if (tid == 0) dead = 0;
+  if (LUT) {
+    for (int e = tid; e < 257 * ncodes; e += blockDim.x) tab[e] = e < 256 * ncodes ? gtab[e] : -1.0e30f;
+  }
   __syncthreads();
   const int nw = P.nw;
   const int na = P.na, nb = P.nb;
@@ -100,7 +108,7 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
   const uint8_t *buf_lane = buf + 64 - l;                // + k = byte of stream position seg*64 + k - l
   auto stage_load = [&](int seg) -> uint32_t {
     const int t = seg * 64 + l;
-    return (t < nb) ? (uint32_t)P.b[t] : 0u;
+    return (t < nb) ? (uint32_t)P.b[t] : (LUT ? (uint32_t)(ncodes - 1) : 0u);
   };
 
   for (int round = 0; round < rounds && ok && w < nw; ++round) {
@@ -120,11 +128,12 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int ai = (s * 64 + l) * R + r;
-      ca[r] = (ai < na) ? (uint32_t)P.a[ai] : 0xFFFFu;  // padding rows never match
+      if (LUT) ca[r] = ((ai < na) ? (uint32_t)P.a[ai] : 256u) * (uint32_t)ncodes;   // row offset into tab
+      else ca[r] = (ai < na) ? (uint32_t)P.a[ai] : 0xFFFFu;                          // padding rows never match
     }
     // stream window of this wavefront: 64 B of history, then the current 64-column segment
     uint32_t nextc = stage_load(0);
-    buf[l] = 0;
+    buf[l] = LUT ? (uint8_t)(ncodes - 1) : 0;
     buf[64 + l] = (uint8_t)nextc;
     nextc = stage_load(1);
 
@@ -151,7 +160,8 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
       for (int k = 0; k < 64; ++k) {
         const int t0 = seg * 64 + k;                                     // lane 0's stream position
         const int t = t0 - l;
-        const uint32_t cb = (uint32_t)buf_lane[k] | ((uint32_t)t >= (uint32_t)nb ? 0x100u : 0u);
+        const uint32_t cb = LUT ? ((uint32_t)t >= (uint32_t)nb ? (uint32_t)(ncodes - 1) : (uint32_t)buf_lane[k])
+                                : ((uint32_t)buf_lane[k] | ((uint32_t)t >= (uint32_t)nb ? 0x100u : 0u));
         const float bnd = has_in ? rin[t0 & (kStripRing - 1)] : 0.0f;    // H(first row of the strip - 1, column t0)
         const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(bnd), (int)__float_as_uint(H[R - 1]),
                                                                   0x138 /*wave_shr:1*/, 0xf, 0xf, false);
@@ -167,7 +177,8 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
           const float wv = H[r];
           const bool eq = ca[r] == cb;
           float x;
-          if (U8) x = eq ? fminf(diag + sc.u8M, 255.0f) : fmaxf(diag - sc.u8X, 0.0f);
+          if (LUT) x = diag + tab[ca[r] + cb];
+          else if (U8) x = eq ? fminf(diag + sc.u8M, 255.0f) : fmaxf(diag - sc.u8X, 0.0f);
           else x = diag + (eq ? sc.match : sc.mismatch);
           const float tmx = fmaxf(wv, north);
           const float h = fmaxf(fmaxf(x, tmx - gpen), 0.0f);

@@ -508,3 +508,17 @@ def test_very_long_queries_strip_rounds(ctx, oracle, pgs, sem):
     for k, m in enumerate((13_000, 20_000)):
         q = pgs.synth.read_from_ref(ref, 320 + k, m, sub_rate=0.02, indel_rate=0.004)[0].tobytes()
         _cmp(ctx.align(q, refb, sem), oracle.align(q, refb, sem), "very long sem=%d |q|=%d" % (sem, m))
+
+
+def test_long_queries_table_scoring(ctx, oracle, pgs):
+    """Queries beyond 512 rows with a substitution table (float engine): locate and traceback on the strip kernel's
+    table instance (scores from LDS), including one beyond a single round of strips."""
+    ref = pgs.synth.protein(411, 40_000)
+    refb = ref.tobytes()
+    lut = pgs.synth.make_lut(77)
+    for k, (m, gap) in enumerate(((700, 2.0), (3_000, 3.0), (17_500, 2.0))):
+        q = pgs.synth.read_from_ref(ref, 420 + k, m, sub_rate=0.05, indel_rate=0.01)[0].tobytes()
+        _cmp(ctx.align(q, refb, 0, 3.0, -3.0, gap, lut), oracle.align(q, refb, 0, 3.0, -3.0, gap, lut), "table |q|=%d" % m)
+    # identity-like scoring the compare-based instances refuse (mismatch >= 0) also goes through the table
+    q = pgs.synth.read_from_ref(ref, 430, 2_500, sub_rate=0.05, indel_rate=0.01)[0].tobytes()
+    _cmp(ctx.align(q, refb, 0, 2.0, 0.0, 3.0), oracle.align(q, refb, 0, 2.0, 0.0, 3.0), "mismatch 0")

@@ -60,18 +60,27 @@ while time.time() - t0 < budget:
     ma, mi, gp = SC[int(rng.integers(0, len(SC)))]
     sem = int(rng.integers(0, 2))
     if kind <= 5:       # single alignment, oracle cost bounded to ~3e8 cells
-        m = int(rng.choice([1, 5, 33, 64, 100, 150, 152, 153, 250, 400, 512, 513, 1000, 2048, 2049, 3000, 6000]))
+        m = int(rng.choice([1, 5, 33, 40, 50, 64, 75, 100, 150, 152, 153, 250, 400, 512, 513, 1000, 2048, 2049, 3000, 6000,
+                            11000, 17000]))
         nmax = max(2, int(3e8 // max(m, 1)))
         n = int(min(nmax, rng.choice([3, 150, 900, 1024, 5000, 40000, 300000, 2000000])))
         ref = rseq(n, alpha)
         q = plant(ref, m, alpha)
-        exp = ob.align(q, ref, sem, ma, mi, gp)
-        got = ctx.align(q, ref, sem, ma, mi, gp)
+        lut = None
+        if sem == 0 and rng.random() < 0.25:      # table scoring (float engine only): integer or fractional table
+            lut = pgs.synth.make_lut(int(rng.integers(1, 1 << 30)), float(rng.choice([1.0, 1.0, 0.5, 1.25])))
+            gp = float(rng.choice([1.0, 2.0, 3.0, 1.5]))
+        exp = ob.align(q, ref, sem, ma, mi, gp, lut)
+        try:
+            got = ctx.align(q, ref, sem, ma, mi, gp, lut)
+        except Exception as e:                   # an error is a finding too: report the case and go on
+            got = {k: repr(e)[:80] for k in KEYS}
         bad = [k for k in KEYS if got[k] != exp[k]]
         if bad:
             nbad += 1
-            print("MISMATCH single m=%d n=%d sem=%d sc=%s alpha=%d keys=%s got=%s exp=%s" %
-                  (len(q), n, sem, (ma, mi, gp), len(alpha), bad, {k: got[k] for k in bad[:2]}, {k: exp[k] for k in bad[:2]}), flush=True)
+            print("MISMATCH single m=%d n=%d sem=%d sc=%s lut=%s alpha=%d keys=%s got=%s exp=%s" %
+                  (len(q), n, sem, (ma, mi, gp), lut is not None, len(alpha), bad, {k: got[k] for k in bad[:2]},
+                   {k: exp[k] for k in bad[:2]}), flush=True)
         ncase += 1
     elif kind <= 7:     # ragged batch
         n = int(rng.choice([1500, 20000, 150000]))
