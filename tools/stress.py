@@ -54,7 +54,11 @@ def plant(ref, m, alpha):
 
 t0 = time.time()
 ncase = nbad = 0
+tick = t0
 while time.time() - t0 < budget:
+    if time.time() - tick > 45:
+        tick = time.time()
+        print("... %d cases, %d mismatches, %.0f s" % (ncase, nbad, tick - t0), flush=True)
     alpha = ALPH[int(rng.integers(0, len(ALPH)))]
     kind = int(rng.integers(0, 10))
     ma, mi, gp = SC[int(rng.integers(0, len(SC)))]
