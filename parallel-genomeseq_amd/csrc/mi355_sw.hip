@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <future>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -172,7 +173,7 @@ int upload_reference(mi355_sw_ctx *ctx, RefData &r, const char *y, size_t ny) {
 }
 
 // 64-bit content hash, four independent multiply-rotate lanes (memory-bound; ~3 ms for 50 MB)
-uint64_t content_hash(const char *p, size_t n) {
+uint64_t content_hash_part(const char *p, size_t n) {
   uint64_t h[4] = {0x9E3779B97F4A7C15ull ^ n, 0xBF58476D1CE4E5B9ull, 0x94D049BB133111EBull, 0xD6E8FEB86659FD93ull};
   size_t k = 0;
   for (; k + 32 <= n; k += 32) {
@@ -186,9 +187,21 @@ uint64_t content_hash(const char *p, size_t n) {
   return r ^ (r >> 32);
 }
 
+// Hash of a whole buffer: four independent quarters (hashed on helper threads when the buffer is large), combined.
+uint64_t content_hash(const char *p, size_t n) {
+  if (n < ((size_t)4 << 20)) return content_hash_part(p, n);
+  const size_t q = (n / 4) & ~(size_t)31;
+  std::future<uint64_t> f[3];
+  for (int k = 0; k < 3; ++k) f[k] = std::async(std::launch::async, content_hash_part, p + (size_t)(k + 1) * q, k == 2 ? n - 3 * q : q);
+  uint64_t r = content_hash_part(p, q);
+  for (int k = 0; k < 3; ++k) r = (r ^ f[k].get()) * 0xBF58476D1CE4E5B9ull + (r >> 29);
+  return r;
+}
+
 // Reference of a single-alignment call: re-used from the previous call when its bytes are identical.
-int adhoc_reference(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData **out) {
-  const uint64_t h = content_hash(y, ny);
+// `known_hash`: the caller has already hashed y.
+int adhoc_reference(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData **out, const uint64_t *known_hash = nullptr) {
+  const uint64_t h = known_hash ? *known_hash : content_hash(y, ny);
   if (!(ctx->adhoc_valid && ctx->adhoc.n == ny && ctx->adhoc_hash == h)) {
     ctx->adhoc_valid = false;
     int rc = upload_reference(ctx, ctx->adhoc, y, ny);
@@ -198,6 +211,34 @@ int adhoc_reference(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData *
   }
   *out = &ctx->adhoc;
   return 0;
+}
+
+// One-by-one loops against a large reference (src/sw_solve_big.cpp:78-92: a new aligner per read, same reference):
+// hashing 50 MB costs as much as aligning against it, so the call starts on the resident copy while a helper
+// thread re-hashes the caller's buffer, and is repeated on a fresh upload in the rare case the content changed.
+struct AdhocSpeculation {
+  std::future<uint64_t> hash;
+  bool active = false;
+};
+int adhoc_begin(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData **out, AdhocSpeculation &sp) {
+  if (ctx->adhoc_valid && ctx->adhoc.n == ny && ny >= ((size_t)1 << 20)) {
+    sp.hash = std::async(std::launch::async, content_hash, y, ny);
+    sp.active = true;
+    *out = &ctx->adhoc;
+    return 0;
+  }
+  return adhoc_reference(ctx, y, ny, out);
+}
+// true: the resident copy was the right one (or nothing was speculated); false: *out now points at a fresh upload
+// (or rc reports why not) and the caller must repeat its work
+bool adhoc_confirm(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData **out, AdhocSpeculation &sp, int &rc) {
+  if (!sp.active) return true;
+  sp.active = false;
+  const uint64_t h = sp.hash.get();
+  if (h == ctx->adhoc_hash) return true;
+  ctx->adhoc_valid = false;
+  rc = adhoc_reference(ctx, y, ny, out, &h);
+  return false;
 }
 
 int upload_queries(mi355_sw_ctx *ctx, QueryBatch &q, size_t n, const char *const *xs, const size_t *nxs) {
@@ -1640,9 +1681,17 @@ int mi355_sw_align(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, s
   HIPCHK(ctx, hipSetDevice(ctx->device));
   reset_timings(ctx);
   const RefData *ref = nullptr;
-  rc = adhoc_reference(ctx, y, ny, &ref);
+  AdhocSpeculation sp;
+  memset(out, 0, sizeof *out);
+  rc = adhoc_begin(ctx, y, ny, &ref, sp);
   if (!rc) rc = upload_queries(ctx, ctx->one, 1, &x, &nx);
   if (!rc) rc = align_range(ctx, *ref, ctx->one, Range{0, (int64_t)ny}, *params, 0, out);
+  int rc2 = 0;
+  if (!adhoc_confirm(ctx, y, ny, &ref, sp, rc2)) {             // the caller's buffer changed since the last call
+    mi355_sw_free_result(out);
+    rc = rc2;
+    if (!rc) rc = align_range(ctx, *ref, ctx->one, Range{0, (int64_t)ny}, *params, 0, out);
+  }
   return rc;
 }
 
@@ -1655,9 +1704,16 @@ int mi355_sw_argmax(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, 
   mi355_sw_result r;
   memset(&r, 0, sizeof r);
   const RefData *ref = nullptr;
-  rc = adhoc_reference(ctx, y, ny, &ref);
+  AdhocSpeculation sp;
+  rc = adhoc_begin(ctx, y, ny, &ref, sp);
   if (!rc) rc = upload_queries(ctx, ctx->one, 1, &x, &nx);
   if (!rc) rc = align_range(ctx, *ref, ctx->one, Range{0, (int64_t)ny}, *params, MI355_SW_SCORE_ONLY, &r);
+  int rc2 = 0;
+  if (!adhoc_confirm(ctx, y, ny, &ref, sp, rc2)) {
+    mi355_sw_free_result(&r);
+    rc = rc2;
+    if (!rc) rc = align_range(ctx, *ref, ctx->one, Range{0, (int64_t)ny}, *params, MI355_SW_SCORE_ONLY, &r);
+  }
   if (rc) return rc;
   if (index_x) *index_x = r.end_x;
   if (index_y) *index_y = r.end_y;
@@ -1699,32 +1755,42 @@ int mi355_sw_align_split(mi355_sw_ctx *ctx, const char *x, size_t nx, const char
   rc = mi355_sw_make_string_range(npiece, (int64_t)nx, (int64_t)ny, overlap_ratio, lefts.data(), rights.data());
   if (rc) return fail(ctx, rc, "_make_string_range: the reference's asserts would fire for these arguments");
   const RefData *refp = nullptr;
-  rc = adhoc_reference(ctx, y, ny, &refp);
+  AdhocSpeculation sp;
+  memset(out, 0, sizeof *out);
+  rc = adhoc_begin(ctx, y, ny, &refp, sp);
   QueryBatch &q = ctx->one;
   if (!rc) rc = upload_queries(ctx, q, 1, &x, &nx);
   int bp = 0;
-  if (!rc) {
+  auto work = [&]() -> int {
     mi355_sw_params ps = *params;
     ps.semantics = sm_semantics;
     std::vector<Range> ranges(npiece);
     for (int k = 0; k < npiece; ++k) ranges[k] = Range{lefts[k], rights[k]};
     std::vector<float> pmax(npiece, 0.0f);
-    rc = range_maxima(ctx, *refp, q, ranges, ps, pmax.data());
-    if (!rc) {
-      float best = -1.0f;                                  // plocalaligner.cpp:106,122-129
-      for (int k = 0; k < npiece; ++k) if (pmax[k] > best) { best = pmax[k]; bp = k; }
-      mi355_sw_params pd;
-      mi355_sw_default_params(&pd);                        // LAT(x, piece): default scoring (:135)
-      pd.semantics = la_semantics;
-      const double t_score = ctx->timings[0];
-      rc = align_range(ctx, *refp, q, ranges[bp], pd, 0, out);
-      if (!rc) {
-        if (out->score > 0) { out->pos += (uint32_t)lefts[bp]; out->end_y += lefts[bp]; }
-        else out->pos = (uint32_t)lefts[bp];
-        out->timings_us[0] = (float)t_score;
-        out->timings_us[1] = (float)t_score;
-      }
-    }
+    int r = range_maxima(ctx, *refp, q, ranges, ps, pmax.data());
+    if (r) return r;
+    float best = -1.0f;                                  // plocalaligner.cpp:106,122-129
+    bp = 0;
+    for (int k = 0; k < npiece; ++k) if (pmax[k] > best) { best = pmax[k]; bp = k; }
+    mi355_sw_params pd;
+    mi355_sw_default_params(&pd);                        // LAT(x, piece): default scoring (:135)
+    pd.semantics = la_semantics;
+    const double t_score = ctx->timings[0];
+    r = align_range(ctx, *refp, q, ranges[bp], pd, 0, out);
+    if (r) return r;
+    if (out->score > 0) { out->pos += (uint32_t)lefts[bp]; out->end_y += lefts[bp]; }
+    else out->pos = (uint32_t)lefts[bp];
+    out->timings_us[0] = (float)t_score;
+    out->timings_us[1] = (float)t_score;
+    return 0;
+  };
+  if (!rc) rc = work();
+  int rc2 = 0;
+  if (!adhoc_confirm(ctx, y, ny, &refp, sp, rc2)) {             // the caller's buffer changed since the last call
+    mi355_sw_free_result(out);
+    reset_timings(ctx);
+    rc = rc2;
+    if (!rc) rc = work();
   }
   if (winning_piece) *winning_piece = bp;
   return rc;

@@ -522,3 +522,28 @@ def test_long_queries_table_scoring(ctx, oracle, pgs):
     # identity-like scoring the compare-based instances refuse (mismatch >= 0) also goes through the table
     q = pgs.synth.read_from_ref(ref, 430, 2_500, sub_rate=0.05, indel_rate=0.01)[0].tobytes()
     _cmp(ctx.align(q, refb, 0, 2.0, 0.0, 3.0), oracle.align(q, refb, 0, 2.0, 0.0, 3.0), "mismatch 0")
+
+
+def test_resident_reference_is_rechecked(ctx, oracle, pgs):
+    """One-by-one calls keep the last reference resident and start on it while its content is re-hashed in the
+    background: a same-length reference with different bytes must not be served from the stale copy."""
+    n = 3_000_000
+    ref_a = pgs.synth.dna(501, n)
+    ref_b = ref_a.copy()
+    ref_b[1_000_000:1_000_400] = pgs.synth.dna(502, 400)             # same length, 400 bases differ
+    q = ref_b[1_000_100:1_000_250].tobytes()                           # exact match only in ref_b
+    for sem in (0, 1):
+        ra = ctx.align(q, ref_a.tobytes(), sem)
+        rb = ctx.align(q, ref_b.tobytes(), sem)
+        ra2 = ctx.align(q, ref_a.tobytes(), sem)
+        assert rb["score"] == (450 if sem == 0 else 255)
+        if sem == 0:
+            assert ra["score"] < rb["score"]
+        assert all(ra[k] == ra2[k] for k in ("score", "pos", "end_x", "end_y", "cons_x", "cons_y"))
+        lo = 999_000
+        exp = oracle.align(q, ref_b[lo:1_002_000].tobytes(), sem)
+        assert rb["score"] == exp["score"] and rb["cons_x"] == exp["cons_x"] and rb["pos"] == exp["pos"] + lo
+        sp = ctx.align_split(q, ref_b.tobytes(), 5, 2.0, sem, sem)
+        assert sp["score"] == rb["score"] and sp["pos"] == rb["pos"]
+        sp_a = ctx.align_split(q, ref_a.tobytes(), 5, 2.0, sem, sem)
+        assert sp_a["score"] == ra["score"]
