@@ -1352,7 +1352,11 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
   const int64_t n = rg.hi - rg.lo;
   std::vector<ExactJob> jobs;
   std::vector<WaveJob> sjobs;                  // long queries with identity scoring: pipelined strip kernel
+  std::vector<WaveJob> wjobs;                  // short queries, float engine, identity scoring: register wavefront
   const bool strip_ok = strip_scoring_ok(ref, p);
+  // float order = (column, row): no cell left of the sub-chunk can equal the maximum (it would have been reported
+  // by an earlier sub-chunk), so the wave kernel's plain first-maximum tracking over the whole window is the answer
+  const bool wave_locate = p.semantics == MI355_SW_F32 && wave_scoring_ok(p) && std::getenv("MI355_SW_NO_WAVE") == nullptr;
   auto key_score = [&](size_t k) {
     float score;
     if (qfloat[k]) { const uint32_t bits = (uint32_t)(keys[k] >> 32); memcpy(&score, &bits, 4); }
@@ -1404,6 +1408,13 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
       for (int64_t own_lo = sub_lo; own_lo < sub_hi; own_lo += plen) {
         const int64_t own_hi = std::min(own_lo + plen, sub_hi);
         const int64_t wl = std::max<int64_t>(0, own_lo - warm);
+        if (wave_locate && q.len[k] <= kWaveMaxLanesSide) {
+          WaveJob wj;
+          wj.q = (int)k; wj.orient = 0; wj.s_lo = wl; wj.nb = (int32_t)(own_hi - wl); wj.track = true; wj.dirs = false;
+          wj.target = score;
+          wjobs.push_back(wj);
+          continue;
+        }
         if (strip_ok && q.len[k] > kWaveMaxLanesSide) {
           WaveJob sj;
           sj.q = (int)k; sj.orient = 0; sj.s_lo = wl; sj.nb = (int32_t)(own_hi - wl); sj.track = true; sj.dirs = false;
@@ -1427,6 +1438,16 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
     if (j.best != j.target) continue;
     const unsigned long long kk = host_order_key(p.semantics, j.ci, j.cj, q.len[j.q], n);
     if (kk < bestkey[j.q]) { bestkey[j.q] = kk; loc[j.q].ix = j.ci; loc[j.q].iy = j.cj; }
+  }
+  for (size_t lo = 0; lo < wjobs.size(); lo += 262144) {
+    std::vector<WaveJob> part(wjobs.begin() + lo, wjobs.begin() + std::min(wjobs.size(), lo + 262144));
+    int rc = run_wave(ctx, ref, q, rg, p, part);
+    if (rc) return rc;
+    for (const WaveJob &j : part) {
+      if (j.best != j.target) continue;
+      const unsigned long long kk = host_order_key(p.semantics, j.ci, j.cj, q.len[j.q], n);
+      if (kk < bestkey[j.q]) { bestkey[j.q] = kk; loc[j.q].ix = j.ci; loc[j.q].iy = j.cj; }
+    }
   }
   if (!sjobs.empty()) {
     // one launch per kernel instance (rows per lane)
