@@ -483,7 +483,7 @@ int launch_score_R(int R, int SL, bool strips, dim3 grid, size_t shmem, hipStrea
   return -1;
 }
 
-int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int SL = 16, bool twin = false) {
+int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int SL = 16, bool twin = false, int maxlen = 0) {
   int64_t cl = 65536;
   while (cl < 8 * warm) cl *= 2;                 // long queries: keep the warm-up redundancy bounded
   // fill the chip: 256 CUs x 32 waves x 4 slots; shrink tiles while they stay >> warm-up
@@ -494,6 +494,12 @@ int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int S
   const double few = (SL == 64 ? 1536.0 : 8192.0) * (twin ? 2.0 : 1.0);   // a 64-lane tile is a wavefront of its own (two tiles with twin)
   while (cl / 2 >= std::max<int64_t>(warm, 2048) &&
          (double)npairs * (double)((max_range_len + cl - 1) / cl) < few) cl /= 2;
+  // tiny problems (one read against a short reference): the call's latency is one tile's sweep and the chip is
+  // mostly idle, so tiles shrink until every CU has a workgroup (down to one sub-chunk: >= 256 columns, >= |x|)
+  int64_t floor_cl = 256;
+  while (floor_cl < maxlen) floor_cl *= 2;
+  const double per_wg = 256.0 / SL * (twin ? 2.0 : 1.0);
+  while (cl / 2 >= floor_cl && (double)npairs * (double)((max_range_len + cl - 1) / cl) / per_wg < 256.0) cl /= 2;
   if (const char *e = std::getenv("MI355_SW_CHUNK")) { const long v = std::atol(e); if (v >= 256) cl = v / 64 * 64; }   // tuning aid
   return cl;
 }
@@ -524,7 +530,7 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   int64_t maxlen = 0;
   for (auto &r : ranges) maxlen = std::max(maxlen, r.hi - r.lo);
   const size_t npairs = (sem_is_float(b.sem) || b.twin) ? (size_t)b.count : ((size_t)b.count + 1) / 2;   // queries per workgroup: 1 or 2
-  b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm, b.SL, b.twin);
+  b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm, b.SL, b.twin, b.maxlen);
   // report maxima per sub-chunk of >= 256 columns (>= query length, so that the uint8 storage order stays
   // within two neighbouring sub-chunks): that is what locate re-runs; the strip-mined instance reports per tile
   b.sub_len = 256;
