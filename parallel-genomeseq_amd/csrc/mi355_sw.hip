@@ -106,6 +106,14 @@ struct mi355_sw_ctx {
   QueryBatch one;                 // the single query of such a call
   // scratch
   DevBuf keys, ranges, stab, ftab, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs;
+  // host sides of small per-call uploads: they must outlive the asynchronous copies, and the tables are only
+  // sent again when they change
+  std::vector<int64_t> h_ranges;
+  std::vector<int16_t> h_stab;
+  std::vector<float> h_ftab;
+  // event pairs around the score launches of a call, read back after the call's first synchronisation
+  std::vector<hipEvent_t> score_ev;
+  size_t score_ev_used = 0;
   double timings[6] = {0, 0, 0, 0, 0, 0};
 };
 
@@ -508,17 +516,24 @@ int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int S
 int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range> &ranges, const ScoreTable &t) {
   const size_t nq = q.nq, nr = ranges.size();
   if (nr > 32768) return fail(ctx, MI355_SW_ENOTSUP, "more than 32768 ranges per launch");
-  std::vector<int64_t> rl(2 * nr);
+  // the previous call's copies out of these host vectors have completed: every call ends synchronised
+  std::vector<int64_t> &rl = ctx->h_ranges;
+  rl.resize(2 * nr);
   for (size_t k = 0; k < nr; ++k) { rl[k] = ranges[k].lo; rl[nr + k] = ranges[k].hi; }
+  const void *stab_was = ctx->stab.p, *ftab_was = ctx->ftab.p;
   if (ctx->ranges.ensure(rl.size() * 8) || ctx->keys.ensure(nq * nr * 8) || ctx->stab.ensure(t.stab.size() * 2) ||
       ctx->ftab.ensure(t.ftab.size() * 4 + 16))
     return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
   HIPCHK(ctx, hipMemcpyAsync(ctx->ranges.p, rl.data(), rl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->stab.p, t.stab.data(), t.stab.size() * 2, hipMemcpyHostToDevice, ctx->stream));
-  if (!t.ftab.empty())
-    HIPCHK(ctx, hipMemcpyAsync(ctx->ftab.p, t.ftab.data(), t.ftab.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->stab.p != stab_was || ctx->h_stab != t.stab) {
+    ctx->h_stab = t.stab;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stab.p, ctx->h_stab.data(), ctx->h_stab.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (!t.ftab.empty() && (ctx->ftab.p != ftab_was || ctx->h_ftab != t.ftab)) {
+    ctx->h_ftab = t.ftab;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ftab.p, ctx->h_ftab.data(), ctx->h_ftab.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
   HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, nq * nr * 8, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // pageable staging buffers above go out of scope
   return 0;
 }
 
@@ -590,7 +605,10 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     a.brow = ctx->brow.as<uint32_t>();
     shmem += (size_t)2 * nslot * kSeg * 4 + (size_t)nslot * 64 * 4;   // boundary windows + per-sub-chunk maxima
   }
-  HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  if (ctx->score_ev.size() < ctx->score_ev_used + 2) {
+    for (int e = 0; e < 2; ++e) { hipEvent_t ev; HIPCHK(ctx, hipEventCreate(&ev)); ctx->score_ev.push_back(ev); }
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->score_ev[ctx->score_ev_used], ctx->stream));
   int rc = b.twin ? (b.sem == kSemU8 ? launch_score_twin<kSemU8>(b.R, b.strips, grid, shmem, ctx->stream, a)
                                      : launch_score_twin<kSemI16>(b.R, b.strips, grid, shmem, ctx->stream, a))
            : b.sem == kSemU8 ? launch_score_R<kSemU8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
@@ -599,11 +617,8 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
                               : launch_score_R<kSemI16>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a);
   if (rc) return fail(ctx, MI355_SW_ENOTSUP, "no score kernel instance for this R");
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-  HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
-  float ms = 0;
-  HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-  ctx->timings[0] += (double)ms * 1000.0;
+  HIPCHK(ctx, hipEventRecord(ctx->score_ev[ctx->score_ev_used + 1], ctx->stream));
+  ctx->score_ev_used += 2;                                // read by score_fetch, after the launches have drained
   ctx->timings[4] += 1;
   }
   double cells = 0;
@@ -617,6 +632,12 @@ int score_fetch(mi355_sw_ctx *ctx, size_t count, std::vector<unsigned long long>
   keys.resize(count);
   HIPCHK(ctx, hipMemcpyAsync(keys.data(), ctx->keys.p, count * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t e = 0; e + 1 < ctx->score_ev_used; e += 2) {     // device time of the score launches
+    float ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->score_ev[e], ctx->score_ev[e + 1]));
+    ctx->timings[0] += (double)ms * 1000.0;
+  }
+  ctx->score_ev_used = 0;
   return 0;
 }
 
@@ -1086,29 +1107,48 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
       }
       HIPCHK(ctx, hipMemcpyAsync(ctx->walkp.p, wp.data(), n * sizeof(WaveWalk), hipMemcpyHostToDevice, ctx->stream));
       const unsigned wblocks = (unsigned)((n + 63) / 64);
-      hipLaunchKernelGGL(sw_wave_walk_kernel<false>, dim3(wblocks), dim3(64), 0, ctx->stream, ctx->walkp.as<WaveWalk>(), (int)n,
-                         (char *)nullptr, (const int64_t *)nullptr);
-      HIPCHK(ctx, hipGetLastError());
       std::vector<int64_t> wo(3 * n), offs(n);
-      HIPCHK(ctx, hipMemcpyAsync(wo.data(), wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-      size_t ctot = 0;
-      for (size_t t = 0; t < n; ++t) { offs[t] = (int64_t)ctot; if (wo[3 * t + 2] == 0) ctot += 2 * (size_t)wo[3 * t]; }
-      if (ctx->cons.ensure(ctot + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(consensus) failed");
-      HIPCHK(ctx, hipMemcpyAsync(woffs, offs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
-      hipLaunchKernelGGL(sw_wave_walk_kernel<true>, dim3(wblocks), dim3(64), 0, ctx->stream, ctx->walkp.as<WaveWalk>(), (int)n,
-                         ctx->cons.as<char>(), (const int64_t *)woffs);
-      HIPCHK(ctx, hipGetLastError());
-      std::vector<char> cons(ctot + 1);
-      if (ctot) HIPCHK(ctx, hipMemcpyAsync(cons.data(), ctx->cons.p, ctot, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      std::vector<char> cons;
+      size_t captot = 0;
+      for (size_t t = 0; t < n; ++t) captot += 2 * (size_t)wp[t].cap;
+      const bool one_pass = n <= 4096 && captot <= ((size_t)32 << 20);
+      if (one_pass) {
+        // few walks: each writes into a buffer of its own capacity (x at offs, y at offs + cap) in one pass
+        size_t at = 0;
+        for (size_t t = 0; t < n; ++t) { offs[t] = (int64_t)at; at += 2 * (size_t)wp[t].cap; }
+        if (ctx->cons.ensure(captot + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(consensus) failed");
+        HIPCHK(ctx, hipMemcpyAsync(woffs, offs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(sw_wave_walk_kernel<kWalkBoth>, dim3(wblocks), dim3(64), 0, ctx->stream, ctx->walkp.as<WaveWalk>(), (int)n,
+                           ctx->cons.as<char>(), (const int64_t *)woffs);
+        HIPCHK(ctx, hipGetLastError());
+        cons.resize(captot + 1);
+        HIPCHK(ctx, hipMemcpyAsync(wo.data(), wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(cons.data(), ctx->cons.p, captot, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      } else {
+        hipLaunchKernelGGL(sw_wave_walk_kernel<kWalkMeasure>, dim3(wblocks), dim3(64), 0, ctx->stream, ctx->walkp.as<WaveWalk>(), (int)n,
+                           (char *)nullptr, (const int64_t *)nullptr);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(wo.data(), wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        size_t ctot = 0;
+        for (size_t t = 0; t < n; ++t) { offs[t] = (int64_t)ctot; if (wo[3 * t + 2] == 0) ctot += 2 * (size_t)wo[3 * t]; }
+        if (ctx->cons.ensure(ctot + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(consensus) failed");
+        HIPCHK(ctx, hipMemcpyAsync(woffs, offs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(sw_wave_walk_kernel<kWalkWrite>, dim3(wblocks), dim3(64), 0, ctx->stream, ctx->walkp.as<WaveWalk>(), (int)n,
+                           ctx->cons.as<char>(), (const int64_t *)woffs);
+        HIPCHK(ctx, hipGetLastError());
+        cons.resize(ctot + 1);
+        if (ctot) HIPCHK(ctx, hipMemcpyAsync(cons.data(), ctx->cons.p, ctot, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      }
       for (size_t t = 0; t < n; ++t) {
         const size_t k = owner[t];
         const int st = (int)wo[3 * t + 2];
         if (st == 0) {
           const size_t len = (size_t)wo[3 * t];
           tout[k].cx.assign(cons.data() + offs[t], len);
-          tout[k].cy.assign(cons.data() + offs[t] + len, len);
+          tout[k].cy.assign(cons.data() + offs[t] + (one_pass ? (size_t)wp[t].cap : len), len);
           tout[k].pos = (uint32_t)wo[3 * t + 1];
         } else if (st == 1) { budget[k] *= 4; next.push_back(k); }
         else return fail(ctx, MI355_SW_ENOTSUP, "consensus longer than |x| + |y|");
@@ -1622,7 +1662,7 @@ int check_params(mi355_sw_ctx *ctx, const mi355_sw_params *p) {
   return 0;
 }
 
-void reset_timings(mi355_sw_ctx *ctx) { for (double &t : ctx->timings) t = 0; }
+void reset_timings(mi355_sw_ctx *ctx) { for (double &t : ctx->timings) t = 0; ctx->score_ev_used = 0; }
 
 }  // namespace
 
@@ -1663,6 +1703,7 @@ void mi355_sw_destroy(mi355_sw_ctx *c) {
   for (DevBuf *b : bufs) b->release();
   c->adhoc.release(); c->one.release();
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+  for (auto &e : c->score_ev) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

@@ -206,19 +206,26 @@ struct WaveWalk {
   int64_t *out;            // [0] length, [1] pos, [2] status (0 ok, 1 window too small, 2 capacity)
 };
 
-// Two passes over the same decisions: WRITE = false measures (length, pos, status); the host then lays the
-// strings out back to back and WRITE = true emits them at cons + offs[p] (x) and cons + offs[p] + length (y),
-// so that only the bytes that exist cross PCIe.
-template <bool WRITE>
+// Many walks take two passes over the same decisions: kWalkMeasure yields (length, pos, status); the host then
+// lays the strings out back to back and kWalkWrite emits them at cons + offs[p] (x) and cons + offs[p] + length
+// (y), so that only the bytes that exist cross PCIe.  A few walks take one pass (kWalkBoth): x at cons + offs[p],
+// y at cons + offs[p] + cap.
+enum : int { kWalkMeasure = 0, kWalkWrite = 1, kWalkBoth = 2 };
+template <int MODE>
 __global__ void sw_wave_walk_kernel(const WaveWalk *probs, int n, char *cons, const int64_t *offs) {
+  constexpr bool WRITE = MODE != kWalkMeasure;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const WaveWalk W = probs[p];
   char *cons_x = nullptr, *cons_y = nullptr;
-  if (WRITE) {
+  if (MODE == kWalkWrite) {
     if (W.out[2] != 0) return;
     cons_x = cons + offs[p];
     cons_y = cons_x + W.out[0];
+  }
+  if (MODE == kWalkBoth) {
+    cons_x = cons + offs[p];
+    cons_y = cons_x + W.cap;
   }
   long long ix = W.start_i, iy = W.start_j;
   int len = 0;
@@ -258,7 +265,7 @@ __global__ void sw_wave_walk_kernel(const WaveWalk *probs, int n, char *cons, co
       ++len; --ix;
     }
   }
-  if (WRITE) return;
+  if (MODE == kWalkWrite) return;
   W.out[0] = len; W.out[1] = pos; W.out[2] = status;
 }
 
