@@ -835,7 +835,8 @@ struct WaveJob {
   int64_t s_lo;           // stream window start (0-based, range-relative), nb positions
   int32_t nb;
   bool track, dirs;
-  float target = 0;       // strip kernel, track: only cells equal to target compete ...
+  bool keyed = false;     // wave kernel, track: first cell equal to target in storage order (else: first maximum)
+  float target = 0;       // strip kernel / keyed: only cells equal to target compete ...
   int32_t own_lo = 0;     // ... at stream positions >= own_lo (0-based)
   // results
   float best = 0;
@@ -848,6 +849,12 @@ void launch_wave_flags(bool track, bool dirs, unsigned blocks, hipStream_t st, c
   if (track && dirs) hipLaunchKernelGGL((sw_wave_kernel<R, ORIENT, U8, true, true>), dim3(blocks), dim3(256), 0, st, pr, n, sc);
   else if (track) hipLaunchKernelGGL((sw_wave_kernel<R, ORIENT, U8, true, false>), dim3(blocks), dim3(256), 0, st, pr, n, sc);
   else hipLaunchKernelGGL((sw_wave_kernel<R, ORIENT, U8, false, true>), dim3(blocks), dim3(256), 0, st, pr, n, sc);
+}
+
+template <int R>
+void launch_wave_keyed(bool u8, unsigned blocks, hipStream_t st, const WaveProblem *pr, int n, const WaveScoring &sc) {
+  if (u8) hipLaunchKernelGGL((sw_wave_kernel<R, 0, true, true, false, true>), dim3(blocks), dim3(256), 0, st, pr, n, sc);
+  else hipLaunchKernelGGL((sw_wave_kernel<R, 0, false, true, false, true>), dim3(blocks), dim3(256), 0, st, pr, n, sc);
 }
 
 template <int R>
@@ -888,7 +895,9 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
     w.dirs = dirs ? reinterpret_cast<uint32_t *>(ctx->dirs.as<uint8_t>() + j.dirs_off) : nullptr;
     w.best = ctx->outs_f.as<float>() + k;
     w.cell = ctx->outs_i.as<int64_t>() + 2 * k;
+    w.target = j.target; w.own_lo = j.own_lo; w.full_n = nref;
   }
+  const bool keyed = jobs[0].keyed;
   HIPCHK(ctx, hipMemcpyAsync(ctx->wprobs.p, pr.data(), n * sizeof(WaveProblem), hipMemcpyHostToDevice, ctx->stream));
   WaveScoring sc;
   sc.match = p.match; sc.mismatch = p.mismatch; sc.gap = p.gap;
@@ -897,7 +906,12 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
   const bool u8 = p.semantics == MI355_SW_U8SAT;
   const unsigned blocks = (unsigned)((n + 15) / 16);
   const WaveProblem *dp = ctx->wprobs.as<WaveProblem>();
-  if (R == 10) launch_wave_R<10>(orient, u8, track, dirs, blocks, ctx->stream, dp, (int)n, sc);
+  if (keyed) {
+    if (R == 10) launch_wave_keyed<10>(u8, blocks, ctx->stream, dp, (int)n, sc);
+    else if (R == 20) launch_wave_keyed<20>(u8, blocks, ctx->stream, dp, (int)n, sc);
+    else launch_wave_keyed<32>(u8, blocks, ctx->stream, dp, (int)n, sc);
+  }
+  else if (R == 10) launch_wave_R<10>(orient, u8, track, dirs, blocks, ctx->stream, dp, (int)n, sc);
   else if (R == 20) launch_wave_R<20>(orient, u8, track, dirs, blocks, ctx->stream, dp, (int)n, sc);
   else launch_wave_R<32>(orient, u8, track, dirs, blocks, ctx->stream, dp, (int)n, sc);
   HIPCHK(ctx, hipGetLastError());
@@ -1402,7 +1416,9 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
   const bool strip_ok = strip_scoring_ok(ref, p);
   // float order = (column, row): no cell left of the sub-chunk can equal the maximum (it would have been reported
   // by an earlier sub-chunk), so the wave kernel's plain first-maximum tracking over the whole window is the answer
-  const bool wave_locate = p.semantics == MI355_SW_F32 && wave_scoring_ok(p) && std::getenv("MI355_SW_NO_WAVE") == nullptr;
+  // the uint8 order needs the storage-order key of every cell that equals the maximum: keyed tracking
+  const bool wave_locate = wave_scoring_ok(p) && std::getenv("MI355_SW_NO_WAVE") == nullptr;
+  const bool wave_keyed = p.semantics == MI355_SW_U8SAT;
   auto key_score = [&](size_t k) {
     float score;
     if (qfloat[k]) { const uint32_t bits = (uint32_t)(keys[k] >> 32); memcpy(&score, &bits, 4); }
@@ -1457,7 +1473,7 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
         if (wave_locate && q.len[k] <= kWaveMaxLanesSide) {
           WaveJob wj;
           wj.q = (int)k; wj.orient = 0; wj.s_lo = wl; wj.nb = (int32_t)(own_hi - wl); wj.track = true; wj.dirs = false;
-          wj.target = score;
+          wj.target = score; wj.keyed = wave_keyed; wj.own_lo = (int32_t)(own_lo - wl);
           wjobs.push_back(wj);
           continue;
         }

@@ -30,6 +30,11 @@ struct WaveProblem {
   uint32_t *dirs;        // DIRS: [nb][16][W] packed decisions (2 bits per cell, cell r of a lane at bit 2*(r%16)), or null
   float *best;           // TRACK: maximum (0 when no positive cell)
   int64_t *cell;         // TRACK: [2] = row (into x), column (into y), 1-based, of the first maximum
+  // KEYED tracking (ORIENT 0): the first cell in the engine's storage order (order_key<>, sw_exact_kernel.h) among
+  // the cells equal to `target` at stream positions >= own_lo; best = target when found, else -1
+  float target;
+  int32_t own_lo;
+  int64_t full_n;        // |y| of the full problem (uint8 storage order)
 };
 
 struct WaveScoring {
@@ -40,8 +45,9 @@ struct WaveScoring {
 constexpr int kWaveSeg = 64;
 constexpr int kWaveBuf = 16 + kWaveSeg;
 
-template <int R, int ORIENT, bool U8, bool TRACK, bool DIRS>
+template <int R, int ORIENT, bool U8, bool TRACK, bool DIRS, bool KEYED = false>
 __global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, int nprob, const WaveScoring sc) {
+  static_assert(!KEYED || (TRACK && !DIRS && ORIENT == 0), "keyed tracking: locate windows, lanes = rows of x");
   __shared__ __attribute__((aligned(16))) uint8_t win[16 * kWaveBuf];
   const int tid = threadIdx.x;
   const int l = tid & 15;
@@ -50,7 +56,8 @@ __global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, 
   const bool active = pid < nprob;
   WaveProblem P;
   if (active) P = probs[pid];
-  else { P.a = nullptr; P.b = nullptr; P.na = 0; P.nb = 0; P.b_offset = 0; P.dirs = nullptr; P.best = nullptr; P.cell = nullptr; }
+  else { P.a = nullptr; P.b = nullptr; P.na = 0; P.nb = 0; P.b_offset = 0; P.dirs = nullptr; P.best = nullptr; P.cell = nullptr;
+         P.target = -1.0f; P.own_lo = 0; P.full_n = 0; }
   const int na = P.na, nb = P.nb;
 
   // this lane's R characters of the short side (0xFFFF = padding, never equal to a byte)
@@ -101,6 +108,8 @@ __global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, 
     for (int r = 0; r < R; ++r) { tbr[r] = 0.0f; ttr[r] = 0; }
   }
   const float gpen = U8 ? sc.u8G : sc.gap;
+  unsigned long long bkey = ~0ull;                                 // KEYED: this lane's first competing cell
+  long long kbi = 0, kbj = 0;
 
   for (int seg = 0; seg < nseg; ++seg) {
 #pragma unroll 4
@@ -118,6 +127,7 @@ __global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, 
 #pragma unroll
         for (int d = 0; d < W; ++d) dpack[d] = 0;
       }
+      bool hit = false;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const float w = H[r];                                      // same lane row, previous step
@@ -140,13 +150,32 @@ __global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, 
           else dir = kDirN;
           dpack[r >> 4] |= (uint32_t)dir << (2 * (r & 15));
         }
-        if (TRACK) {
+        if (KEYED) hit |= h == P.target;
+        else if (TRACK) {
           if (ORIENT == 0) { if (h > tb0) { tb0 = h; tt0 = t; tr0 = r; } }
           else { if (h > tbr[r]) { tbr[r] = h; ttr[r] = t; } }
         }
         diag = w;
         H[r] = h;
         north = h;
+      }
+      if (KEYED) {
+        // rare path, out of the recurrence: which rows, and where they stand in the storage order
+        if (hit && t >= P.own_lo && t < nb) {
+          const long long j = P.b_offset + t + 1;
+          uint32_t rows = 0;
+#pragma unroll
+          for (int r = 0; r < R; ++r) rows |= (H[r] == P.target ? 1u : 0u) << r;
+          while (rows) {
+            const int r = __builtin_ctz(rows);
+            rows &= rows - 1;
+            const long long i = (long long)l * R + r + 1;
+            if (i <= na) {
+              const unsigned long long key = U8 ? order_key<1>(i, j, na, P.full_n) : order_key<0>(i, j, na, P.full_n);
+              if (key < bkey) { bkey = key; kbi = i; kbj = j; }
+            }
+          }
+        }
       }
       if (DIRS) {
         if (P.dirs != nullptr && t >= 0 && t < nb) {
@@ -162,7 +191,19 @@ __global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, 
     nextc = stage_load(seg + 2);
   }
 
-  if (TRACK) {
+  if (KEYED) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+      const unsigned long long ok = __shfl_xor(bkey, off, 16);
+      const long long oi = __shfl_xor(kbi, off, 16), oj = __shfl_xor(kbj, off, 16);
+      if (ok < bkey) { bkey = ok; kbi = oi; kbj = oj; }
+    }
+    if (l == 0 && active) {
+      *P.best = bkey != ~0ull ? P.target : -1.0f;
+      P.cell[0] = bkey != ~0ull ? kbi : 0;
+      P.cell[1] = bkey != ~0ull ? kbj : 0;
+    }
+  } else if (TRACK) {
     // per-lane winner in storage order (column of y first, then row of x), then across the 16 lanes
     float bv;
     long long bi, bj;
