@@ -1,0 +1,252 @@
+// host_common.h — engine context, device buffers, reference / query upload, the resident-reference cache
+// Part of the single translation unit mi355_sw.hip (included there, in order; not a standalone header).
+namespace {
+
+constexpr size_t kProfileLdsMax = 120 * 1024;  // LDS budget of the query profile (ncodes x 16 lanes x stride x 4 B)
+constexpr int kMaxRowsFast = 512;             // 16 lanes x R <= 32 rows in one strip; longer queries are strip-mined
+constexpr size_t kDirsBudget = 16ull << 30;    // bytes of traceback decisions per exact launch
+constexpr size_t kExactLdsMax = 159 * 1024;    // dynamic part; the wide instance adds < 1 KiB of static LDS
+
+// MI355_SW_TRACE=1: wall-clock of the host-side phases of every call on stderr (diagnostic)
+struct HostTrace {
+  const char *name;
+  std::chrono::steady_clock::time_point t0;
+  explicit HostTrace(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
+  ~HostTrace() {
+    static const bool on = std::getenv("MI355_SW_TRACE") != nullptr;
+    if (on) std::fprintf(stderr, "[mi355_sw] %-28s %9.3f ms\n", name,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+};
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct RefData {
+  DevBuf bytes, codes;
+  size_t n = 0;
+  int ncodes = 0;                 // incl. pad
+  int code_of[256];
+  uint8_t byte_of[256];
+  void release() { bytes.release(); codes.release(); n = 0; }
+};
+
+struct QueryBatch {
+  DevBuf bytes, lens, offs, sel;  // concatenated bytes (16-byte aligned starts), lengths, offsets, length-sorted ids
+  std::vector<int32_t> len;
+  std::vector<int64_t> off;
+  std::vector<int32_t> order;     // query ids sorted by length (stable)
+  size_t nq = 0;
+  int maxlen = 0;
+  void release() { bytes.release(); lens.release(); offs.release(); sel.release(); }
+};
+
+struct Range { int64_t lo, hi; };
+
+// One alignment's intermediate state on the host
+struct Located {
+  float score = 0;
+  int64_t ix = 0, iy = 0;         // argmax, iy relative to the range start (1-based)
+};
+
+}  // namespace
+
+struct mi355_sw_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {};
+  std::string err;
+  RefData ref;                    // resident reference (set_reference)
+  QueryBatch batch;               // resident queries (batch_upload)
+  RefData adhoc;                  // reference of the last mi355_sw_align-style call, kept while its content hash
+  uint64_t adhoc_hash = 0;        // matches (one-by-one driver loops pass the same reference every time)
+  bool adhoc_valid = false;
+  QueryBatch one;                 // the single query of such a call
+  // scratch
+  DevBuf keys, ranges, stab, ftab, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs;
+  // host sides of small per-call uploads: they must outlive the asynchronous copies, and the tables are only
+  // sent again when they change
+  std::vector<int64_t> h_ranges;
+  std::vector<int16_t> h_stab;
+  std::vector<float> h_ftab;
+  // event pairs around the score launches of a call, read back after the call's first synchronisation
+  std::vector<hipEvent_t> score_ev;
+  size_t score_ev_used = 0;
+  double timings[6] = {0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                  \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+      return MI355_SW_ENODEV;                                                              \
+    }                                                                                      \
+  } while (0)
+
+int fail(mi355_sw_ctx *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+inline float lut_or(const mi355_sw_params &p, uint8_t a, uint8_t b) {
+  if (p.lut) return p.lut[(size_t)a * 256 + b];
+  return a == b ? p.match : p.mismatch;
+}
+
+// similaritymatrix.cpp:376-384
+inline int sat8(float a) { return a < 0 ? 0 : (a > 255 ? 255 : (int)(uint8_t)a); }
+
+struct U8Params { int M, X, G; };
+U8Params u8_params(const mi355_sw_params &p) {
+  return {sat8(lut_or(p, 'A', 'A')), sat8(-lut_or(p, 'A', 'T')), sat8(p.gap)};   // :389-392
+}
+
+// host twin of order_key<> (sw_exact_kernel.h)
+unsigned long long host_order_key(int sem, int64_t i, int64_t j, int64_t m, int64_t n) {
+  if (sem == MI355_SW_F32) return ((unsigned long long)j << 32) | (unsigned long long)i;
+  const int64_t len_x = n + 1, len_y = m + 1;
+  const int64_t nrows = std::min(len_x, len_y), ncols = std::max(len_x, len_y);
+  const int64_t ti = j, tj = i;
+  int64_t ri, rj;
+  if (ti + tj < nrows - 1) { ri = ti; rj = ti + tj; }
+  else if (ti + tj > ncols - 1) { ri = ti - ncols + len_y; rj = ti + tj - (ncols - 1) - 1; }
+  else { ri = (len_x <= len_y) ? ti : len_y - 1 - tj; rj = ti + tj; }
+  return ((unsigned long long)rj << 32) | (unsigned long long)ri;
+}
+
+int upload_reference(mi355_sw_ctx *ctx, RefData &r, const char *y, size_t ny) {
+  HostTrace trace_("upload_reference");
+  bool present[256] = {false};
+  const uint8_t *u = reinterpret_cast<const uint8_t *>(y);
+  for (size_t k = 0; k < ny; ++k) present[u[k]] = true;
+  int nc = 0;
+  for (int b = 0; b < 256; ++b) {
+    r.code_of[b] = -1;
+    if (present[b]) { r.code_of[b] = nc; r.byte_of[nc] = (uint8_t)b; ++nc; }
+  }
+  r.ncodes = nc + 1;   // + pad
+  r.n = ny;
+  if (r.bytes.ensure(ny + 64) || r.codes.ensure(ny + 64)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(reference) failed");
+  std::vector<uint8_t> codes(ny);
+  for (size_t k = 0; k < ny; ++k) codes[k] = (uint8_t)r.code_of[u[k]];
+  HIPCHK(ctx, hipMemcpyAsync(r.bytes.p, y, ny, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(r.codes.p, codes.data(), ny, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// 64-bit content hash, four independent multiply-rotate lanes (memory-bound; ~3 ms for 50 MB)
+uint64_t content_hash_part(const char *p, size_t n) {
+  uint64_t h[4] = {0x9E3779B97F4A7C15ull ^ n, 0xBF58476D1CE4E5B9ull, 0x94D049BB133111EBull, 0xD6E8FEB86659FD93ull};
+  size_t k = 0;
+  for (; k + 32 <= n; k += 32) {
+    uint64_t w[4];
+    memcpy(w, p + k, 32);
+    for (int l = 0; l < 4; ++l) { h[l] = (h[l] ^ w[l]) * 0x9FB21C651E98DF25ull; h[l] = (h[l] << 29) | (h[l] >> 35); }
+  }
+  for (; k < n; ++k) { h[k & 3] = (h[k & 3] ^ (uint8_t)p[k]) * 0x9FB21C651E98DF25ull; h[k & 3] = (h[k & 3] << 29) | (h[k & 3] >> 35); }
+  uint64_t r = h[0];
+  for (int l = 1; l < 4; ++l) r = (r ^ h[l]) * 0xBF58476D1CE4E5B9ull + (r >> 31);
+  return r ^ (r >> 32);
+}
+
+// Hash of a whole buffer: four independent quarters (hashed on helper threads when the buffer is large), combined.
+uint64_t content_hash(const char *p, size_t n) {
+  if (n < ((size_t)4 << 20)) return content_hash_part(p, n);
+  const size_t q = (n / 4) & ~(size_t)31;
+  std::future<uint64_t> f[3];
+  for (int k = 0; k < 3; ++k) f[k] = std::async(std::launch::async, content_hash_part, p + (size_t)(k + 1) * q, k == 2 ? n - 3 * q : q);
+  uint64_t r = content_hash_part(p, q);
+  for (int k = 0; k < 3; ++k) r = (r ^ f[k].get()) * 0xBF58476D1CE4E5B9ull + (r >> 29);
+  return r;
+}
+
+// Reference of a single-alignment call: re-used from the previous call when its bytes are identical.
+// `known_hash`: the caller has already hashed y.
+int adhoc_reference(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData **out, const uint64_t *known_hash = nullptr) {
+  const uint64_t h = known_hash ? *known_hash : content_hash(y, ny);
+  if (!(ctx->adhoc_valid && ctx->adhoc.n == ny && ctx->adhoc_hash == h)) {
+    ctx->adhoc_valid = false;
+    int rc = upload_reference(ctx, ctx->adhoc, y, ny);
+    if (rc) return rc;
+    ctx->adhoc_hash = h;
+    ctx->adhoc_valid = true;
+  }
+  *out = &ctx->adhoc;
+  return 0;
+}
+
+// One-by-one loops against a large reference (src/sw_solve_big.cpp:78-92: a new aligner per read, same reference):
+// hashing 50 MB costs as much as aligning against it, so the call starts on the resident copy while a helper
+// thread re-hashes the caller's buffer, and is repeated on a fresh upload in the rare case the content changed.
+struct AdhocSpeculation {
+  std::future<uint64_t> hash;
+  bool active = false;
+};
+int adhoc_begin(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData **out, AdhocSpeculation &sp) {
+  if (ctx->adhoc_valid && ctx->adhoc.n == ny && ny >= ((size_t)1 << 20)) {
+    sp.hash = std::async(std::launch::async, content_hash, y, ny);
+    sp.active = true;
+    *out = &ctx->adhoc;
+    return 0;
+  }
+  return adhoc_reference(ctx, y, ny, out);
+}
+// true: the resident copy was the right one (or nothing was speculated); false: *out now points at a fresh upload
+// (or rc reports why not) and the caller must repeat its work
+bool adhoc_confirm(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData **out, AdhocSpeculation &sp, int &rc) {
+  if (!sp.active) return true;
+  sp.active = false;
+  const uint64_t h = sp.hash.get();
+  if (h == ctx->adhoc_hash) return true;
+  ctx->adhoc_valid = false;
+  rc = adhoc_reference(ctx, y, ny, out, &h);
+  return false;
+}
+
+int upload_queries(mi355_sw_ctx *ctx, QueryBatch &q, size_t n, const char *const *xs, const size_t *nxs) {
+  HostTrace trace_("upload_queries");
+  q.nq = n;
+  q.len.resize(n);
+  q.off.resize(n);
+  size_t mx = 0, tot = 0;
+  for (size_t k = 0; k < n; ++k) {
+    if (nxs[k] > 0x3fffffff) return fail(ctx, MI355_SW_EINVAL, "query too long");
+    q.len[k] = (int32_t)nxs[k];
+    q.off[k] = (int64_t)tot;
+    tot += (nxs[k] + 15) / 16 * 16;
+    mx = std::max(mx, nxs[k]);
+  }
+  q.maxlen = (int)mx;
+  q.order.resize(n);
+  for (size_t k = 0; k < n; ++k) q.order[k] = (int32_t)k;
+  std::stable_sort(q.order.begin(), q.order.end(), [&](int32_t a, int32_t b) { return q.len[a] < q.len[b]; });
+  std::vector<uint8_t> host(tot + 16, 0);
+  for (size_t k = 0; k < n; ++k) memcpy(&host[(size_t)q.off[k]], xs[k], nxs[k]);
+  if (q.bytes.ensure(host.size()) || q.lens.ensure(n * 4 + 16) || q.offs.ensure(n * 8 + 16) || q.sel.ensure(n * 4 + 16))
+    return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(queries) failed");
+  HIPCHK(ctx, hipMemcpyAsync(q.bytes.p, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(q.lens.p, q.len.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(q.offs.p, q.off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(q.sel.p, q.order.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+}  // namespace

@@ -1,0 +1,512 @@
+// host_pipeline.h — the per-call pipeline: locate, traceback routing, whole-matrix path, align_range, range_maxima
+// Part of the single translation unit mi355_sw.hip (included there, in order; not a standalone header).
+namespace {
+
+void set_result(mi355_sw_result &r, float score, int64_t ix, int64_t iy, const TraceOut *t) {
+  r.score = score;
+  r.end_x = score > 0 ? ix : 0;
+  r.end_y = score > 0 ? iy : 0;
+  r.pos = t ? t->pos : 0;
+  const std::string empty;
+  const std::string &cx = t ? t->cx : empty, &cy = t ? t->cy : empty;
+  r.cons_len = cx.size();
+  // both strings live in ONE allocation owned through cons_x (mi355_sw_free_result frees only that)
+  r.cons_x = (char *)malloc(cx.size() + cy.size() + 2);
+  r.cons_y = r.cons_x + cx.size() + 1;
+  memcpy(r.cons_x, cx.data(), cx.size()); r.cons_x[cx.size()] = 0;
+  memcpy(r.cons_y, cy.data(), cy.size()); r.cons_y[cy.size()] = 0;
+}
+
+// Traceback for located alignments of one range: windows left of the argmax, grown on demand.
+int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
+                  const mi355_sw_params &p, const std::vector<int64_t> &qwarm, const ScoreTable &table,
+                  const std::vector<int> &qidx, const std::vector<Located> &loc, std::vector<TraceOut> &tout) {
+  tout.assign(qidx.size(), TraceOut());
+  // A cell in row i is exact once it lies i + ceil(i * smax / g) columns into a window (the bound of DESIGN.md
+  // §3.3 for a path that can only use rows 1..i), so the window needs that margin at the argmax row plus room
+  // for the horizontal excursions of the walk; the walk kernel checks every cell it visits against the bound.
+  const float slope = table.gapf > 0 ? table.smaxf / table.gapf : 0.0f;
+  auto row_need = [&](int64_t i) { return i + (int64_t)std::ceil((double)i * (double)slope) + 2; };
+  std::vector<size_t> todo;
+  // short reads with identity scoring: decisions by the register-wavefront kernel (lanes = rows of x);
+  // long queries (identity scoring, or any table in the float engine): the pipelined strip kernel
+  const bool wave_ok = wave_scoring_ok(p) && std::getenv("MI355_SW_NO_WAVE") == nullptr;
+  const bool strip_ok = strip_scoring_ok(ref, p);
+  for (int pass = 0; pass < 2; ++pass) {
+    std::vector<int> sub;
+    std::vector<Located> sl;
+    std::vector<size_t> owner;
+    for (size_t k = 0; k < qidx.size(); ++k) {
+      if (!(loc[k].score > 0)) continue;
+      const bool is_long = q.len[qidx[k]] > kWaveMaxLanesSide;
+      if (is_long != (pass == 1)) continue;
+      if (is_long ? strip_ok : wave_ok) { sub.push_back(qidx[k]); sl.push_back(loc[k]); owner.push_back(k); }
+      else todo.push_back(k);
+    }
+    if (sub.empty()) continue;
+    std::vector<TraceOut> t2;
+    int rc = wave_trace(ctx, ref, q, rg, p, 0, sub, sl, t2, pass == 1, &table);
+    if (rc) return rc;
+    for (size_t t = 0; t < sub.size(); ++t) tout[owner[t]] = t2[t];
+  }
+  std::vector<int64_t> budget(qidx.size());
+  for (size_t k : todo) budget[k] = (int64_t)q.len[qidx[k]] / 8 + 64;
+  while (!todo.empty()) {
+    // build jobs in memory-bounded groups
+    std::vector<size_t> next;
+    size_t pos = 0;
+    while (pos < todo.size()) {
+      std::vector<ExactJob> jobs;
+      std::vector<size_t> owner;
+      std::vector<std::pair<int32_t, int32_t>> starts;
+      std::vector<int32_t> exlo;
+      size_t bytes = 0;
+      while (pos < todo.size()) {
+        const size_t k = todo[pos];
+        const int qi = qidx[k];
+        const int64_t iy = loc[k].iy;
+        const int64_t warm = qwarm[qi];
+        int64_t wl = iy - (budget[k] + row_need(loc[k].ix));   // range-relative 0-based start of window
+        if (wl < 0) wl = 0;
+        const int64_t nw = iy - wl;
+        const size_t need = dirs_bytes(q.len[qi], nw) + 16;
+        if (need > kDirsBudget) return fail(ctx, MI355_SW_ENOTSUP, "traceback window exceeds the device scratch budget");
+        if (!jobs.empty() && bytes + need > kDirsBudget) break;
+        ExactJob j;
+        j.q = qi; j.ylo = rg.lo + wl; j.nw = (int32_t)nw; j.col_offset = wl; j.full_n = rg.hi - rg.lo;
+        j.own_lo = (int32_t)(nw + 1);                   // nothing competes: decisions only
+        j.quirk = 0;                                    // |x| == |y| never reaches the score path (bucket_fast_ok)
+        j.target = 1e30f; j.want_dirs = true;
+        jobs.push_back(j); owner.push_back(k);
+        starts.emplace_back((int32_t)loc[k].ix, (int32_t)nw);
+        exlo.push_back(wl == 0 ? 0 : (int32_t)warm);
+        bytes += need;
+        ++pos;
+      }
+      int rc = run_exact(ctx, ref, q, p, jobs, 0, jobs.size(), nullptr);
+      if (rc) return rc;
+      std::vector<TraceOut> outs;
+      std::vector<int> st;
+      rc = run_walk(ctx, ref, q, jobs, 0, jobs.size(), starts, exlo, outs, st, slope);
+      if (rc) return rc;
+      for (size_t t = 0; t < jobs.size(); ++t) {
+        const size_t k = owner[t];
+        if (st[t] == 0) tout[k] = outs[t];
+        else if (st[t] == 1) { budget[k] *= 4; next.push_back(k); }
+        else return fail(ctx, MI355_SW_ENOTSUP, "consensus longer than |x| + window");
+      }
+    }
+    todo.swap(next);
+  }
+  return 0;
+}
+
+// Whole-matrix path on the LDS anti-diagonal kernel (sw_exact_kernel.h) for the listed queries over one range.
+int exact_full_lds(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
+                   const mi355_sw_params &p, const std::vector<int> &qidx, bool want_trace,
+                   std::vector<Located> &loc, std::vector<TraceOut> &tout) {
+  const int64_t n = rg.hi - rg.lo;
+  loc.assign(qidx.size(), Located());
+  tout.assign(qidx.size(), TraceOut());
+  size_t pos = 0;
+  while (pos < qidx.size()) {
+    std::vector<ExactJob> jobs;
+    std::vector<size_t> owner;
+    size_t bytes = 0;
+    while (pos < qidx.size()) {
+      const int qi = qidx[pos];
+      const size_t need = dirs_bytes(q.len[qi], n) + 16;
+      if (want_trace && need > kDirsBudget) return fail(ctx, MI355_SW_ENOTSUP, "problem needs the score kernel but is outside its coverage");
+      if (!jobs.empty() && want_trace && bytes + need > kDirsBudget) break;
+      if (jobs.size() >= 65536) break;
+      ExactJob j;
+      j.q = qi; j.ylo = rg.lo; j.nw = (int32_t)n; j.col_offset = 0; j.full_n = n; j.own_lo = 1;
+      j.quirk = (p.semantics == MI355_SW_U8SAT && q.len[qi] == n) ? 1 : 0;
+      j.target = -1.0f; j.want_dirs = want_trace;
+      jobs.push_back(j); owner.push_back(pos);
+      bytes += need;
+      ++pos;
+    }
+    int rc = run_exact(ctx, ref, q, p, jobs, 0, jobs.size(), nullptr);
+    if (rc) return rc;
+    std::vector<std::pair<int32_t, int32_t>> starts;
+    std::vector<int32_t> exlo(jobs.size(), 0);
+    for (size_t t = 0; t < jobs.size(); ++t) {
+      Located &L = loc[owner[t]];
+      L.score = jobs[t].best > 0 ? jobs[t].best : 0;
+      L.ix = jobs[t].ci; L.iy = jobs[t].cj;
+      starts.emplace_back(L.score > 0 ? (int32_t)L.ix : 0, L.score > 0 ? (int32_t)L.iy : 0);
+    }
+    if (want_trace) {
+      std::vector<TraceOut> outs;
+      std::vector<int> st;
+      rc = run_walk(ctx, ref, q, jobs, 0, jobs.size(), starts, exlo, outs, st);
+      if (rc) return rc;
+      for (size_t t = 0; t < jobs.size(); ++t) {
+        if (st[t] != 0) return fail(ctx, MI355_SW_ENOTSUP, "traceback walk failed on a whole-matrix window");
+        tout[owner[t]] = outs[t];
+      }
+    }
+  }
+  return 0;
+}
+
+// Whole-matrix path for the listed queries over one range (problems the score kernel does not take).
+// Small problems with identity scoring run on the register-wavefront kernel (sw_wave_kernel.h): argmax tracking
+// for the float engine, traceback decisions for both engines; everything else on the LDS anti-diagonal kernel.
+int exact_full(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
+               const mi355_sw_params &p, const std::vector<int> &qidx, bool want_trace,
+               std::vector<Located> &loc, std::vector<TraceOut> &tout) {
+  HostTrace trace_("exact_full");
+  const int64_t n = rg.hi - rg.lo;
+  loc.assign(qidx.size(), Located());
+  tout.assign(qidx.size(), TraceOut());
+  const bool wave_ok = wave_scoring_ok(p) && std::getenv("MI355_SW_NO_WAVE") == nullptr;
+  const bool u8 = p.semantics == MI355_SW_U8SAT;
+  // orientation per query: -1 = LDS kernel for everything
+  std::vector<int> orient(qidx.size(), -1);
+  for (size_t k = 0; k < qidx.size(); ++k) {
+    const int m = q.len[qidx[k]];
+    if (!wave_ok || m < 1 || n < 1) continue;
+    if (u8 && m == n) continue;                                   // |x| == |y| quirk lives in the LDS kernel
+    if (m <= kWaveMaxLanesSide && m <= n) orient[k] = 0;
+    else if (n <= kWaveMaxLanesSide) orient[k] = 1;
+  }
+  // 1. score + argmax
+  std::vector<int> lds_all, lds_score_only;                       // positions k
+  for (size_t k = 0; k < qidx.size(); ++k) {
+    if (orient[k] < 0) lds_all.push_back((int)k);
+    else if (u8) lds_score_only.push_back((int)k);                // uint8 storage order: LDS kernel's order_key
+  }
+  auto run_lds = [&](const std::vector<int> &ks, bool trace) -> int {
+    if (ks.empty()) return 0;
+    std::vector<int> sub(ks.size());
+    for (size_t t = 0; t < ks.size(); ++t) sub[t] = qidx[ks[t]];
+    std::vector<Located> l2;
+    std::vector<TraceOut> t2;
+    int rc = exact_full_lds(ctx, ref, q, rg, p, sub, trace, l2, t2);
+    if (rc) return rc;
+    for (size_t t = 0; t < ks.size(); ++t) { loc[ks[t]] = l2[t]; tout[ks[t]] = t2[t]; }
+    return 0;
+  };
+  int rc = run_lds(lds_all, want_trace);
+  if (rc) return rc;
+  rc = run_lds(lds_score_only, false);
+  if (rc) return rc;
+  if (!u8) {
+    for (int o = 0; o < 2; ++o) {
+      std::vector<WaveJob> jobs;
+      std::vector<size_t> owner;
+      for (size_t k = 0; k < qidx.size(); ++k) {
+        if (orient[k] != o) continue;
+        WaveJob j;
+        j.q = qidx[k]; j.orient = o; j.s_lo = 0; j.nb = o == 0 ? (int32_t)n : q.len[qidx[k]]; j.track = true; j.dirs = false;
+        jobs.push_back(j); owner.push_back(k);
+      }
+      rc = run_wave(ctx, ref, q, rg, p, jobs);
+      if (rc) return rc;
+      for (size_t t = 0; t < jobs.size(); ++t) {
+        Located &L = loc[owner[t]];
+        L.score = jobs[t].best > 0 ? jobs[t].best : 0;
+        L.ix = jobs[t].ci; L.iy = jobs[t].cj;
+      }
+    }
+  }
+  // 2. traceback of the wave-eligible ones
+  if (want_trace) {
+    for (int o = 0; o < 2; ++o) {
+      std::vector<int> sub;
+      std::vector<Located> sl;
+      std::vector<size_t> owner;
+      for (size_t k = 0; k < qidx.size(); ++k)
+        if (orient[k] == o) { sub.push_back(qidx[k]); sl.push_back(loc[k]); owner.push_back(k); }
+      if (sub.empty()) continue;
+      std::vector<TraceOut> t2;
+      rc = wave_trace(ctx, ref, q, rg, p, o, sub, sl, t2);
+      if (rc) return rc;
+      for (size_t t = 0; t < sub.size(); ++t) tout[owner[t]] = t2[t];
+    }
+  }
+  return 0;
+}
+
+// Argmax cells for the score-kernel queries (qfast[q] != 0) over one range, from the score pass' keys.
+// qchunk / qwarm: tile geometry of each query's bucket.
+int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
+                const mi355_sw_params &p, const std::vector<char> &qfast, const std::vector<int64_t> &qchunk,
+                const std::vector<int64_t> &qwarm, const std::vector<char> &qfloat, const unsigned long long *keys,
+                const ScoreTable &table, std::vector<Located> &loc) {
+  HostTrace trace_("locate_fast");
+  const size_t nq = q.nq;
+  const int64_t n = rg.hi - rg.lo;
+  std::vector<ExactJob> jobs;
+  std::vector<WaveJob> sjobs;                  // long queries with identity scoring: pipelined strip kernel
+  std::vector<WaveJob> wjobs;                  // short queries, float engine, identity scoring: register wavefront
+  const bool strip_ok = strip_scoring_ok(ref, p);
+  // float order = (column, row): no cell left of the sub-chunk can equal the maximum (it would have been reported
+  // by an earlier sub-chunk), so the wave kernel's plain first-maximum tracking over the whole window is the answer
+  // the uint8 order needs the storage-order key of every cell that equals the maximum: keyed tracking
+  const bool wave_locate = wave_scoring_ok(p) && std::getenv("MI355_SW_NO_WAVE") == nullptr;
+  const bool wave_keyed = p.semantics == MI355_SW_U8SAT;
+  auto key_score = [&](size_t k) {
+    float score;
+    if (qfloat[k]) { const uint32_t bits = (uint32_t)(keys[k] >> 32); memcpy(&score, &bits, 4); }
+    else score = (float)(int)(keys[k] >> 32);
+    return score;
+  };
+  // long queries are few and each re-run occupies one workgroup: cut their sub-chunk into pieces (each with its
+  // own margin) so that the idle CUs share the work
+  size_t nlong = 0;                       // workgroups the long queries' sub-chunks need before cutting
+  for (size_t k = 0; k < nq; ++k)
+    if (qfast[k] && q.len[k] > 512 && key_score(k) > 0) nlong += p.semantics == MI355_SW_U8SAT ? 5 : 1;
+  for (size_t k = 0; k < nq; ++k) {
+    if (!qfast[k]) continue;
+    const unsigned long long key = keys[k];
+    const float score = key_score(k);
+    if (!(score > 0)) continue;
+    const int64_t chunk_len = qchunk[k];           // sub-chunk granularity of this query's bucket
+    const int64_t nchunks = (n + chunk_len - 1) / chunk_len;
+    // only cells equal to the known maximum compete: a path that reaches `score` within |x| diagonal steps can
+    // afford fewer gap columns than the general margin allows (DESIGN.md §3.3 with the score subtracted)
+    int64_t warm = qwarm[k];
+    if (table.gapf > 0) {
+      const double spare = std::max(0.0, (double)table.smaxf * (double)q.len[k] - (double)score);
+      warm = std::min<int64_t>(warm, (int64_t)q.len[k] + (int64_t)std::ceil(spare / (double)table.gapf) + 2);
+    }
+    const int64_t first = (int64_t)(0xFFFFFFFFull - (key & 0xFFFFFFFFull));
+    loc[k].score = score;
+    int64_t cand[5];
+    int nc = 0;
+    cand[nc++] = first;
+    if (p.semantics == MI355_SW_U8SAT) {
+      // storage order = anti-diagonal (mod ncols): the first maximum lies in the first tile that
+      // reached the maximum or the next one, or in the corner triangles (first / last two tiles)
+      const int64_t extra[4] = {first + 1, 0, nchunks - 2, nchunks - 1};
+      for (int64_t c : extra) {
+        if (c < 0 || c >= nchunks) continue;
+        bool dup = false;
+        for (int t = 0; t < nc; ++t) dup |= cand[t] == c;
+        if (!dup) cand[nc++] = c;
+      }
+    }
+    for (int t = 0; t < nc; ++t) {
+      // lanes lag by up to 63 columns (whole-wavefront tiles): the end of the previous sub-chunk is reported with this one
+      const int64_t sub_lo = std::max<int64_t>(0, cand[t] * chunk_len - 63);   // range-relative, 0-based
+      const int64_t sub_hi = std::min((cand[t] + 1) * chunk_len, n);
+      int64_t pieces = 1;
+      if (q.len[k] > 512) pieces = std::max<int64_t>(1, std::min<int64_t>((sub_hi - sub_lo) / 256, 224 / (int64_t)nlong));   // one 1024-thread workgroup per CU
+      const int64_t plen = (sub_hi - sub_lo + pieces - 1) / pieces;
+      for (int64_t own_lo = sub_lo; own_lo < sub_hi; own_lo += plen) {
+        const int64_t own_hi = std::min(own_lo + plen, sub_hi);
+        const int64_t wl = std::max<int64_t>(0, own_lo - warm);
+        if (wave_locate && q.len[k] <= kWaveMaxLanesSide) {
+          WaveJob wj;
+          wj.q = (int)k; wj.orient = 0; wj.s_lo = wl; wj.nb = (int32_t)(own_hi - wl); wj.track = true; wj.dirs = false;
+          wj.target = score; wj.keyed = wave_keyed; wj.own_lo = (int32_t)(own_lo - wl);
+          wjobs.push_back(wj);
+          continue;
+        }
+        if (strip_ok && q.len[k] > kWaveMaxLanesSide) {
+          WaveJob sj;
+          sj.q = (int)k; sj.orient = 0; sj.s_lo = wl; sj.nb = (int32_t)(own_hi - wl); sj.track = true; sj.dirs = false;
+          sj.target = score; sj.own_lo = (int32_t)(own_lo - wl);
+          sjobs.push_back(sj);
+          continue;
+        }
+        ExactJob j;
+        j.q = (int)k; j.ylo = rg.lo + wl; j.nw = (int32_t)(own_hi - wl); j.col_offset = wl; j.full_n = n;
+        j.own_lo = (int32_t)(own_lo - wl + 1); j.quirk = 0; j.target = score; j.want_dirs = false;
+        jobs.push_back(j);
+      }
+    }
+  }
+  for (size_t lo = 0; lo < jobs.size(); lo += 65536) {
+    int rc = run_exact(ctx, ref, q, p, jobs, lo, std::min(jobs.size(), lo + 65536), nullptr);
+    if (rc) return rc;
+  }
+  std::vector<unsigned long long> bestkey(nq, ~0ull);
+  for (const ExactJob &j : jobs) {
+    if (j.best != j.target) continue;
+    const unsigned long long kk = host_order_key(p.semantics, j.ci, j.cj, q.len[j.q], n);
+    if (kk < bestkey[j.q]) { bestkey[j.q] = kk; loc[j.q].ix = j.ci; loc[j.q].iy = j.cj; }
+  }
+  for (size_t lo = 0; lo < wjobs.size(); lo += 262144) {
+    std::vector<WaveJob> part(wjobs.begin() + lo, wjobs.begin() + std::min(wjobs.size(), lo + 262144));
+    int rc = run_wave(ctx, ref, q, rg, p, part);
+    if (rc) return rc;
+    for (const WaveJob &j : part) {
+      if (j.best != j.target) continue;
+      const unsigned long long kk = host_order_key(p.semantics, j.ci, j.cj, q.len[j.q], n);
+      if (kk < bestkey[j.q]) { bestkey[j.q] = kk; loc[j.q].ix = j.ci; loc[j.q].iy = j.cj; }
+    }
+  }
+  if (!sjobs.empty()) {
+    // one launch per kernel instance (rows per lane)
+    for (int R : {10, 16}) {
+      std::vector<WaveJob> group;
+      for (const WaveJob &j : sjobs) if (strip_R(q.len[j.q]) == R) group.push_back(j);
+      for (size_t lo = 0; lo < group.size(); lo += 4096) {
+        std::vector<WaveJob> part(group.begin() + lo, group.begin() + std::min(group.size(), lo + 4096));
+        int rc = run_strip(ctx, ref, q, rg, p, part, R);
+        if (rc) return rc;
+        for (const WaveJob &j : part) {
+          if (j.ci <= 0) continue;
+          const unsigned long long kk = host_order_key(p.semantics, j.ci, j.cj, q.len[j.q], n);
+          if (kk < bestkey[j.q]) { bestkey[j.q] = kk; loc[j.q].ix = j.ci; loc[j.q].iy = j.cj; }
+        }
+      }
+    }
+  }
+  for (size_t k = 0; k < nq; ++k)
+    if (qfast[k] && loc[k].score > 0 && bestkey[k] == ~0ull)
+      return fail(ctx, MI355_SW_ENODEV, "internal: maximum of the score pass not found again by the exact kernel");
+  return 0;
+}
+
+float elapsed_us(mi355_sw_ctx *ctx, hipEvent_t a, hipEvent_t b) {
+  float ms = 0;
+  if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0;
+  (void)ctx;
+  return ms * 1000.0f;
+}
+
+// All queries of `q` against one range of the reference.
+int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
+                const mi355_sw_params &p, int flags, mi355_sw_result *outs) {
+  HostTrace trace_("align_range");
+  const bool want_trace = !(flags & MI355_SW_SCORE_ONLY);
+  const size_t nq = q.nq;
+  const int64_t n = rg.hi - rg.lo;
+  HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  std::vector<Located> loc(nq);
+  std::vector<TraceOut> tout(nq);
+  if (n >= 1 && nq > 0) {
+    const ScoreTable table = plan_table(ref, p);
+    std::vector<Bucket> buckets = make_buckets(ref, q, table, p, n);
+    std::vector<char> qfast(nq, 0), qfloat(nq, 0);
+    std::vector<int64_t> qchunk(nq, 0), qwarm(nq, 0);
+    bool any_fast = false;
+    for (Bucket &b : buckets) { b.fast = bucket_fast_ok(ref, table, b, n, p); any_fast |= b.fast; }
+    if (any_fast) {
+      const std::vector<Range> ranges{rg};
+      int rc = score_begin(ctx, q, ranges, table);
+      if (rc) return rc;
+      for (Bucket &b : buckets) {
+        if (!b.fast) continue;
+        rc = score_launch(ctx, ref, q, ranges, p, table, b);
+        if (rc) return rc;
+        for (int k = 0; k < b.count; ++k) {
+          const int id = q.order[b.first + k];
+          qfast[id] = 1; qchunk[id] = b.sub_len; qwarm[id] = b.warm; qfloat[id] = sem_is_float(b.sem);
+        }
+      }
+      std::vector<unsigned long long> keys;
+      rc = score_fetch(ctx, nq, keys);
+      if (rc) return rc;
+      HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+      rc = locate_fast(ctx, ref, q, rg, p, qfast, qchunk, qwarm, qfloat, keys.data(), table, loc);
+      if (rc) return rc;
+      HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+      ctx->timings[1] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
+      if (want_trace) {
+        std::vector<int> fq;
+        std::vector<Located> floc;
+        for (size_t k = 0; k < nq; ++k) if (qfast[k]) { fq.push_back((int)k); floc.push_back(loc[k]); }
+        std::vector<TraceOut> ft;
+        HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+        rc = trace_located(ctx, ref, q, rg, p, qwarm, table, fq, floc, ft);
+        if (rc) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+        ctx->timings[2] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
+        for (size_t t = 0; t < fq.size(); ++t) tout[fq[t]] = ft[t];
+      }
+    }
+    std::vector<int> slow;
+    for (size_t k = 0; k < nq; ++k) if (!qfast[k]) slow.push_back((int)k);
+    if (!slow.empty()) {
+      std::vector<Located> sl;
+      std::vector<TraceOut> st;
+      HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+      int rc = exact_full(ctx, ref, q, rg, p, slow, want_trace, sl, st);
+      if (rc) {
+        if (!table.ok && ctx->err.find("outside its coverage") != std::string::npos) ctx->err += " (" + table.why + ")";
+        return rc;
+      }
+      HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+      ctx->timings[2] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
+      for (size_t t = 0; t < slow.size(); ++t) { loc[slow[t]] = sl[t]; tout[slow[t]] = st[t]; }
+    }
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+  ctx->timings[3] += elapsed_us(ctx, ctx->ev[4], ctx->ev[5]);
+  HostTrace trace_results("set_results");
+  for (size_t k = 0; k < nq; ++k) {
+    set_result(outs[k], loc[k].score, loc[k].ix, loc[k].iy, (want_trace && loc[k].score > 0) ? &tout[k] : nullptr);
+    outs[k].timings_us[0] = (float)(ctx->timings[0] > 0 ? ctx->timings[0] : ctx->timings[3]);
+    outs[k].timings_us[1] = 0;
+  }
+  return 0;
+}
+
+// Per-range maxima of every query (value half of find_index_of_maximum per piece).
+int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const std::vector<Range> &ranges,
+                 const mi355_sw_params &p, float *maxima /* [nranges][nq] */) {
+  const size_t nq = q.nq, nr = ranges.size();
+  if (nq == 0 || nr == 0) return 0;
+  const ScoreTable table = plan_table(ref, p);
+  int64_t maxn = 0;
+  for (auto &r : ranges) maxn = std::max(maxn, r.hi - r.lo);
+  std::vector<Bucket> buckets = make_buckets(ref, q, table, p, maxn);
+  std::vector<char> qfast(nq, 0), qfloat(nq, 0);
+  for (Bucket &b : buckets) {
+    b.fast = true;
+    for (auto &r : ranges) b.fast = b.fast && bucket_fast_ok(ref, table, b, r.hi - r.lo, p);
+  }
+  for (size_t lo = 0; lo < nr; lo += 32768) {
+    const size_t hi = std::min(nr, lo + 32768);
+    const std::vector<Range> sub(ranges.begin() + lo, ranges.begin() + hi);
+    bool any = false;
+    for (Bucket &b : buckets) any |= b.fast;
+    if (!any) break;
+    int rc = score_begin(ctx, q, sub, table);
+    if (rc) return rc;
+    for (Bucket &b : buckets) {
+      if (!b.fast) continue;
+      rc = score_launch(ctx, ref, q, sub, p, table, b);
+      if (rc) return rc;
+      for (int k = 0; k < b.count; ++k) { qfast[q.order[b.first + k]] = 1; qfloat[q.order[b.first + k]] = sem_is_float(b.sem); }
+    }
+    std::vector<unsigned long long> keys;
+    rc = score_fetch(ctx, nq * sub.size(), keys);
+    if (rc) return rc;
+    for (size_t r = 0; r < sub.size(); ++r)
+      for (size_t k = 0; k < nq; ++k)
+        if (qfast[k]) {
+          const uint32_t hi32 = (uint32_t)(keys[r * nq + k] >> 32);
+          float v;
+          if (qfloat[k]) memcpy(&v, &hi32, 4); else v = (float)hi32;
+          maxima[(lo + r) * nq + k] = v;
+        }
+  }
+  std::vector<int> slow;
+  for (size_t k = 0; k < nq; ++k) if (!qfast[k]) slow.push_back((int)k);
+  for (size_t r = 0; r < nr && !slow.empty(); ++r) {
+    std::vector<Located> loc;
+    std::vector<TraceOut> t;
+    int rc = exact_full(ctx, ref, q, ranges[r], p, slow, false, loc, t);
+    if (rc) return rc;
+    for (size_t i = 0; i < slow.size(); ++i) maxima[r * nq + slow[i]] = loc[i].score;
+  }
+  return 0;
+}
+
+int check_params(mi355_sw_ctx *ctx, const mi355_sw_params *p) {
+  if (!ctx) return MI355_SW_EINVAL;
+  if (!p) return fail(ctx, MI355_SW_EINVAL, "params is NULL");
+  if (p->semantics != MI355_SW_F32 && p->semantics != MI355_SW_U8SAT) return fail(ctx, MI355_SW_EINVAL, "unknown semantics");
+  return 0;
+}
+
+void reset_timings(mi355_sw_ctx *ctx) { for (double &t : ctx->timings) t = 0; ctx->score_ev_used = 0; }
+
+}  // namespace

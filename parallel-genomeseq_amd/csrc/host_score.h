@@ -1,0 +1,368 @@
+// host_score.h — score pass: score table, length buckets, tile geometry, sw_score_kernel launches
+// Part of the single translation unit mi355_sw.hip (included there, in order; not a standalone header).
+namespace {
+
+// ---- what the packed 16-bit score kernel covers --------------------------------------------
+// Score table shared by every launch of a call: which (params, reference alphabet) the packed 16-bit
+// kernel can represent exactly.
+struct ScoreTable {
+  bool ok = false;            // some score-kernel instance can represent (params, alphabet) exactly
+  bool integral = false;      // the packed 16-bit instances can
+  std::string why;
+  int gap = 0, smax = 0;      // packed instances
+  float gapf = 0, smaxf = 0;  // float32 instance
+  std::vector<int16_t> stab;  // [256][ncodes]
+  std::vector<float> ftab;    // [256][ncodes]
+};
+
+// A run of length-sorted queries swept by one kernel instance.
+struct Bucket {
+  int first = 0, count = 0;   // positions in QueryBatch::order
+  int maxlen = 0;
+  int R = 0;
+  int SL = 16;                // lanes per tile: 16, or 8 where 8*R rows fit the reads more tightly
+  int sem = kSemI16;          // kernel instance: kSemI16 / kSemU8 packed pairs, kSemF32 one query per slot
+  bool strips = false;        // queries longer than one 512-row strip
+  bool twin = false;          // lone long query: two tiles of it per packed register (sw_score_kernel TWIN)
+  int64_t warm = 0;           // exactness margin in columns
+  bool fast = false;          // swept by the score kernel (else whole-matrix exact path)
+  int64_t chunk_len = 0;      // own columns per tile
+  int64_t sub_len = 0;        // granularity at which tile maxima are reported (= what locate re-runs)
+};
+
+int pick_R(int maxlen) {
+  static const int rs[] = {2, 4, 6, 8, 10, 12, 16, 20, 24, 32};
+  const int need = (maxlen + 15) / 16;
+  for (int r : rs) if (r >= need) return r;
+  return 0;
+}
+
+// 8-lane tiles: instances for the common short-read lengths (<= 56, 80, 104, 128, 152, 208, 256 rows)
+int pick_R8(int maxlen) {
+  static const int rs[] = {7, 10, 13, 16, 19, 26, 32};
+  const int need = (maxlen + 7) / 8;
+  for (int r : rs) if (r >= need) return r;
+  return 0;
+}
+
+// (SL, R) with the fewest padded rows; ties go to 8 lanes (fewer per-step overhead ops per cell)
+void pick_shape(int len, int &SL, int &R) {
+  SL = 16; R = len < 1 ? 2 : pick_R(len);
+  const int r8 = len < 36 ? 0 : pick_R8(len);
+  if (r8 && 8 * r8 <= 16 * R) { SL = 8; R = r8; }
+  if (const char *e = std::getenv("MI355_SW_SLOT")) { if (std::atoi(e) == 16) { SL = 16; R = len < 1 ? 2 : pick_R(len); } }   // tuning aid
+}
+
+ScoreTable plan_table(const RefData &ref, const mi355_sw_params &p) {
+  ScoreTable f;
+  const int nc = ref.ncodes;
+  f.stab.assign((size_t)256 * nc, (int16_t)kPadScore);
+  if (p.semantics == MI355_SW_U8SAT) {
+    const U8Params u = u8_params(p);
+    if (u.G < 1) { f.why = "gap penalty saturates to 0: no finite warm-up margin"; return f; }
+    f.ftab.assign((size_t)256 * nc, kPadScoreF);
+    for (int a = 0; a < 256; ++a)
+      for (int c = 0; c < nc - 1; ++c) {
+        const int v = (uint8_t)a == ref.byte_of[c] ? u.M : -u.X;
+        f.stab[(size_t)a * nc + c] = (int16_t)v;
+        f.ftab[(size_t)a * nc + c] = (float)v;
+      }
+    f.gap = u.G; f.smax = u.M;
+    f.gapf = (float)u.G; f.smaxf = (float)u.M;
+    f.integral = true;
+  } else {
+    const float g = p.gap;
+    if (!(g > 0.0f) || !std::isfinite(g)) { f.why = "gap penalty is not positive: no finite warm-up margin"; return f; }
+    f.ftab.assign((size_t)256 * nc, kPadScoreF);
+    bool integral = g >= 1.0f && g == std::floor(g) && g <= 8000;
+    float smaxf = 0;
+    for (int a = 0; a < 256; ++a)
+      for (int c = 0; c < nc - 1; ++c) {
+        const float s = lut_or(p, (uint8_t)a, ref.byte_of[c]);
+        if (!std::isfinite(s) || std::fabs(s) > 1e6f) { f.why = "substitution score out of range"; return f; }
+        f.ftab[(size_t)a * nc + c] = s;
+        smaxf = std::max(smaxf, s);
+        if (s != std::floor(s) || std::fabs(s) > 8000) integral = false;
+        else f.stab[(size_t)a * nc + c] = (int16_t)s;
+      }
+    f.gapf = g; f.smaxf = smaxf;
+    f.integral = integral;
+    if (integral) { f.gap = (int)g; f.smax = (int)smaxf; }
+  }
+  f.ok = true;
+  return f;
+}
+
+size_t profile_lds_bytes(int ncodes, int R, int SL = 16, bool twin = false) {
+  return (size_t)ncodes * (size_t)std::max(16, SL) * lane_stride(twin ? R / 2 : R) * 4;
+}
+
+// Length classes of the batch: one bucket per kernel instance (R), plus one strip-mined bucket.
+std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const ScoreTable &t, const mi355_sw_params &p, int64_t n) {
+  std::vector<Bucket> out;
+  // queries beyond 512 rows: whole-wavefront tiles (64 lanes x R rows: one strip up to 2048 rows, 2048-row
+  // strips beyond) when the 64-position profile fits LDS, else 16-lane tiles in 512-row strips
+  const bool wide_ok = profile_lds_bytes(ref.ncodes, 32, 64) <= kProfileLdsMax && std::getenv("MI355_SW_NO_WIDE") == nullptr;
+  for (size_t pos = 0; pos < q.nq; ++pos) {
+    const int len = q.len[q.order[pos]];
+    bool strips = false;
+    int SL = 16, R = 32;
+    if (len <= kMaxRowsFast) pick_shape(len, SL, R);
+    else if (wide_ok) { SL = 64; R = len <= 1024 ? 16 : 32; strips = len > 2048; }
+    else strips = true;
+    if (out.empty() || out.back().R != R || out.back().SL != SL || out.back().strips != strips) {
+      Bucket b;
+      b.first = (int)pos; b.R = R; b.SL = SL; b.strips = strips;
+      out.push_back(b);
+    }
+    out.back().count++;
+    out.back().maxlen = std::max(out.back().maxlen, len);
+  }
+  for (Bucket &b : out) {
+    const bool twin_ok = b.count == 1 && b.SL == 64 && std::getenv("MI355_SW_NO_TWIN") == nullptr;
+    if (p.semantics == MI355_SW_U8SAT) {
+      // lone query: two of its tiles per packed register on whole-wavefront tiles, else one query per register
+      b.twin = twin_ok;
+      b.sem = b.count == 1 && !b.twin ? kSemF32U8 : kSemU8;
+    } else {
+      // packed 16-bit cells when scores are small integers and the score bound fits; float32 cells otherwise
+      const bool fits = t.integral && (int64_t)t.smax * std::min<int64_t>(b.maxlen, std::max<int64_t>(n, 1)) + t.smax <= 32000;
+      b.sem = fits ? kSemI16 : kSemF32;
+      // a lone query would fill both halves of every packed register with itself; the float32 instance
+      // (one query per slot, exact for integer scores below 2^24) sweeps it ~1.5x faster
+      if (b.count == 1 && b.sem == kSemI16) {
+        if (twin_ok) b.twin = true;                               // long lone query: two of its tiles per register
+        else if ((double)t.smax * b.maxlen < 1.6e7) b.sem = kSemF32;
+      }
+    }
+    const double smax = sem_is_float(b.sem) ? (double)t.smaxf : (double)t.smax;
+    const double gap = sem_is_float(b.sem) ? (double)t.gapf : (double)t.gap;
+    if (smax <= 0 || gap <= 0) b.warm = 0;
+    else b.warm = (int64_t)b.maxlen + (int64_t)std::ceil(smax * b.maxlen / gap);
+    b.warm = (b.warm + 63) / 64 * 64;
+  }
+  return out;
+}
+
+// May this bucket's queries be swept by the score kernel over a reference range of n columns?
+bool bucket_fast_ok(const RefData &ref, const ScoreTable &t, const Bucket &b, int64_t n, const mi355_sw_params &p) {
+  if (!t.ok || n < 1 || b.maxlen < 1) return false;
+  if (profile_lds_bytes(ref.ncodes, b.R, b.SL) > kProfileLdsMax) return false;  // alphabet too large for this shape
+  // the uint8 engine's storage order is only bounded to a few tiles when the reference is the longer side;
+  // shorter references take the whole-matrix path (which also holds the |x| == |y| quirk)
+  if (p.semantics == MI355_SW_U8SAT && n <= (int64_t)b.maxlen + 1) return false;
+  // float32 cells stay exact integers only below 2^24
+  if (b.sem == kSemF32 && t.integral && (double)t.smax * (double)std::min<int64_t>(b.maxlen, n) > 1.6e7) return false;
+  // the warm-up margin must stay a small fraction of the range (tiny gap penalties)
+  if (b.warm > 64 * (int64_t)b.maxlen + 1024) return false;
+  // strip-mining re-streams the range once per 512 rows: only worth it on long ranges
+  if (b.strips && n < 4096) return false;
+  // short references (UniProt shape: many sequences against one 144-residue query): one whole-matrix
+  // pass of the exact kernel does score + argmax + decisions at once; the tile machinery would idle
+  if (n < 1024) return false;
+  return true;
+}
+
+template <class K>
+void launch_score(K kernel, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
+  // large alphabets x many rows per lane need more than the default 64 KiB of dynamic LDS
+  if (shmem > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  hipLaunchKernelGGL(kernel, grid, dim3(256), shmem, st, a);
+}
+
+template <int SEM>
+int launch_score_twin(int R, bool strips, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
+  if (strips) {
+    if (R != 32) return -1;
+    launch_score(sw_score_kernel<32, SEM, true, 64, true>, grid, shmem, st, a);
+    return 0;
+  }
+  if (R == 16) launch_score(sw_score_kernel<16, SEM, false, 64, true>, grid, shmem, st, a);
+  else if (R == 32) launch_score(sw_score_kernel<32, SEM, false, 64, true>, grid, shmem, st, a);
+  else return -1;
+  return 0;
+}
+
+template <int SEM>
+int launch_score_R(int R, int SL, bool strips, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
+  if (strips) {
+    if (R != 32) return -1;
+    if (SL == 64) launch_score(sw_score_kernel<32, SEM, true, 64>, grid, shmem, st, a);
+    else if (SL == 16) launch_score(sw_score_kernel<32, SEM, true, 16>, grid, shmem, st, a);
+    else return -1;
+    return 0;
+  }
+  if (SL == 64) {
+    if (R == 16) launch_score(sw_score_kernel<16, SEM, false, 64>, grid, shmem, st, a);
+    else if (R == 32) launch_score(sw_score_kernel<32, SEM, false, 64>, grid, shmem, st, a);
+    else return -1;
+    return 0;
+  }
+  if (SL == 8) {
+    switch (R) {
+#define CASE_R8(r) case r: launch_score(sw_score_kernel<r, SEM, false, 8>, grid, shmem, st, a); return 0;
+      CASE_R8(7) CASE_R8(10) CASE_R8(13) CASE_R8(16) CASE_R8(19) CASE_R8(26) CASE_R8(32)
+#undef CASE_R8
+    }
+    return -1;
+  }
+  switch (R) {
+#define CASE_R(r) case r: launch_score(sw_score_kernel<r, SEM, false>, grid, shmem, st, a); return 0;
+    CASE_R(2) CASE_R(4) CASE_R(6) CASE_R(8) CASE_R(10) CASE_R(12) CASE_R(16) CASE_R(20) CASE_R(24) CASE_R(32)
+#undef CASE_R
+  }
+  return -1;
+}
+
+int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int SL = 16, bool twin = false, int maxlen = 0) {
+  int64_t cl = 65536;
+  while (cl < 8 * warm) cl *= 2;                 // long queries: keep the warm-up redundancy bounded
+  // fill the chip: 256 CUs x 32 waves x 4 slots; shrink tiles while they stay >> warm-up
+  while (cl > 2048 && cl / 2 >= 4 * warm &&
+         (double)npairs * (double)((max_range_len + cl - 1) / cl) < 65536.0) cl /= 2;
+  // few tiles (one long query): filling the SIMDs beats the warm-up redundancy down to cl == warm
+  // (measured, 10 kbp x 250 Mbp: 1.17 s at 131 k columns, 0.58 s at 32 k; profiles/r01_config5*.log)
+  const double few = (SL == 64 ? 1536.0 : 8192.0) * (twin ? 2.0 : 1.0);   // a 64-lane tile is a wavefront of its own (two tiles with twin)
+  while (cl / 2 >= std::max<int64_t>(warm, 2048) &&
+         (double)npairs * (double)((max_range_len + cl - 1) / cl) < few) cl /= 2;
+  // tiny problems (one read against a short reference): the call's latency is one tile's sweep and the chip is
+  // mostly idle, so tiles shrink until every CU has a workgroup (down to one sub-chunk: >= 256 columns, >= |x|)
+  int64_t floor_cl = 256;
+  while (floor_cl < maxlen) floor_cl *= 2;
+  const double per_wg = 256.0 / SL * (twin ? 2.0 : 1.0);
+  while (cl / 2 >= floor_cl && (double)npairs * (double)((max_range_len + cl - 1) / cl) / per_wg < 256.0) cl /= 2;
+  if (const char *e = std::getenv("MI355_SW_CHUNK")) { const long v = std::atol(e); if (v >= 256) cl = v / 64 * 64; }   // tuning aid
+  return cl;
+}
+
+// Uploads what every score launch of a call shares and clears the keys.
+int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range> &ranges, const ScoreTable &t) {
+  const size_t nq = q.nq, nr = ranges.size();
+  if (nr > 32768) return fail(ctx, MI355_SW_ENOTSUP, "more than 32768 ranges per launch");
+  // the previous call's copies out of these host vectors have completed: every call ends synchronised
+  std::vector<int64_t> &rl = ctx->h_ranges;
+  rl.resize(2 * nr);
+  for (size_t k = 0; k < nr; ++k) { rl[k] = ranges[k].lo; rl[nr + k] = ranges[k].hi; }
+  const void *stab_was = ctx->stab.p, *ftab_was = ctx->ftab.p;
+  if (ctx->ranges.ensure(rl.size() * 8) || ctx->keys.ensure(nq * nr * 8) || ctx->stab.ensure(t.stab.size() * 2) ||
+      ctx->ftab.ensure(t.ftab.size() * 4 + 16))
+    return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
+  HIPCHK(ctx, hipMemcpyAsync(ctx->ranges.p, rl.data(), rl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->stab.p != stab_was || ctx->h_stab != t.stab) {
+    ctx->h_stab = t.stab;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stab.p, ctx->h_stab.data(), ctx->h_stab.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (!t.ftab.empty() && (ctx->ftab.p != ftab_was || ctx->h_ftab != t.ftab)) {
+    ctx->h_ftab = t.ftab;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ftab.p, ctx->h_ftab.data(), ctx->h_ftab.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, nq * nr * 8, ctx->stream));
+  return 0;
+}
+
+// One score-kernel launch: bucket b over all ranges.  Device time is added to ctx->timings[0].
+int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const std::vector<Range> &ranges,
+                 const mi355_sw_params &p, const ScoreTable &t, Bucket &b) {
+  HostTrace trace_("score_launch");
+  const size_t nr = ranges.size();
+  int64_t maxlen = 0;
+  for (auto &r : ranges) maxlen = std::max(maxlen, r.hi - r.lo);
+  const size_t npairs = (sem_is_float(b.sem) || b.twin) ? (size_t)b.count : ((size_t)b.count + 1) / 2;   // queries per workgroup: 1 or 2
+  b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm, b.SL, b.twin, b.maxlen);
+  // report maxima per sub-chunk of >= 256 columns (>= query length, so that the uint8 storage order stays
+  // within two neighbouring sub-chunks): that is what locate re-runs; the strip-mined instance reports per tile
+  b.sub_len = 256;
+  while (b.sub_len < b.maxlen) b.sub_len *= 2;
+  if (b.strips) while (b.chunk_len / b.sub_len > 64) b.sub_len *= 2;      // the strip-mined instances keep <= 64 sub-chunk maxima in LDS
+  if (b.sub_len > b.chunk_len || b.chunk_len % b.sub_len != 0) b.sub_len = b.chunk_len;
+  const int64_t cpr = (maxlen + b.chunk_len - 1) / b.chunk_len;
+  const int nslot = 256 / b.SL;                                     // tiles (twin: tile pairs) per workgroup
+  const int64_t cgroups = ((b.twin ? (cpr + 1) / 2 : cpr) + nslot - 1) / nslot;
+  if ((double)npairs * (double)cgroups > 2.0e9) return fail(ctx, MI355_SW_ENOTSUP, "grid too large");
+
+  ScoreArgs a;
+  a.refcodes = ref.codes.as<uint8_t>();
+  a.ref_len = (int64_t)ref.n;
+  a.range_lo = ctx->ranges.as<int64_t>();
+  a.range_hi = ctx->ranges.as<int64_t>() + nr;
+  a.chunk_len = b.chunk_len;
+  a.sub_len = b.sub_len;
+  a.warm = (cpr == 1) ? 0 : b.warm;              // a single tile per range starts at the range's own border
+  a.chunks_per_range = (int)cpr;
+  a.qbytes = q.bytes.as<uint8_t>();
+  a.qoff = q.offs.as<int64_t>();
+  a.qlen = q.lens.as<int32_t>();
+  a.qsel = q.sel.as<int32_t>();
+  a.qfirst = b.first;
+  a.qcount = b.count;
+  a.nq = (int)q.nq;
+  a.stab = sem_is_float(b.sem) ? ctx->ftab.p : ctx->stab.p;
+  a.ncodes = ref.ncodes;
+  if (sem_is_float(b.sem)) memcpy(&a.gap2, &t.gapf, 4);
+  else a.gap2 = (uint32_t)t.gap * 0x00010001u;
+  a.clamp2 = 255u * 0x00010001u;
+  a.keys = ctx->keys.as<unsigned long long>();
+
+  const int nqw = (sem_is_float(b.sem) || b.twin) ? 1 : 2;          // queries per workgroup
+  // keep single launches to a few seconds: split the bucket's pairs over several launches
+  double range_cols = 0;
+  for (auto &r : ranges) range_cols += (double)(r.hi - r.lo);
+  const double cells_per_pair = (double)nqw * std::max(1, b.maxlen) * std::max(1.0, range_cols);
+  const size_t pairs_per_launch = (size_t)std::max(1.0, std::min((double)npairs, 5.0e13 / cells_per_pair));
+  for (size_t p0 = 0; p0 < npairs; p0 += pairs_per_launch) {
+  const size_t pn = std::min(pairs_per_launch, npairs - p0);
+  a.qfirst = b.first + (int)(p0 * nqw);
+  a.qcount = std::min(b.count - (int)(p0 * nqw), (int)(pn * nqw));
+  size_t shmem = profile_lds_bytes(ref.ncodes, b.R, b.SL, b.twin) + (size_t)(b.twin ? 2 : 1) * nslot * codebuf_bytes(b.SL);
+  dim3 grid((unsigned)(pn * cgroups), (unsigned)nr);
+  a.brow = nullptr;
+  a.brow_stride = 0;
+  if (b.strips) {
+    const int64_t nseg = (a.warm + b.chunk_len + b.SL + kSeg - 1) / kSeg;
+    a.brow_stride = (nseg + 3) * kSeg + kBrowFront + 32;
+    const size_t slots = (size_t)grid.x * grid.y * nslot;
+    const size_t bytes = slots * 2 * (size_t)a.brow_stride * 4;
+    if (bytes > ((size_t)64 << 30)) return fail(ctx, MI355_SW_ENOTSUP, "strip-mined sweep needs more than 64 GiB of boundary scratch");
+    if (ctx->brow.ensure(bytes)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(strip boundary rows) failed");
+    HIPCHK(ctx, hipMemsetAsync(ctx->brow.p, 0, bytes, ctx->stream));
+    a.brow = ctx->brow.as<uint32_t>();
+    shmem += (size_t)2 * nslot * kSeg * 4 + (size_t)nslot * 64 * 4;   // boundary windows + per-sub-chunk maxima
+  }
+  if (ctx->score_ev.size() < ctx->score_ev_used + 2) {
+    for (int e = 0; e < 2; ++e) { hipEvent_t ev; HIPCHK(ctx, hipEventCreate(&ev)); ctx->score_ev.push_back(ev); }
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->score_ev[ctx->score_ev_used], ctx->stream));
+  int rc = b.twin ? (b.sem == kSemU8 ? launch_score_twin<kSemU8>(b.R, b.strips, grid, shmem, ctx->stream, a)
+                                     : launch_score_twin<kSemI16>(b.R, b.strips, grid, shmem, ctx->stream, a))
+           : b.sem == kSemU8 ? launch_score_R<kSemU8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
+           : b.sem == kSemF32U8 ? launch_score_R<kSemF32U8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
+           : b.sem == kSemF32 ? launch_score_R<kSemF32>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
+                              : launch_score_R<kSemI16>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a);
+  if (rc) return fail(ctx, MI355_SW_ENOTSUP, "no score kernel instance for this R");
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipEventRecord(ctx->score_ev[ctx->score_ev_used + 1], ctx->stream));
+  ctx->score_ev_used += 2;                                // read by score_fetch, after the launches have drained
+  ctx->timings[4] += 1;
+  }
+  double cells = 0;
+  for (int k = 0; k < b.count; ++k)
+    for (auto &r : ranges) cells += (double)q.len[q.order[b.first + k]] * (double)(r.hi - r.lo);
+  ctx->timings[5] += cells;
+  return 0;
+}
+
+int score_fetch(mi355_sw_ctx *ctx, size_t count, std::vector<unsigned long long> &keys) {
+  keys.resize(count);
+  HIPCHK(ctx, hipMemcpyAsync(keys.data(), ctx->keys.p, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t e = 0; e + 1 < ctx->score_ev_used; e += 2) {     // device time of the score launches
+    float ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->score_ev[e], ctx->score_ev[e + 1]));
+    ctx->timings[0] += (double)ms * 1000.0;
+  }
+  ctx->score_ev_used = 0;
+  return 0;
+}
+
+}  // namespace

@@ -1,0 +1,364 @@
+// host_wave.h — register-wavefront exact kernels: sw_wave_kernel (short sides), sw_strip_kernel (long queries), their walks
+// Part of the single translation unit mi355_sw.hip (included there, in order; not a standalone header).
+namespace {
+
+// ---- wavefront exact kernel (sw_wave_kernel.h): small problems, identity scoring ---------------
+constexpr int kWaveMaxLanesSide = 512;
+
+// Scoring the wave kernel evaluates: no table, and penalties that strictly lower a path (so that padding cells
+// can never reach the maximum).
+bool wave_scoring_ok(const mi355_sw_params &p) {
+  if (p.semantics == MI355_SW_U8SAT) { const U8Params u = u8_params(p); return u.M > 0; }
+  return p.lut == nullptr && p.match > 0 && p.mismatch < 0 && p.gap > 0 && std::isfinite(p.match) &&
+         std::isfinite(p.mismatch) && std::isfinite(p.gap);
+}
+
+// rows per lane of the wave kernel instance that covers `na` cells on the lane side, and its decision bytes
+int wave_R(int na) { return na <= 160 ? 10 : (na <= 320 ? 20 : 32); }
+size_t wave_dirs_bytes(int64_t nb, int R) { return (size_t)nb * 16 * (size_t)((R + 15) / 16) * 4 + 64; }
+
+struct WaveJob {
+  int q;                  // query index
+  int orient;             // 0: lanes = rows of x, stream = columns of y; 1: lanes = columns of y, stream = rows of x
+  int64_t s_lo;           // stream window start (0-based, range-relative), nb positions
+  int32_t nb;
+  bool track, dirs;
+  bool keyed = false;     // wave kernel, track: first cell equal to target in storage order (else: first maximum)
+  float target = 0;       // strip kernel / keyed: only cells equal to target compete ...
+  int32_t own_lo = 0;     // ... at stream positions >= own_lo (0-based)
+  // results
+  float best = 0;
+  int64_t ci = 0, cj = 0;
+  size_t dirs_off = 0;
+};
+
+template <int R, int ORIENT, bool U8>
+void launch_wave_flags(bool track, bool dirs, unsigned blocks, hipStream_t st, const WaveProblem *pr, int n, const WaveScoring &sc) {
+  if (track && dirs) hipLaunchKernelGGL((sw_wave_kernel<R, ORIENT, U8, true, true>), dim3(blocks), dim3(256), 0, st, pr, n, sc);
+  else if (track) hipLaunchKernelGGL((sw_wave_kernel<R, ORIENT, U8, true, false>), dim3(blocks), dim3(256), 0, st, pr, n, sc);
+  else hipLaunchKernelGGL((sw_wave_kernel<R, ORIENT, U8, false, true>), dim3(blocks), dim3(256), 0, st, pr, n, sc);
+}
+
+template <int R>
+void launch_wave_keyed(bool u8, unsigned blocks, hipStream_t st, const WaveProblem *pr, int n, const WaveScoring &sc) {
+  if (u8) hipLaunchKernelGGL((sw_wave_kernel<R, 0, true, true, false, true>), dim3(blocks), dim3(256), 0, st, pr, n, sc);
+  else hipLaunchKernelGGL((sw_wave_kernel<R, 0, false, true, false, true>), dim3(blocks), dim3(256), 0, st, pr, n, sc);
+}
+
+template <int R>
+void launch_wave_R(int orient, bool u8, bool track, bool dirs, unsigned blocks, hipStream_t st, const WaveProblem *pr, int n, const WaveScoring &sc) {
+  if (orient == 0) { if (u8) launch_wave_flags<R, 0, true>(track, dirs, blocks, st, pr, n, sc); else launch_wave_flags<R, 0, false>(track, dirs, blocks, st, pr, n, sc); }
+  else { if (u8) launch_wave_flags<R, 1, true>(track, dirs, blocks, st, pr, n, sc); else launch_wave_flags<R, 1, false>(track, dirs, blocks, st, pr, n, sc); }
+}
+
+// One launch: all jobs share orientation and flags; lanes side <= 512.
+int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg, const mi355_sw_params &p,
+             std::vector<WaveJob> &jobs) {
+  HostTrace trace_("run_wave");
+  const size_t n = jobs.size();
+  if (n == 0) return 0;
+  const int orient = jobs[0].orient;
+  const bool track = jobs[0].track, dirs = jobs[0].dirs;
+  const int64_t nref = rg.hi - rg.lo;
+  size_t dirs_total = 0;
+  int maxna = 0;
+  for (WaveJob &j : jobs) maxna = std::max(maxna, orient == 0 ? q.len[j.q] : (int)nref);
+  if (maxna > kWaveMaxLanesSide) return fail(ctx, MI355_SW_EINVAL, "internal: wave kernel side too long");
+  const int R = wave_R(maxna);
+  for (WaveJob &j : jobs)
+    if (dirs) { j.dirs_off = dirs_total; dirs_total += wave_dirs_bytes(j.nb, R); }
+  if (ctx->wprobs.ensure(n * sizeof(WaveProblem)) || ctx->outs_f.ensure(n * 4) || ctx->outs_i.ensure(n * 16) ||
+      (dirs_total && ctx->dirs.ensure(dirs_total)))
+    return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(wave scratch) failed");
+  std::vector<WaveProblem> pr(n);
+  for (size_t k = 0; k < n; ++k) {
+    const WaveJob &j = jobs[k];
+    WaveProblem &w = pr[k];
+    const uint8_t *xq = q.bytes.as<uint8_t>() + q.off[j.q];
+    const uint8_t *yr = ref.bytes.as<uint8_t>() + rg.lo;
+    if (orient == 0) { w.a = xq; w.na = q.len[j.q]; w.b = yr + j.s_lo; }
+    else { w.a = yr; w.na = (int32_t)nref; w.b = xq + j.s_lo; }
+    w.nb = j.nb;
+    w.b_offset = j.s_lo;
+    w.dirs = dirs ? reinterpret_cast<uint32_t *>(ctx->dirs.as<uint8_t>() + j.dirs_off) : nullptr;
+    w.best = ctx->outs_f.as<float>() + k;
+    w.cell = ctx->outs_i.as<int64_t>() + 2 * k;
+    w.target = j.target; w.own_lo = j.own_lo; w.full_n = nref;
+  }
+  const bool keyed = jobs[0].keyed;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->wprobs.p, pr.data(), n * sizeof(WaveProblem), hipMemcpyHostToDevice, ctx->stream));
+  WaveScoring sc;
+  sc.match = p.match; sc.mismatch = p.mismatch; sc.gap = p.gap;
+  const U8Params u = u8_params(p);
+  sc.u8M = (float)u.M; sc.u8X = (float)u.X; sc.u8G = (float)u.G;
+  const bool u8 = p.semantics == MI355_SW_U8SAT;
+  const unsigned blocks = (unsigned)((n + 15) / 16);
+  const WaveProblem *dp = ctx->wprobs.as<WaveProblem>();
+  if (keyed) {
+    if (R == 10) launch_wave_keyed<10>(u8, blocks, ctx->stream, dp, (int)n, sc);
+    else if (R == 20) launch_wave_keyed<20>(u8, blocks, ctx->stream, dp, (int)n, sc);
+    else launch_wave_keyed<32>(u8, blocks, ctx->stream, dp, (int)n, sc);
+  }
+  else if (R == 10) launch_wave_R<10>(orient, u8, track, dirs, blocks, ctx->stream, dp, (int)n, sc);
+  else if (R == 20) launch_wave_R<20>(orient, u8, track, dirs, blocks, ctx->stream, dp, (int)n, sc);
+  else launch_wave_R<32>(orient, u8, track, dirs, blocks, ctx->stream, dp, (int)n, sc);
+  HIPCHK(ctx, hipGetLastError());
+  if (track) {
+    std::vector<float> bf(n);
+    std::vector<int64_t> ci(2 * n);
+    HIPCHK(ctx, hipMemcpyAsync(bf.data(), ctx->outs_f.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ci.data(), ctx->outs_i.p, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t k = 0; k < n; ++k) { jobs[k].best = bf[k]; jobs[k].ci = ci[2 * k]; jobs[k].cj = ci[2 * k + 1]; }
+  }
+  return 0;
+}
+
+// Rows per lane of the strip kernel instance for a query of `na` rows, and its strips of 64*R rows (sixteen run
+// concurrently; longer queries take several rounds).
+int strip_R(int na) { return na <= 64 * kStripMaxWaves * 10 ? 10 : 16; }
+int strip_count(int na, int R) { return std::max(1, (na + 64 * R - 1) / (64 * R)); }
+size_t strip_dirs_bytes(int64_t nb, int nstrips, int R) { return (size_t)nb * 64 * (size_t)nstrips * (size_t)((R + 15) / 16) * 4 + 64; }
+
+template <int R>
+void launch_strip(bool u8, bool track, dim3 grid, dim3 block, hipStream_t st, const StripProblem *dp, const WaveScoring &sc,
+                  const float *gtab, int ncodes) {
+  if (gtab) {                                   // table scoring (float engine): tab[257][ncodes] in dynamic LDS
+    const size_t lds = (size_t)257 * ncodes * 4;
+    if (track) hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripTrack, true>), grid, block, lds, st, dp, sc, gtab, ncodes);
+    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripDirs, true>), grid, block, lds, st, dp, sc, gtab, ncodes);
+    return;
+  }
+  if (track) {
+    if (u8) hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripTrack>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0);
+    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripTrack>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0);
+  } else {
+    if (u8) hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripDirs>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0);
+    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripDirs>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0);
+  }
+}
+
+// Long queries (ORIENT 0 windows) on the pipelined strip kernel, one workgroup per job: traceback decisions
+// (jobs[.].dirs) or the first cell equal to jobs[.].target in storage order (jobs[.].track -> ci, cj; ci = 0: none).
+// The score table of general (non-identity) float scoring the strip kernel can hold in LDS next to its rings.
+bool strip_table_ok(const RefData &ref, const mi355_sw_params &p) {
+  return p.semantics == MI355_SW_F32 && (size_t)257 * ref.ncodes * 4 <= 96 * 1024;
+}
+// Which long queries the strip kernel takes: identity scoring in both engines, any table in the float engine.
+bool strip_scoring_ok(const RefData &ref, const mi355_sw_params &p) {
+  if (std::getenv("MI355_SW_NO_STRIP") != nullptr) return false;
+  return wave_scoring_ok(p) || strip_table_ok(ref, p);
+}
+
+int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg, const mi355_sw_params &p,
+              std::vector<WaveJob> &jobs, int R) {
+  HostTrace trace_("run_strip");
+  const bool use_table = !wave_scoring_ok(p);            // ctx->ftab holds plan_table()'s [256][ncodes] (score_begin)
+  const size_t n = jobs.size();
+  if (n == 0) return 0;
+  const bool track = jobs[0].track;
+  size_t dirs_total = 0, gtotal = 0;
+  int nwmax = 1;
+  std::vector<size_t> goff(n, 0);
+  for (size_t k = 0; k < n; ++k) {
+    WaveJob &j = jobs[k];
+    const int ns = strip_count(q.len[j.q], R);
+    nwmax = std::max(nwmax, std::min(ns, kStripMaxWaves));
+    if (!track) { j.dirs_off = dirs_total; dirs_total += strip_dirs_bytes(j.nb, ns, R); }
+    if (ns > kStripMaxWaves) { goff[k] = gtotal; gtotal += 2 * ((size_t)j.nb + 192); }
+  }
+  if (ctx->wprobs.ensure(n * sizeof(StripProblem)) || ctx->outs_i.ensure(n * 16) || ctx->outs_f.ensure(n * 4) ||
+      (dirs_total && ctx->dirs.ensure(dirs_total)) || (gtotal && ctx->brow.ensure(gtotal * 4)))
+    return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(strip scratch) failed");
+  std::vector<StripProblem> pr(n);
+  for (size_t k = 0; k < n; ++k) {
+    const WaveJob &j = jobs[k];
+    StripProblem &s = pr[k];
+    s.a = q.bytes.as<uint8_t>() + q.off[j.q];
+    s.na = q.len[j.q];
+    s.b = (use_table ? ref.codes.as<uint8_t>() : ref.bytes.as<uint8_t>()) + rg.lo + j.s_lo;
+    s.nb = j.nb;
+    s.nstrips = strip_count(q.len[j.q], R);
+    s.nw = std::min(s.nstrips, kStripMaxWaves);
+    s.gbound = s.nstrips > kStripMaxWaves ? ctx->brow.as<float>() + goff[k] : nullptr;
+    s.gstride = (int64_t)j.nb + 192;
+    s.dirs = track ? nullptr : reinterpret_cast<uint32_t *>(ctx->dirs.as<uint8_t>() + j.dirs_off);
+    s.target = j.target;
+    s.own_lo = j.own_lo;
+    s.col_offset = j.s_lo;
+    s.full_n = rg.hi - rg.lo;
+    s.cell = ctx->outs_i.as<int64_t>() + 2 * k;
+    s.status = ctx->outs_f.as<int32_t>() + k;
+  }
+  HIPCHK(ctx, hipMemsetAsync(ctx->outs_f.p, 0, n * 4, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->wprobs.p, pr.data(), n * sizeof(StripProblem), hipMemcpyHostToDevice, ctx->stream));
+  WaveScoring sc;
+  sc.match = p.match; sc.mismatch = p.mismatch; sc.gap = p.gap;
+  const U8Params u = u8_params(p);
+  sc.u8M = (float)u.M; sc.u8X = (float)u.X; sc.u8G = (float)u.G;
+  const bool u8 = p.semantics == MI355_SW_U8SAT;
+  const StripProblem *dp = ctx->wprobs.as<StripProblem>();
+  const dim3 grid((unsigned)n), block((unsigned)(64 * nwmax));
+  const float *gtab = use_table ? ctx->ftab.as<float>() : nullptr;
+  if (use_table && (size_t)257 * ref.ncodes * 4 > 48 * 1024) {
+    const int lds = 257 * ref.ncodes * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<10, false, kStripTrack, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<10, false, kStripDirs, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<16, false, kStripTrack, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<16, false, kStripDirs, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  }
+  if (R == 10) launch_strip<10>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes);
+  else launch_strip<16>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes);
+  HIPCHK(ctx, hipGetLastError());
+  std::vector<int32_t> st(n);
+  std::vector<int64_t> ci(2 * n);
+  HIPCHK(ctx, hipMemcpyAsync(st.data(), ctx->outs_f.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (track) HIPCHK(ctx, hipMemcpyAsync(ci.data(), ctx->outs_i.p, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t k = 0; k < n; ++k) {
+    if (st[k] != 0) return fail(ctx, MI355_SW_ENODEV, "internal: strip pipeline wait expired");
+    if (track) { jobs[k].ci = ci[2 * k]; jobs[k].cj = ci[2 * k + 1]; jobs[k].best = ci[2 * k] > 0 ? jobs[k].target : -1.0f; }
+  }
+  return 0;
+}
+
+// Traceback of located alignments with the wave kernel: decisions over a window that ends at the argmax along
+// the streamed side, grown on demand; then the greedy walk.  orient as WaveJob.
+int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg, const mi355_sw_params &p,
+               int orient, const std::vector<int> &qidx, const std::vector<Located> &loc, std::vector<TraceOut> &tout,
+               bool strips = false /* long queries: pipelined strip kernel (orient 0 only) */,
+               const ScoreTable *table = nullptr /* strips with table scoring: its smax / gap bound the margins */) {
+  HostTrace trace_("wave_trace");
+  const int64_t nref = rg.hi - rg.lo;
+  tout.assign(qidx.size(), TraceOut());
+  std::vector<size_t> todo;
+  for (size_t k = 0; k < qidx.size(); ++k) if (loc[k].score > 0) todo.push_back(k);
+  // exactness margin along the stream: a positive path ending at a stream index spans fewer than
+  // na + smax*na/g stream positions (DESIGN.md §3.3 with the roles of the two sequences as given)
+  double smax, g;
+  if (p.semantics == MI355_SW_U8SAT) { const U8Params u = u8_params(p); smax = u.M; g = u.G; }
+  else if (table != nullptr && table->ok) { smax = table->smaxf; g = table->gapf; }
+  else { smax = p.match; g = p.gap; }
+  // ... and a cell whose lane-side index is a (its path is confined to a rows / columns) is exact a + ceil(a*smax/g)
+  // positions into the window: the window needs that margin at the argmax plus room for the walk's excursions
+  // along the stream; the walk kernel checks every cell it visits
+  const float slope = g > 0 ? (float)(smax / g) : 0.0f;
+  auto lane_need = [&](int64_t a) { return a + (int64_t)std::ceil((double)a * (double)slope) + 2; };
+  std::vector<int64_t> budget(qidx.size()), warm(qidx.size());
+  for (size_t k : todo) {
+    const int64_t na = orient == 0 ? q.len[qidx[k]] : nref;
+    budget[k] = na / 8 + 64;
+    warm[k] = g > 0 ? na + (int64_t)std::ceil(smax * (double)na / g) : (int64_t)1 << 40;
+  }
+  while (!todo.empty()) {
+    std::vector<size_t> next;
+    size_t pos = 0;
+    while (pos < todo.size()) {
+      std::vector<WaveJob> jobs;
+      std::vector<size_t> owner;
+      size_t bytes = 0;
+      while (pos < todo.size() && jobs.size() < 262144) {
+        const size_t k = todo[pos];
+        const int qi = qidx[k];
+        const int64_t na = orient == 0 ? q.len[qi] : nref;
+        const int64_t s_end = orient == 0 ? loc[k].iy : loc[k].ix;   // 1-based stream index of the argmax
+        const int64_t a_end = orient == 0 ? loc[k].ix : loc[k].iy;   // lane-side index of the argmax
+        const int64_t wl = std::max<int64_t>(0, s_end - (budget[k] + std::min(warm[k], lane_need(a_end))));
+        const int64_t nb = s_end - wl;
+        const size_t need = strips ? strip_dirs_bytes(nb, strip_count((int)na, 10), 10)
+                                   : wave_dirs_bytes(nb, 32);      // upper bound whatever instance the group gets
+        if (need > kDirsBudget) return fail(ctx, MI355_SW_ENOTSUP, "traceback window exceeds the device scratch budget");
+        if (!jobs.empty() && bytes + need > kDirsBudget) break;
+        WaveJob j;
+        j.q = qi; j.orient = orient; j.s_lo = wl; j.nb = (int32_t)nb; j.track = false; j.dirs = true;
+        jobs.push_back(j); owner.push_back(k);
+        bytes += need;
+        ++pos;
+      }
+      int gmax = 0;
+      for (const WaveJob &j : jobs) gmax = std::max(gmax, orient == 0 ? q.len[j.q] : (int)nref);
+      const int groupR = strips ? strip_R(gmax) : wave_R(gmax);     // the instance this group runs on
+      int rc = strips ? run_strip(ctx, ref, q, rg, p, jobs, groupR) : run_wave(ctx, ref, q, rg, p, jobs);
+      if (rc) return rc;
+      // walk: measure, lay out, write (only the bytes that exist are copied back)
+      const size_t n = jobs.size();
+      std::vector<WaveWalk> wp(n);
+      if (ctx->walkp.ensure(n * sizeof(WaveWalk) + n * 24 + n * 8 + 64))
+        return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(walk scratch) failed");
+      int64_t *wout = reinterpret_cast<int64_t *>(ctx->walkp.as<uint8_t>() + n * sizeof(WaveWalk));
+      int64_t *woffs = wout + 3 * n;
+      for (size_t t = 0; t < n; ++t) {
+        const WaveJob &j = jobs[t];
+        const size_t k = owner[t];
+        WaveWalk &w = wp[t];
+        const int na = orient == 0 ? q.len[j.q] : (int)nref;
+        w.x = q.bytes.as<uint8_t>() + q.off[j.q];
+        w.y = ref.bytes.as<uint8_t>() + rg.lo;
+        w.dirs = reinterpret_cast<const uint32_t *>(ctx->dirs.as<uint8_t>() + j.dirs_off);
+        w.na = na;
+        w.nb = j.nb;
+        w.orient = orient;
+        w.R = groupR;
+        w.lanes = strips ? 64 * strip_count(na, groupR) : 16;
+        w.need_slope = slope;
+        w.b_offset = j.s_lo;
+        w.start_i = loc[k].ix; w.start_j = loc[k].iy;
+        w.exact_from = j.s_lo == 0 ? 0 : j.s_lo + warm[k];
+        w.cap = na + j.nb + 2;                                      // a walk inside the window emits <= na + nb pairs
+        w.out = wout + 3 * t;
+      }
+      HIPCHK(ctx, hipMemcpyAsync(ctx->walkp.p, wp.data(), n * sizeof(WaveWalk), hipMemcpyHostToDevice, ctx->stream));
+      const unsigned wblocks = (unsigned)((n + 63) / 64);
+      std::vector<int64_t> wo(3 * n), offs(n);
+      std::vector<char> cons;
+      size_t captot = 0;
+      for (size_t t = 0; t < n; ++t) captot += 2 * (size_t)wp[t].cap;
+      const bool one_pass = n <= 4096 && captot <= ((size_t)32 << 20);
+      if (one_pass) {
+        // few walks: each writes into a buffer of its own capacity (x at offs, y at offs + cap) in one pass
+        size_t at = 0;
+        for (size_t t = 0; t < n; ++t) { offs[t] = (int64_t)at; at += 2 * (size_t)wp[t].cap; }
+        if (ctx->cons.ensure(captot + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(consensus) failed");
+        HIPCHK(ctx, hipMemcpyAsync(woffs, offs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(sw_wave_walk_kernel<kWalkBoth>, dim3(wblocks), dim3(64), 0, ctx->stream, ctx->walkp.as<WaveWalk>(), (int)n,
+                           ctx->cons.as<char>(), (const int64_t *)woffs);
+        HIPCHK(ctx, hipGetLastError());
+        cons.resize(captot + 1);
+        HIPCHK(ctx, hipMemcpyAsync(wo.data(), wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(cons.data(), ctx->cons.p, captot, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      } else {
+        hipLaunchKernelGGL(sw_wave_walk_kernel<kWalkMeasure>, dim3(wblocks), dim3(64), 0, ctx->stream, ctx->walkp.as<WaveWalk>(), (int)n,
+                           (char *)nullptr, (const int64_t *)nullptr);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(wo.data(), wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        size_t ctot = 0;
+        for (size_t t = 0; t < n; ++t) { offs[t] = (int64_t)ctot; if (wo[3 * t + 2] == 0) ctot += 2 * (size_t)wo[3 * t]; }
+        if (ctx->cons.ensure(ctot + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(consensus) failed");
+        HIPCHK(ctx, hipMemcpyAsync(woffs, offs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(sw_wave_walk_kernel<kWalkWrite>, dim3(wblocks), dim3(64), 0, ctx->stream, ctx->walkp.as<WaveWalk>(), (int)n,
+                           ctx->cons.as<char>(), (const int64_t *)woffs);
+        HIPCHK(ctx, hipGetLastError());
+        cons.resize(ctot + 1);
+        if (ctot) HIPCHK(ctx, hipMemcpyAsync(cons.data(), ctx->cons.p, ctot, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      }
+      for (size_t t = 0; t < n; ++t) {
+        const size_t k = owner[t];
+        const int st = (int)wo[3 * t + 2];
+        if (st == 0) {
+          const size_t len = (size_t)wo[3 * t];
+          tout[k].cx.assign(cons.data() + offs[t], len);
+          tout[k].cy.assign(cons.data() + offs[t] + (one_pass ? (size_t)wp[t].cap : len), len);
+          tout[k].pos = (uint32_t)wo[3 * t + 1];
+        } else if (st == 1) { budget[k] *= 4; next.push_back(k); }
+        else return fail(ctx, MI355_SW_ENOTSUP, "consensus longer than |x| + |y|");
+      }
+    }
+    todo.swap(next);
+  }
+  return 0;
+}
+
+}  // namespace
