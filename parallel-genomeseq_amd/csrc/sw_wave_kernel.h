@@ -143,11 +143,9 @@ __global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, 
           const float n1 = diag;
           const float n2 = ORIENT == 0 ? w : north;
           const float n3 = ORIENT == 0 ? north : w;
-          int dir;
-          if (n1 == 0.0f || n2 == 0.0f || n3 == 0.0f) dir = kDirStop;
-          else if (n1 >= n2 && n1 >= n3) dir = kDirNW;
-          else if (n2 >= n1 && n2 >= n3) dir = kDirW;
-          else dir = kDirN;
+          // stop when a neighbour is 0 (all are >= 0), else NW if it is >= both others, else W if it is >= N, else N
+          const float lowest = fminf(fminf(n1, n2), n3);
+          const int dir = lowest == 0.0f ? kDirStop : (n1 >= tmx ? kDirNW : (n2 >= n3 ? kDirW : kDirN));
           dpack[r >> 4] |= (uint32_t)dir << (2 * (r & 15));
         }
         if (KEYED) hit |= h == P.target;
