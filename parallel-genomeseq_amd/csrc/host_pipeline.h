@@ -45,7 +45,8 @@ int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, co
     }
     if (sub.empty()) continue;
     std::vector<TraceOut> t2;
-    int rc = wave_trace(ctx, ref, q, rg, p, 0, sub, sl, t2, pass == 1, &table);
+    const bool latency_mode = pass == 0 && sub.size() <= kLatencyJobs && strip_ok;
+    int rc = wave_trace(ctx, ref, q, rg, p, 0, sub, sl, t2, pass == 1 || latency_mode, &table);
     if (rc) return rc;
     for (size_t t = 0; t < sub.size(); ++t) tout[owner[t]] = t2[t];
   }
@@ -302,7 +303,9 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
         if (wave_locate && q.len[k] <= kWaveMaxLanesSide) {
           WaveJob wj;
           wj.q = (int)k; wj.orient = 0; wj.s_lo = wl; wj.nb = (int32_t)(own_hi - wl); wj.track = true; wj.dirs = false;
-          wj.target = score; wj.keyed = wave_keyed; wj.own_lo = (int32_t)(own_lo - wl);
+          wj.target = score; wj.keyed = wave_keyed;
+          // float order: nothing left of the sub-chunk can equal the maximum, so the whole window may compete
+          wj.own_lo = wave_keyed ? (int32_t)(own_lo - wl) : 0;
           wjobs.push_back(wj);
           continue;
         }
@@ -330,6 +333,11 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
     const unsigned long long kk = host_order_key(p.semantics, j.ci, j.cj, q.len[j.q], n);
     if (kk < bestkey[j.q]) { bestkey[j.q] = kk; loc[j.q].ix = j.ci; loc[j.q].iy = j.cj; }
   }
+  if (!wjobs.empty() && wjobs.size() <= kLatencyJobs && strip_ok) {
+    // latency mode: a handful of short problems — a whole wavefront each, few rows per lane
+    sjobs.insert(sjobs.end(), wjobs.begin(), wjobs.end());
+    wjobs.clear();
+  }
   for (size_t lo = 0; lo < wjobs.size(); lo += 262144) {
     std::vector<WaveJob> part(wjobs.begin() + lo, wjobs.begin() + std::min(wjobs.size(), lo + 262144));
     int rc = run_wave(ctx, ref, q, rg, p, part);
@@ -342,7 +350,7 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
   }
   if (!sjobs.empty()) {
     // one launch per kernel instance (rows per lane)
-    for (int R : {10, 16}) {
+    for (int R : {3, 5, 8, 10, 16}) {
       std::vector<WaveJob> group;
       for (const WaveJob &j : sjobs) if (strip_R(q.len[j.q]) == R) group.push_back(j);
       for (size_t lo = 0; lo < group.size(); lo += 4096) {

@@ -116,7 +116,10 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
 
 // Rows per lane of the strip kernel instance for a query of `na` rows, and its strips of 64*R rows (sixteen run
 // concurrently; longer queries take several rounds).
-int strip_R(int na) { return na <= 64 * kStripMaxWaves * 10 ? 10 : 16; }
+// Short queries get a whole wavefront with few rows per lane (latency mode, below): the recurrence's dependent chain
+// per step is R rows long, so 64 lanes x 3 rows sweep a 150 bp window three times faster than 16 lanes x 10 rows.
+int strip_R(int na) { return na <= 192 ? 3 : (na <= 320 ? 5 : (na <= 512 ? 8 : (na <= 64 * kStripMaxWaves * 10 ? 10 : 16))); }
+constexpr size_t kLatencyJobs = 64;            // up to this many short problems per call run in latency mode
 int strip_count(int na, int R) { return std::max(1, (na + 64 * R - 1) / (64 * R)); }
 size_t strip_dirs_bytes(int64_t nb, int nstrips, int R) { return (size_t)nb * 64 * (size_t)nstrips * (size_t)((R + 15) / 16) * 4 + 64; }
 
@@ -202,12 +205,16 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   const float *gtab = use_table ? ctx->ftab.as<float>() : nullptr;
   if (use_table && (size_t)257 * ref.ncodes * 4 > 48 * 1024) {
     const int lds = 257 * ref.ncodes * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<10, false, kStripTrack, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<10, false, kStripDirs, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<16, false, kStripTrack, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<16, false, kStripDirs, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+#define STRIP_LDS_ATTR(r)                                                                                              \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<r, false, kStripTrack, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<r, false, kStripDirs, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    STRIP_LDS_ATTR(3) STRIP_LDS_ATTR(5) STRIP_LDS_ATTR(8) STRIP_LDS_ATTR(10) STRIP_LDS_ATTR(16)
+#undef STRIP_LDS_ATTR
   }
-  if (R == 10) launch_strip<10>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes);
+  if (R == 3) launch_strip<3>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes);
+  else if (R == 5) launch_strip<5>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes);
+  else if (R == 8) launch_strip<8>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes);
+  else if (R == 10) launch_strip<10>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes);
   else launch_strip<16>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes);
   HIPCHK(ctx, hipGetLastError());
   std::vector<int32_t> st(n);
