@@ -185,8 +185,10 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
           if (MODE == kStripDirs) {
             // smithwaterman.cpp:51,59,66,72 at this cell (n1 = NW = diag, n2 = W = wv, n3 = N = north): stop when a
             // neighbour is 0, else NW if it is >= both others, else W if it is >= N, else N
+            // (arithmetic on the three conditions: written as nested selects the compiler turns it into branches)
             const float lowest = fminf(fminf(diag, wv), north);
-            const int dir = lowest == 0.0f ? kDirStop : (diag >= tmx ? kDirNW : (wv >= north ? kDirW : kDirN));
+            const uint32_t c_go = lowest != 0.0f ? 1u : 0u, c_nw = diag >= tmx ? 1u : 0u, c_w = wv >= north ? 1u : 0u;
+            const uint32_t dir = c_go * (3u - c_w - c_nw * (2u - c_w));   // 0 stop, 1 NW, 2 W, 3 N
             dpack[r >> 4] |= (uint32_t)dir << (2 * (r & 15));
           } else {
             hit |= h == P.target;

@@ -144,8 +144,10 @@ __global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, 
           const float n2 = ORIENT == 0 ? w : north;
           const float n3 = ORIENT == 0 ? north : w;
           // stop when a neighbour is 0 (all are >= 0), else NW if it is >= both others, else W if it is >= N, else N
+          // (arithmetic on the three conditions: written as nested selects the compiler turns it into branches)
           const float lowest = fminf(fminf(n1, n2), n3);
-          const int dir = lowest == 0.0f ? kDirStop : (n1 >= tmx ? kDirNW : (n2 >= n3 ? kDirW : kDirN));
+          const uint32_t c_go = lowest != 0.0f ? 1u : 0u, c_nw = n1 >= tmx ? 1u : 0u, c_w = n2 >= n3 ? 1u : 0u;
+          const uint32_t dir = c_go * (3u - c_w - c_nw * (2u - c_w));   // 0 stop, 1 NW, 2 W, 3 N
           dpack[r >> 4] |= (uint32_t)dir << (2 * (r & 15));
         }
         if (KEYED) hit |= h == P.target;
