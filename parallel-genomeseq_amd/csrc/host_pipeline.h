@@ -48,7 +48,7 @@ int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, co
     const bool latency_mode = pass == 0 && sub.size() <= kLatencyJobs && strip_ok;
     int rc = wave_trace(ctx, ref, q, rg, p, 0, sub, sl, t2, pass == 1 || latency_mode, &table);
     if (rc) return rc;
-    for (size_t t = 0; t < sub.size(); ++t) tout[owner[t]] = t2[t];
+    for (size_t t = 0; t < sub.size(); ++t) tout[owner[t]] = std::move(t2[t]);
   }
   std::vector<int64_t> budget(qidx.size());
   for (size_t k : todo) budget[k] = (int64_t)q.len[qidx[k]] / 8 + 64;
@@ -92,7 +92,7 @@ int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, co
       if (rc) return rc;
       for (size_t t = 0; t < jobs.size(); ++t) {
         const size_t k = owner[t];
-        if (st[t] == 0) tout[k] = outs[t];
+        if (st[t] == 0) tout[k] = std::move(outs[t]);
         else if (st[t] == 1) { budget[k] *= 4; next.push_back(k); }
         else return fail(ctx, MI355_SW_ENOTSUP, "consensus longer than |x| + window");
       }
@@ -145,7 +145,7 @@ int exact_full_lds(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, c
       if (rc) return rc;
       for (size_t t = 0; t < jobs.size(); ++t) {
         if (st[t] != 0) return fail(ctx, MI355_SW_ENOTSUP, "traceback walk failed on a whole-matrix window");
-        tout[owner[t]] = outs[t];
+        tout[owner[t]] = std::move(outs[t]);
       }
     }
   }
@@ -187,7 +187,7 @@ int exact_full(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
     std::vector<TraceOut> t2;
     int rc = exact_full_lds(ctx, ref, q, rg, p, sub, trace, l2, t2);
     if (rc) return rc;
-    for (size_t t = 0; t < ks.size(); ++t) { loc[ks[t]] = l2[t]; tout[ks[t]] = t2[t]; }
+    for (size_t t = 0; t < ks.size(); ++t) { loc[ks[t]] = l2[t]; tout[ks[t]] = std::move(t2[t]); }
     return 0;
   };
   int rc = run_lds(lds_all, want_trace);
@@ -225,7 +225,7 @@ int exact_full(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
       std::vector<TraceOut> t2;
       rc = wave_trace(ctx, ref, q, rg, p, o, sub, sl, t2);
       if (rc) return rc;
-      for (size_t t = 0; t < sub.size(); ++t) tout[owner[t]] = t2[t];
+      for (size_t t = 0; t < sub.size(); ++t) tout[owner[t]] = std::move(t2[t]);
     }
   }
   return 0;
@@ -426,7 +426,7 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
         if (rc) return rc;
         HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
         ctx->timings[2] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
-        for (size_t t = 0; t < fq.size(); ++t) tout[fq[t]] = ft[t];
+        for (size_t t = 0; t < fq.size(); ++t) tout[fq[t]] = std::move(ft[t]);
       }
     }
     std::vector<int> slow;
@@ -442,7 +442,7 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
       }
       HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
       ctx->timings[2] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
-      for (size_t t = 0; t < slow.size(); ++t) { loc[slow[t]] = sl[t]; tout[slow[t]] = st[t]; }
+      for (size_t t = 0; t < slow.size(); ++t) { loc[slow[t]] = sl[t]; tout[slow[t]] = std::move(st[t]); }
     }
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));

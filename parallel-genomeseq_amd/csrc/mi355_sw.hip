@@ -17,11 +17,13 @@
 #include <algorithm>
 #include <chrono>
 #include <future>
+#include <memory>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "sw_exact_kernel.h"
