@@ -85,6 +85,8 @@ struct mi355_sw_ctx {
   // event pairs around the score launches of a call, read back after the call's first synchronisation
   std::vector<hipEvent_t> score_ev;
   size_t score_ev_used = 0;
+  // D2H consensus buffers of the running call (TraceOut points into them); cleared when the next call starts
+  std::vector<std::vector<char>> arenas;
   double timings[6] = {0, 0, 0, 0, 0, 0};
 };
 

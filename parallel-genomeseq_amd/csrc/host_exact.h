@@ -113,8 +113,11 @@ int run_exact(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   return 0;
 }
 
+// Consensus of one alignment: views into a D2H buffer the context keeps until the next call (ctx->arenas) —
+// with half a million alignments per call, a std::string pair each was a quarter of the host time.
 struct TraceOut {
-  std::string cx, cy;
+  const char *cx = nullptr, *cy = nullptr;
+  size_t len = 0;
   uint32_t pos = 0;
 };
 
@@ -163,13 +166,15 @@ int run_walk(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const s
   HIPCHK(ctx, hipMemcpyAsync(cons.data(), ctx->cons.p, ctot, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   outs.resize(n); status.resize(n);
+  ctx->arenas.push_back(std::move(cons));
+  const char *base = ctx->arenas.back().data();
   for (size_t k = 0; k < n; ++k) {
     const ExactJob &j = jobs[lo + k];
     const int cap = q.len[j.q] + j.nw + 2;
     status[k] = (int)wo[3 * k + 2];
-    const size_t len = (size_t)wo[3 * k];
-    outs[k].cx.assign(cons.data() + coff[k], len);
-    outs[k].cy.assign(cons.data() + coff[k] + cap, len);
+    outs[k].len = (size_t)wo[3 * k];
+    outs[k].cx = base + coff[k];
+    outs[k].cy = base + coff[k] + cap;
     outs[k].pos = (uint32_t)wo[3 * k + 1];
   }
   return 0;

@@ -7,14 +7,14 @@ void set_result(mi355_sw_result &r, float score, int64_t ix, int64_t iy, const T
   r.end_x = score > 0 ? ix : 0;
   r.end_y = score > 0 ? iy : 0;
   r.pos = t ? t->pos : 0;
-  const std::string empty;
-  const std::string &cx = t ? t->cx : empty, &cy = t ? t->cy : empty;
-  r.cons_len = cx.size();
+  const size_t len = t ? t->len : 0;
+  r.cons_len = len;
   // both strings live in ONE allocation owned through cons_x (mi355_sw_free_result frees only that)
-  r.cons_x = (char *)malloc(cx.size() + cy.size() + 2);
-  r.cons_y = r.cons_x + cx.size() + 1;
-  memcpy(r.cons_x, cx.data(), cx.size()); r.cons_x[cx.size()] = 0;
-  memcpy(r.cons_y, cy.data(), cy.size()); r.cons_y[cy.size()] = 0;
+  r.cons_x = (char *)malloc(2 * len + 2);
+  r.cons_y = r.cons_x + len + 1;
+  if (len) { memcpy(r.cons_x, t->cx, len); memcpy(r.cons_y, t->cy, len); }
+  r.cons_x[len] = 0;
+  r.cons_y[len] = 0;
 }
 
 // Traceback for located alignments of one range: windows left of the argmax, grown on demand.
@@ -390,7 +390,9 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
   std::vector<TraceOut> tout(nq);
   if (n >= 1 && nq > 0) {
     const ScoreTable table = plan_table(ref, p);
-    std::vector<Bucket> buckets = make_buckets(ref, q, table, p, n);
+    // references shorter than 1024 columns never take the score kernel (bucket_fast_ok): skip the length classes
+    std::vector<Bucket> buckets;
+    if (n >= 1024) buckets = make_buckets(ref, q, table, p, n);
     std::vector<char> qfast(nq, 0), qfloat(nq, 0);
     std::vector<int64_t> qchunk(nq, 0), qwarm(nq, 0);
     bool any_fast = false;
@@ -515,6 +517,6 @@ int check_params(mi355_sw_ctx *ctx, const mi355_sw_params *p) {
   return 0;
 }
 
-void reset_timings(mi355_sw_ctx *ctx) { for (double &t : ctx->timings) t = 0; ctx->score_ev_used = 0; }
+void reset_timings(mi355_sw_ctx *ctx) { for (double &t : ctx->timings) t = 0; ctx->score_ev_used = 0; ctx->arenas.clear(); }
 
 }  // namespace

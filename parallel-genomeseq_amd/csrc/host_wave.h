@@ -351,13 +351,16 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         if (ctot) HIPCHK(ctx, hipMemcpyAsync(cons.data(), ctx->cons.p, ctot, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       }
+      ctx->arenas.push_back(std::move(cons));                       // the strings stay where the copy put them
+      const char *base = ctx->arenas.back().data();
       for (size_t t = 0; t < n; ++t) {
         const size_t k = owner[t];
         const int st = (int)wo[3 * t + 2];
         if (st == 0) {
           const size_t len = (size_t)wo[3 * t];
-          tout[k].cx.assign(cons.data() + offs[t], len);
-          tout[k].cy.assign(cons.data() + offs[t] + (one_pass ? (size_t)wp[t].cap : len), len);
+          tout[k].len = len;
+          tout[k].cx = base + offs[t];
+          tout[k].cy = base + offs[t] + (one_pass ? (size_t)wp[t].cap : len);
           tout[k].pos = (uint32_t)wo[3 * t + 1];
         } else if (st == 1) { budget[k] *= 4; next.push_back(k); }
         else return fail(ctx, MI355_SW_ENOTSUP, "consensus longer than |x| + |y|");
