@@ -168,6 +168,18 @@ uint64_t content_hash_part(const char *p, size_t n) {
   return r ^ (r >> 32);
 }
 
+// Per-item host loops over a big batch (half a million small alignments per call): four-way on helper threads.
+// fn(k0, k1) must only touch items k0 <= k < k1.
+template <class F>
+void parallel_for(size_t n, F fn) {
+  if (n < 65536) { fn((size_t)0, n); return; }
+  const size_t step = (n + 3) / 4;
+  std::future<void> parts[3];
+  for (int t = 0; t < 3; ++t) parts[t] = std::async(std::launch::async, fn, std::min(n, (size_t)(t + 1) * step), std::min(n, (size_t)(t + 2) * step));
+  fn((size_t)0, std::min(n, step));
+  for (auto &f : parts) f.get();
+}
+
 // Hash of a whole buffer: four independent quarters (hashed on helper threads when the buffer is large), combined.
 uint64_t content_hash(const char *p, size_t n) {
   if (n < ((size_t)4 << 20)) return content_hash_part(p, n);

@@ -198,6 +198,7 @@ int exact_full(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
     for (int o = 0; o < 2; ++o) {
       std::vector<WaveJob> jobs;
       std::vector<size_t> owner;
+      jobs.reserve(qidx.size()); owner.reserve(qidx.size());
       for (size_t k = 0; k < qidx.size(); ++k) {
         if (orient[k] != o) continue;
         WaveJob j;
@@ -206,11 +207,13 @@ int exact_full(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
       }
       rc = run_wave(ctx, ref, q, rg, p, jobs);
       if (rc) return rc;
-      for (size_t t = 0; t < jobs.size(); ++t) {
-        Located &L = loc[owner[t]];
-        L.score = jobs[t].best > 0 ? jobs[t].best : 0;
-        L.ix = jobs[t].ci; L.iy = jobs[t].cj;
-      }
+      parallel_for(jobs.size(), [&](size_t t0, size_t t1) {
+        for (size_t t = t0; t < t1; ++t) {
+          Located &L = loc[owner[t]];
+          L.score = jobs[t].best > 0 ? jobs[t].best : 0;
+          L.ix = jobs[t].ci; L.iy = jobs[t].cj;
+        }
+      });
     }
   }
   // 2. traceback of the wave-eligible ones
@@ -219,6 +222,7 @@ int exact_full(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
       std::vector<int> sub;
       std::vector<Located> sl;
       std::vector<size_t> owner;
+      sub.reserve(qidx.size()); sl.reserve(qidx.size()); owner.reserve(qidx.size());
       for (size_t k = 0; k < qidx.size(); ++k)
         if (orient[k] == o) { sub.push_back(qidx[k]); sl.push_back(loc[k]); owner.push_back(k); }
       if (sub.empty()) continue;
@@ -450,11 +454,14 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
   HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
   ctx->timings[3] += elapsed_us(ctx, ctx->ev[4], ctx->ev[5]);
   HostTrace trace_results("set_results");
-  for (size_t k = 0; k < nq; ++k) {
-    set_result(outs[k], loc[k].score, loc[k].ix, loc[k].iy, (want_trace && loc[k].score > 0) ? &tout[k] : nullptr);
-    outs[k].timings_us[0] = (float)(ctx->timings[0] > 0 ? ctx->timings[0] : ctx->timings[3]);
-    outs[k].timings_us[1] = 0;
-  }
+  const float t_iter = (float)(ctx->timings[0] > 0 ? ctx->timings[0] : ctx->timings[3]);
+  parallel_for(nq, [&](size_t k0, size_t k1) {
+    for (size_t k = k0; k < k1; ++k) {
+      set_result(outs[k], loc[k].score, loc[k].ix, loc[k].iy, (want_trace && loc[k].score > 0) ? &tout[k] : nullptr);
+      outs[k].timings_us[0] = t_iter;
+      outs[k].timings_us[1] = 0;
+    }
+  });
   return 0;
 }
 

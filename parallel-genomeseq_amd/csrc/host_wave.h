@@ -71,7 +71,8 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
       (dirs_total && ctx->dirs.ensure(dirs_total)))
     return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(wave scratch) failed");
   std::vector<WaveProblem> pr(n);
-  for (size_t k = 0; k < n; ++k) {
+  parallel_for(n, [&](size_t k0, size_t k1) {
+  for (size_t k = k0; k < k1; ++k) {
     const WaveJob &j = jobs[k];
     WaveProblem &w = pr[k];
     const uint8_t *xq = q.bytes.as<uint8_t>() + q.off[j.q];
@@ -85,6 +86,7 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
     w.cell = ctx->outs_i.as<int64_t>() + 2 * k;
     w.target = j.target; w.own_lo = j.own_lo; w.full_n = nref;
   }
+  });
   const bool keyed = jobs[0].keyed;
   HIPCHK(ctx, hipMemcpyAsync(ctx->wprobs.p, pr.data(), n * sizeof(WaveProblem), hipMemcpyHostToDevice, ctx->stream));
   WaveScoring sc;
@@ -109,7 +111,9 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
     HIPCHK(ctx, hipMemcpyAsync(bf.data(), ctx->outs_f.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ci.data(), ctx->outs_i.p, n * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    for (size_t k = 0; k < n; ++k) { jobs[k].best = bf[k]; jobs[k].ci = ci[2 * k]; jobs[k].cj = ci[2 * k + 1]; }
+    parallel_for(n, [&](size_t k0, size_t k1) {
+      for (size_t k = k0; k < k1; ++k) { jobs[k].best = bf[k]; jobs[k].ci = ci[2 * k]; jobs[k].cj = ci[2 * k + 1]; }
+    });
   }
   return 0;
 }
@@ -294,7 +298,8 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(walk scratch) failed");
       int64_t *wout = reinterpret_cast<int64_t *>(ctx->walkp.as<uint8_t>() + n * sizeof(WaveWalk));
       int64_t *woffs = wout + 3 * n;
-      for (size_t t = 0; t < n; ++t) {
+      parallel_for(n, [&](size_t t0, size_t t1) {
+      for (size_t t = t0; t < t1; ++t) {
         const WaveJob &j = jobs[t];
         const size_t k = owner[t];
         WaveWalk &w = wp[t];
@@ -314,6 +319,7 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         w.cap = na + j.nb + 2;                                      // a walk inside the window emits <= na + nb pairs
         w.out = wout + 3 * t;
       }
+      });
       HIPCHK(ctx, hipMemcpyAsync(ctx->walkp.p, wp.data(), n * sizeof(WaveWalk), hipMemcpyHostToDevice, ctx->stream));
       const unsigned wblocks = (unsigned)((n + 63) / 64);
       std::vector<int64_t> wo(3 * n), offs(n);
@@ -353,17 +359,21 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
       }
       ctx->arenas.push_back(std::move(cons));                       // the strings stay where the copy put them
       const char *base = ctx->arenas.back().data();
-      for (size_t t = 0; t < n; ++t) {
-        const size_t k = owner[t];
-        const int st = (int)wo[3 * t + 2];
-        if (st == 0) {
+      parallel_for(n, [&](size_t t0, size_t t1) {
+        for (size_t t = t0; t < t1; ++t) {
+          if (wo[3 * t + 2] != 0) continue;
+          const size_t k = owner[t];
           const size_t len = (size_t)wo[3 * t];
           tout[k].len = len;
           tout[k].cx = base + offs[t];
           tout[k].cy = base + offs[t] + (one_pass ? (size_t)wp[t].cap : len);
           tout[k].pos = (uint32_t)wo[3 * t + 1];
-        } else if (st == 1) { budget[k] *= 4; next.push_back(k); }
-        else return fail(ctx, MI355_SW_ENOTSUP, "consensus longer than |x| + |y|");
+        }
+      });
+      for (size_t t = 0; t < n; ++t) {                              // the rare ones that need a wider window
+        const int st = (int)wo[3 * t + 2];
+        if (st == 1) { budget[owner[t]] *= 4; next.push_back(owner[t]); }
+        else if (st != 0) return fail(ctx, MI355_SW_ENOTSUP, "consensus longer than |x| + |y|");
       }
     }
     todo.swap(next);
