@@ -35,6 +35,24 @@ struct DevBuf {
   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// Pinned host staging (problem lists up, results down): pageable copies of tens of MB per launch were the largest
+// single host cost of the many-small-alignments shape.
+struct PinBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return -1; }
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 struct RefData {
   DevBuf bytes, codes;
   size_t n = 0;
@@ -87,6 +105,11 @@ struct mi355_sw_ctx {
   size_t score_ev_used = 0;
   // D2H consensus buffers of the running call (TraceOut points into them); cleared when the next call starts
   std::vector<std::vector<char>> arenas;
+  // pinned staging: problem / walk descriptors (up), small results (down), and a pool of consensus buffers that
+  // live until the next call (cons_used of them are taken)
+  PinBuf pin_probs, pin_walk, pin_out;
+  std::vector<PinBuf> pin_cons;
+  size_t cons_used = 0;
   double timings[6] = {0, 0, 0, 0, 0, 0};
 };
 

@@ -524,6 +524,6 @@ int check_params(mi355_sw_ctx *ctx, const mi355_sw_params *p) {
   return 0;
 }
 
-void reset_timings(mi355_sw_ctx *ctx) { for (double &t : ctx->timings) t = 0; ctx->score_ev_used = 0; ctx->arenas.clear(); }
+void reset_timings(mi355_sw_ctx *ctx) { for (double &t : ctx->timings) t = 0; ctx->score_ev_used = 0; ctx->arenas.clear(); ctx->cons_used = 0; }
 
 }  // namespace

@@ -70,7 +70,9 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
   if (ctx->wprobs.ensure(n * sizeof(WaveProblem)) || ctx->outs_f.ensure(n * 4) || ctx->outs_i.ensure(n * 16) ||
       (dirs_total && ctx->dirs.ensure(dirs_total)))
     return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(wave scratch) failed");
-  std::vector<WaveProblem> pr(n);
+  if (ctx->pin_probs.ensure(n * sizeof(WaveProblem)) || ctx->pin_out.ensure(n * 20 + 64))
+    return fail(ctx, MI355_SW_ENOMEM, "hipHostMalloc(wave staging) failed");
+  WaveProblem *pr = ctx->pin_probs.as<WaveProblem>();
   parallel_for(n, [&](size_t k0, size_t k1) {
   for (size_t k = k0; k < k1; ++k) {
     const WaveJob &j = jobs[k];
@@ -88,7 +90,7 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
   }
   });
   const bool keyed = jobs[0].keyed;
-  HIPCHK(ctx, hipMemcpyAsync(ctx->wprobs.p, pr.data(), n * sizeof(WaveProblem), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->wprobs.p, pr, n * sizeof(WaveProblem), hipMemcpyHostToDevice, ctx->stream));
   WaveScoring sc;
   sc.match = p.match; sc.mismatch = p.mismatch; sc.gap = p.gap;
   const U8Params u = u8_params(p);
@@ -106,10 +108,10 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
   else launch_wave_R<32>(orient, u8, track, dirs, blocks, ctx->stream, dp, (int)n, sc);
   HIPCHK(ctx, hipGetLastError());
   if (track) {
-    std::vector<float> bf(n);
-    std::vector<int64_t> ci(2 * n);
-    HIPCHK(ctx, hipMemcpyAsync(bf.data(), ctx->outs_f.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ci.data(), ctx->outs_i.p, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    int64_t *ci = ctx->pin_out.as<int64_t>();
+    float *bf = reinterpret_cast<float *>(ci + 2 * n);
+    HIPCHK(ctx, hipMemcpyAsync(bf, ctx->outs_f.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ci, ctx->outs_i.p, n * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     parallel_for(n, [&](size_t k0, size_t k1) {
       for (size_t k = k0; k < k1; ++k) { jobs[k].best = bf[k]; jobs[k].ci = ci[2 * k]; jobs[k].cj = ci[2 * k + 1]; }
@@ -293,9 +295,11 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
       if (rc) return rc;
       // walk: measure, lay out, write (only the bytes that exist are copied back)
       const size_t n = jobs.size();
-      std::vector<WaveWalk> wp(n);
       if (ctx->walkp.ensure(n * sizeof(WaveWalk) + n * 24 + n * 8 + 64))
         return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(walk scratch) failed");
+      if (ctx->pin_walk.ensure(n * sizeof(WaveWalk)) || ctx->pin_out.ensure(n * 32 + 64))
+        return fail(ctx, MI355_SW_ENOMEM, "hipHostMalloc(walk staging) failed");
+      WaveWalk *wp = ctx->pin_walk.as<WaveWalk>();
       int64_t *wout = reinterpret_cast<int64_t *>(ctx->walkp.as<uint8_t>() + n * sizeof(WaveWalk));
       int64_t *woffs = wout + 3 * n;
       parallel_for(n, [&](size_t t0, size_t t1) {
@@ -320,10 +324,13 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         w.out = wout + 3 * t;
       }
       });
-      HIPCHK(ctx, hipMemcpyAsync(ctx->walkp.p, wp.data(), n * sizeof(WaveWalk), hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->walkp.p, wp, n * sizeof(WaveWalk), hipMemcpyHostToDevice, ctx->stream));
       const unsigned wblocks = (unsigned)((n + 63) / 64);
-      std::vector<int64_t> wo(3 * n), offs(n);
-      std::vector<char> cons;
+      int64_t *wo = ctx->pin_out.as<int64_t>();                     // [3n] walk outputs, then [n] offsets
+      int64_t *offs = wo + 3 * n;
+      // the consensus bytes land in a pinned buffer that stays alive until the next call (TraceOut points into it)
+      if (ctx->pin_cons.size() <= ctx->cons_used) ctx->pin_cons.resize(ctx->cons_used + 1);
+      PinBuf &cons = ctx->pin_cons[ctx->cons_used];
       size_t captot = 0;
       for (size_t t = 0; t < n; ++t) captot += 2 * (size_t)wp[t].cap;
       const bool one_pass = n <= 4096 && captot <= ((size_t)32 << 20);
@@ -332,33 +339,33 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         size_t at = 0;
         for (size_t t = 0; t < n; ++t) { offs[t] = (int64_t)at; at += 2 * (size_t)wp[t].cap; }
         if (ctx->cons.ensure(captot + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(consensus) failed");
-        HIPCHK(ctx, hipMemcpyAsync(woffs, offs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(woffs, offs, n * 8, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(sw_wave_walk_kernel<kWalkBoth>, dim3(wblocks), dim3(64), 0, ctx->stream, ctx->walkp.as<WaveWalk>(), (int)n,
                            ctx->cons.as<char>(), (const int64_t *)woffs);
         HIPCHK(ctx, hipGetLastError());
-        cons.resize(captot + 1);
-        HIPCHK(ctx, hipMemcpyAsync(wo.data(), wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(cons.data(), ctx->cons.p, captot, hipMemcpyDeviceToHost, ctx->stream));
+        if (cons.ensure(captot + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipHostMalloc(consensus) failed");
+        HIPCHK(ctx, hipMemcpyAsync(wo, wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(cons.p, ctx->cons.p, captot, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       } else {
         hipLaunchKernelGGL(sw_wave_walk_kernel<kWalkMeasure>, dim3(wblocks), dim3(64), 0, ctx->stream, ctx->walkp.as<WaveWalk>(), (int)n,
                            (char *)nullptr, (const int64_t *)nullptr);
         HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(wo.data(), wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(wo, wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         size_t ctot = 0;
         for (size_t t = 0; t < n; ++t) { offs[t] = (int64_t)ctot; if (wo[3 * t + 2] == 0) ctot += 2 * (size_t)wo[3 * t]; }
         if (ctx->cons.ensure(ctot + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(consensus) failed");
-        HIPCHK(ctx, hipMemcpyAsync(woffs, offs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(woffs, offs, n * 8, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(sw_wave_walk_kernel<kWalkWrite>, dim3(wblocks), dim3(64), 0, ctx->stream, ctx->walkp.as<WaveWalk>(), (int)n,
                            ctx->cons.as<char>(), (const int64_t *)woffs);
         HIPCHK(ctx, hipGetLastError());
-        cons.resize(ctot + 1);
-        if (ctot) HIPCHK(ctx, hipMemcpyAsync(cons.data(), ctx->cons.p, ctot, hipMemcpyDeviceToHost, ctx->stream));
+        if (cons.ensure(ctot + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipHostMalloc(consensus) failed");
+        if (ctot) HIPCHK(ctx, hipMemcpyAsync(cons.p, ctx->cons.p, ctot, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       }
-      ctx->arenas.push_back(std::move(cons));                       // the strings stay where the copy put them
-      const char *base = ctx->arenas.back().data();
+      ctx->cons_used++;                                             // the strings stay where the copy put them
+      const char *base = cons.as<char>();
       parallel_for(n, [&](size_t t0, size_t t1) {
         for (size_t t = t0; t < t1; ++t) {
           if (wo[3 * t + 2] != 0) continue;

@@ -75,6 +75,8 @@ void mi355_sw_destroy(mi355_sw_ctx *c) {
                     &c->batch.offs, &c->batch.sel, &c->ftab, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow, &c->wprobs};
   for (DevBuf *b : bufs) b->release();
   c->adhoc.release(); c->one.release();
+  c->pin_probs.release(); c->pin_walk.release(); c->pin_out.release();
+  for (PinBuf &b : c->pin_cons) b.release();
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto &e : c->score_ev) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
