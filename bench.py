@@ -40,10 +40,23 @@ def kernel_shape(read_len):
     return 16, r16
 
 
-def ops_per_cell(sl, r, sem):
+def ops_per_cell(sl, r, sem, f16=False):
     over = 4 if sl == 8 else 3
-    core = (5 if sem == 1 else 4) * r + (r + 1) // 2 + (r % 2) + over
+    if f16:      # three-input packed maximum: one running-maximum op per two odd rows
+        odd = r // 2
+        core = 4 * r + odd // 2 + odd % 2 + (r % 2) + over
+    else:
+        core = (5 if sem == 1 else 4) * r + (r + 1) // 2 + (r % 2) + over
     return core / (2.0 * r)
+
+
+def uses_f16(args):
+    """The library's choice (host_score.h make_buckets): float32 engine, integer scores, every value within the
+    exactly representable float16 integers."""
+    ints = all(float(v) == int(v) for v in (args.match, args.mismatch, args.gap))
+    return (args.semantics == "f32" and ints and args.gap >= 1 and abs(args.mismatch) <= 2048 and
+            args.match * (args.read_len + 1) <= 2040 and args.gap <= 2040 and args.read_len <= 512 and
+            os.environ.get("MI355_SW_NO_F16") is None)
 
 
 def load_package():
@@ -215,13 +228,14 @@ def main():
             except Exception:
                 traffic = None
         kern_cells_per_s = cells_per_step / avg_launch_s
-        opc = ops_per_cell(kshape[0], kshape[1], sem)
+        f16 = uses_f16(args)
+        opc = ops_per_cell(kshape[0], kshape[1], sem, f16)
         line = {
             "metric": "GCUPS (cell updates/s), 150 bp reads vs 50 Mbp reference, whole job (score + argmax + traceback)",
             "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32" if (args.match != int(args.match) or args.mismatch != int(args.mismatch) or args.gap != int(args.gap)) else "i16") if sem == pgs.F32 else "u8",
-            "dtype_note": "i16 = packed 2x16-bit cells, exact for the float32 engine's integer scores; u8 = saturating uint8 semantics held in packed 16-bit lanes; f32 = float32 cells (fractional scoring)",
+            "dtype": ("f32" if (args.match != int(args.match) or args.mismatch != int(args.mismatch) or args.gap != int(args.gap)) else ("f16" if f16 else "i16")) if sem == pgs.F32 else "u8",
+            "dtype_note": "f16 = packed 2x float16 cells (every value an integer within +-2048: exact); i16 = packed 2x16-bit integer cells; both exact for the float32 engine's integer scores; u8 = saturating uint8 semantics held in packed 16-bit lanes; f32 = float32 cells (fractional scoring)",
             "data": "synthetic",
             "config": {"workload": "configs[2]: %d x %d bp reads per GPU per step vs %d bp reference (one batch of the 100k-read set)"
                                    % (args.reads, args.read_len, args.ref_len),

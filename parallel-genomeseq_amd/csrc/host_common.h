@@ -94,12 +94,13 @@ struct mi355_sw_ctx {
   bool adhoc_valid = false;
   QueryBatch one;                 // the single query of such a call
   // scratch
-  DevBuf keys, ranges, stab, ftab, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs;
+  DevBuf keys, ranges, stab, ftab, htab, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs;
   // host sides of small per-call uploads: they must outlive the asynchronous copies, and the tables are only
   // sent again when they change
   std::vector<int64_t> h_ranges;
   std::vector<int16_t> h_stab;
   std::vector<float> h_ftab;
+  std::vector<uint16_t> h_htab;
   // event pairs around the score launches of a call, read back after the call's first synchronisation
   std::vector<hipEvent_t> score_ev;
   size_t score_ev_used = 0;
@@ -140,6 +141,38 @@ inline int sat8(float a) { return a < 0 ? 0 : (a > 255 ? 255 : (int)(uint8_t)a);
 struct U8Params { int M, X, G; };
 U8Params u8_params(const mi355_sw_params &p) {
   return {sat8(lut_or(p, 'A', 'A')), sat8(-lut_or(p, 'A', 'T')), sat8(p.gap)};   // :389-392
+}
+
+// float32 <-> float16 bit patterns (round to nearest even; the values here are small integers, exactly representable)
+uint16_t half_bits(float f) {
+  uint32_t x; memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  const int32_t e = (int32_t)((x >> 23) & 0xFF) - 127 + 15;
+  uint32_t m = x & 0x7FFFFFu;
+  if (((x >> 23) & 0xFF) == 0) return (uint16_t)sign;                     // zero / float32 subnormal
+  if (e >= 31) return (uint16_t)(sign | 0x7C00u);                        // overflow -> inf
+  if (e <= 0) {                                                          // float16 subnormal
+    if (e < -10) return (uint16_t)sign;
+    m |= 0x800000u;
+    const int sh = 14 - e;
+    uint32_t h = m >> sh;
+    const uint32_t rem = m & ((1u << sh) - 1), halfway = 1u << (sh - 1);
+    if (rem > halfway || (rem == halfway && (h & 1))) ++h;
+    return (uint16_t)(sign | h);
+  }
+  uint32_t h = ((uint32_t)e << 10) | (m >> 13);
+  const uint32_t rem = m & 0x1FFFu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;
+  return (uint16_t)(sign | h);
+}
+float half_value(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  const uint32_t e = (h >> 10) & 0x1F, m = h & 0x3FFu;
+  float f;
+  if (e == 0) { f = std::ldexp((float)m, -24); uint32_t b; memcpy(&b, &f, 4); b |= sign; memcpy(&f, &b, 4); return f; }
+  const uint32_t x = sign | ((e == 31 ? 255u : e - 15 + 127) << 23) | (m << 13);
+  memcpy(&f, &x, 4);
+  return f;
 }
 
 // host twin of order_key<> (sw_exact_kernel.h)

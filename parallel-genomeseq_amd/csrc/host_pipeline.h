@@ -255,7 +255,8 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
   const bool wave_keyed = p.semantics == MI355_SW_U8SAT;
   auto key_score = [&](size_t k) {
     float score;
-    if (qfloat[k]) { const uint32_t bits = (uint32_t)(keys[k] >> 32); memcpy(&score, &bits, 4); }
+    if (qfloat[k] == 2) score = half_value((uint16_t)(keys[k] >> 32));
+    else if (qfloat[k]) { const uint32_t bits = (uint32_t)(keys[k] >> 32); memcpy(&score, &bits, 4); }
     else score = (float)(int)(keys[k] >> 32);
     return score;
   };
@@ -411,7 +412,7 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
         if (rc) return rc;
         for (int k = 0; k < b.count; ++k) {
           const int id = q.order[b.first + k];
-          qfast[id] = 1; qchunk[id] = b.sub_len; qwarm[id] = b.warm; qfloat[id] = sem_is_float(b.sem);
+          qfast[id] = 1; qchunk[id] = b.sub_len; qwarm[id] = b.warm; qfloat[id] = b.sem == kSemF16 ? 2 : (sem_is_float(b.sem) ? 1 : 0);
         }
       }
       std::vector<unsigned long long> keys;
@@ -491,7 +492,7 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
       if (!b.fast) continue;
       rc = score_launch(ctx, ref, q, sub, p, table, b);
       if (rc) return rc;
-      for (int k = 0; k < b.count; ++k) { qfast[q.order[b.first + k]] = 1; qfloat[q.order[b.first + k]] = sem_is_float(b.sem); }
+      for (int k = 0; k < b.count; ++k) { qfast[q.order[b.first + k]] = 1; qfloat[q.order[b.first + k]] = b.sem == kSemF16 ? 2 : (sem_is_float(b.sem) ? 1 : 0); }
     }
     std::vector<unsigned long long> keys;
     rc = score_fetch(ctx, nq * sub.size(), keys);
@@ -501,7 +502,7 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
         if (qfast[k]) {
           const uint32_t hi32 = (uint32_t)(keys[r * nq + k] >> 32);
           float v;
-          if (qfloat[k]) memcpy(&v, &hi32, 4); else v = (float)hi32;
+          if (qfloat[k] == 2) v = half_value((uint16_t)hi32); else if (qfloat[k]) memcpy(&v, &hi32, 4); else v = (float)hi32;
           maxima[(lo + r) * nq + k] = v;
         }
   }

@@ -12,6 +12,8 @@ struct ScoreTable {
   int gap = 0, smax = 0;      // packed instances
   float gapf = 0, smaxf = 0;  // float32 instance
   std::vector<int16_t> stab;  // [256][ncodes]
+  std::vector<uint16_t> htab; // [256][ncodes] the same scores as float16 bits (packed float16 instances), empty when
+                              // an entry does not fit (|s| <= 2048; padding -16384)
   std::vector<float> ftab;    // [256][ncodes]
 };
 
@@ -90,6 +92,14 @@ ScoreTable plan_table(const RefData &ref, const mi355_sw_params &p) {
     if (integral) { f.gap = (int)g; f.smax = (int)smaxf; }
   }
   f.ok = true;
+  if (p.semantics == MI355_SW_F32 && f.integral && f.gap <= 2040) {
+    bool fits = true;
+    for (int16_t v : f.stab) fits = fits && (v == (int16_t)kPadScore || (v >= -2048 && v <= 2048));
+    if (fits) {
+      f.htab.resize(f.stab.size());
+      for (size_t k = 0; k < f.stab.size(); ++k) f.htab[k] = half_bits((float)f.stab[k]);
+    }
+  }
   return f;
 }
 
@@ -128,6 +138,10 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       // packed 16-bit cells when scores are small integers and the score bound fits; float32 cells otherwise
       const bool fits = t.integral && (int64_t)t.smax * std::min<int64_t>(b.maxlen, std::max<int64_t>(n, 1)) + t.smax <= 32000;
       b.sem = fits ? kSemI16 : kSemF32;
+      // small scores on short reads: packed float16 cells (three-input maximum: 4.25 instead of 4.5 ops per cell)
+      if (fits && !t.htab.empty() && !b.strips && b.SL != 64 && b.count >= 2 &&
+          (int64_t)t.smax * b.maxlen + t.smax <= 2040 && std::getenv("MI355_SW_NO_F16") == nullptr)
+        b.sem = kSemF16;
       // a lone query would fill both halves of every packed register with itself; the float32 instance
       // (one query per slot, exact for integer scores below 2^24) sweeps it ~1.5x faster
       if (b.count == 1 && b.sem == kSemI16) {
@@ -182,6 +196,25 @@ int launch_score_twin(int R, bool strips, dim3 grid, size_t shmem, hipStream_t s
   else if (R == 32) launch_score(sw_score_kernel<32, SEM, false, 64, true>, grid, shmem, st, a);
   else return -1;
   return 0;
+}
+
+// packed float16 cells: short reads only (scores within +-2048), 8- and 16-lane tiles
+int launch_score_f16(int R, int SL, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
+  if (SL == 8) {
+    switch (R) {
+#define CASE_H8(r) case r: launch_score(sw_score_kernel<r, kSemF16, false, 8>, grid, shmem, st, a); return 0;
+      CASE_H8(7) CASE_H8(10) CASE_H8(13) CASE_H8(16) CASE_H8(19) CASE_H8(26) CASE_H8(32)
+#undef CASE_H8
+    }
+    return -1;
+  }
+  if (SL != 16) return -1;
+  switch (R) {
+#define CASE_H(r) case r: launch_score(sw_score_kernel<r, kSemF16, false>, grid, shmem, st, a); return 0;
+    CASE_H(2) CASE_H(4) CASE_H(6) CASE_H(8) CASE_H(10) CASE_H(12) CASE_H(16) CASE_H(20) CASE_H(24) CASE_H(32)
+#undef CASE_H
+  }
+  return -1;
 }
 
 template <int SEM>
@@ -257,6 +290,14 @@ int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range>
     ctx->h_ftab = t.ftab;
     HIPCHK(ctx, hipMemcpyAsync(ctx->ftab.p, ctx->h_ftab.data(), ctx->h_ftab.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   }
+  if (!t.htab.empty()) {
+    const void *htab_was = ctx->htab.p;
+    if (ctx->htab.ensure(t.htab.size() * 2 + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
+    if (ctx->htab.p != htab_was || ctx->h_htab != t.htab) {
+      ctx->h_htab = t.htab;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->htab.p, ctx->h_htab.data(), ctx->h_htab.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+    }
+  }
   HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, nq * nr * 8, ctx->stream));
   return 0;
 }
@@ -297,9 +338,10 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   a.qfirst = b.first;
   a.qcount = b.count;
   a.nq = (int)q.nq;
-  a.stab = sem_is_float(b.sem) ? ctx->ftab.p : ctx->stab.p;
+  a.stab = sem_is_float(b.sem) ? ctx->ftab.p : (b.sem == kSemF16 ? ctx->htab.p : ctx->stab.p);
   a.ncodes = ref.ncodes;
   if (sem_is_float(b.sem)) memcpy(&a.gap2, &t.gapf, 4);
+  else if (b.sem == kSemF16) a.gap2 = (uint32_t)half_bits(-(float)t.gap) * 0x00010001u;
   else a.gap2 = (uint32_t)t.gap * 0x00010001u;
   a.clamp2 = 255u * 0x00010001u;
   a.keys = ctx->keys.as<unsigned long long>();
@@ -335,6 +377,7 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   HIPCHK(ctx, hipEventRecord(ctx->score_ev[ctx->score_ev_used], ctx->stream));
   int rc = b.twin ? (b.sem == kSemU8 ? launch_score_twin<kSemU8>(b.R, b.strips, grid, shmem, ctx->stream, a)
                                      : launch_score_twin<kSemI16>(b.R, b.strips, grid, shmem, ctx->stream, a))
+           : b.sem == kSemF16 ? launch_score_f16(b.R, b.SL, grid, shmem, ctx->stream, a)
            : b.sem == kSemU8 ? launch_score_R<kSemU8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
            : b.sem == kSemF32U8 ? launch_score_R<kSemF32U8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
            : b.sem == kSemF32 ? launch_score_R<kSemF32>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)

@@ -43,6 +43,9 @@ constexpr int kSemF32 = 2;             // Similarity_Matrix semantics in float32
                                        // one query per register: the general instance behind the packed ones
 constexpr int kSemF32U8 = 3;           // Similarity_Matrix_Skewed cell rule on integer-valued float32 cells, one query per
                                        // register: a lone uint8-engine query (the packed instance would carry it twice)
+constexpr int kSemF16 = 4;             // Similarity_Matrix semantics on small integer scores in packed FLOAT16 cells (exact while
+                                       // every value stays within +-2048), two queries per register: gfx950's three-input
+                                       // packed maximum folds the zero floor into the cell and halves the running-maximum ops
 constexpr float kPadScoreF = -1.0e30f;
 __host__ __device__ constexpr bool sem_is_float(int sem) { return sem == kSemF32 || sem == kSemF32U8; }
 
@@ -114,8 +117,37 @@ template <int SEM> struct CellF {
   static __device__ __forceinline__ T sub_gap(T t, uint32_t gap2) { return t - __uint_as_float(gap2); }
   static __device__ __forceinline__ T cell(T x, T y) { return fmaxf(fmaxf(x, y), 0.0f); }
 };
+// Packed float16 cells, handled as raw 32 bits (two halves); every operation is one VOP3P instruction.
+template <> struct Cell<kSemF16> {
+  typedef uint32_t T;
+  static constexpr int kQueries = 2;
+  static __device__ __forceinline__ T from_bits(uint32_t v) { return v; }
+  static __device__ __forceinline__ uint32_t bits(T v) { return v; }
+  static __device__ __forceinline__ T add(T d, T sc, uint32_t) {
+    T r; asm("v_pk_add_f16 %0, %1, %2" : "=v"(r) : "v"(d), "v"(sc)); return r;
+  }
+  static __device__ __forceinline__ T vmax(T a, T b) {
+    T r; asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+  }
+  static __device__ __forceinline__ T vmax3(T a, T b, T c) {
+    T r; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+  }
+  // gap2 holds -g in both halves; the zero floor is applied by cell()
+  static __device__ __forceinline__ T sub_gap(T t, uint32_t gap2) {
+    T r; asm("v_pk_add_f16 %0, %1, %2" : "=v"(r) : "v"(t), "s"(gap2)); return r;
+  }
+  static __device__ __forceinline__ T cell(T x, T y) {
+    T r; asm("v_pk_maximum3_f16 %0, %1, %2, 0" : "=v"(r) : "v"(x), "v"(y)); return r;
+  }
+};
 template <> struct Cell<kSemF32> : CellF<kSemF32> {};
 template <> struct Cell<kSemF32U8> : CellF<kSemF32U8> {};
+
+// three-input maximum where the cell type has one (packed float16), else two steps
+template <int SEM> __device__ __forceinline__ typename Cell<SEM>::T cell_max3(typename Cell<SEM>::T a, typename Cell<SEM>::T b, typename Cell<SEM>::T c) {
+  if constexpr (SEM == kSemF16) return Cell<SEM>::vmax3(a, b, c);
+  else return Cell<SEM>::vmax(Cell<SEM>::vmax(a, b), c);
+}
 
 // value of the lane above inside the 16-lane DPP row, 0 for the first lane (row H(0,.) = 0)
 __device__ __forceinline__ uint32_t row_shr1(uint32_t v) {
@@ -188,9 +220,11 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
         const float *ft = static_cast<const float *>(a.stab);
         e32 = __float_as_uint((i < mA) ? ft[(int)xA[i] * a.ncodes + c] : kPadScoreF);
       } else {
+        // 16-bit table entries: int16 scores, or float16 bit patterns for the packed float16 instance
         const int16_t *st = static_cast<const int16_t *>(a.stab);
-        const int sa = (i < mA) ? st[(int)xA[i] * a.ncodes + c] : kPadScore;
-        const int sb = (i < mB) ? st[(int)xB[i] * a.ncodes + c] : kPadScore;
+        constexpr int kPadEntry = SEM == kSemF16 ? (int)(int16_t)0xF400 /* float16 -16384 */ : kPadScore;
+        const int sa = (i < mA) ? st[(int)xA[i] * a.ncodes + c] : kPadEntry;
+        const int sb = (i < mB) ? st[(int)xB[i] * a.ncodes + c] : kPadEntry;
         e32 = (uint32_t)(uint16_t)sa | ((uint32_t)(uint16_t)sb << 16);
       }
       prof[(c * PL + ll) * LS + r] = e32;
@@ -424,12 +458,18 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
         T diag = C::from_bits(up_prev);                            // H(i0-1, j-1)
         T north = C::from_bits(up);
         up_prev = up;
+        T tpend = C::from_bits(0u);
+        (void)tpend;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const T w = H[r];
           const T x = C::add(diag, C::from_bits(p[r]), a.clamp2);
           const T t = C::vmax(w, north);
-          if (r & 1) mx = C::vmax(mx, t);                          // covers (r, j-1) and (r-1, j)
+          if (SEM == kSemF16) {
+            // three-input maximum: two odd rows per running-maximum op (t covers cells (r, j-1) and (r-1, j))
+            if ((r & 3) == 1) { if (r + 2 < R) tpend = t; else mx = C::vmax(mx, t); }
+            if ((r & 3) == 3) mx = cell_max3<SEM>(mx, tpend, t);
+          } else if (r & 1) mx = C::vmax(mx, t);                   // covers (r, j-1) and (r-1, j)
           const T y = C::sub_gap(t, a.gap2);
           const T h = C::cell(x, y);
           diag = w;
