@@ -72,6 +72,9 @@ ScoreTable plan_table(const RefData &ref, const mi355_sw_params &p) {
     f.gap = u.G; f.smax = u.M;
     f.gapf = (float)u.G; f.smaxf = (float)u.M;
     f.integral = true;
+    // packed float16 instance (kSemU8H): cells hold (H + 1) / 256, scores are s / 256, padding -64
+    f.htab.resize(f.stab.size());
+    for (size_t k = 0; k < f.stab.size(); ++k) f.htab[k] = half_bits((float)f.stab[k] / 256.0f);
   } else {
     const float g = p.gap;
     if (!(g > 0.0f) || !std::isfinite(g)) { f.why = "gap penalty is not positive: no finite warm-up margin"; return f; }
@@ -134,6 +137,8 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       // lone query: two of its tiles per packed register on whole-wavefront tiles, else one query per register
       b.twin = twin_ok;
       b.sem = b.count == 1 && !b.twin ? kSemF32U8 : kSemU8;
+      // short reads: the same rule in packed float16 cells scaled by 1/256 (4.25 instead of 5.5 ops per cell)
+      if (b.sem == kSemU8 && !b.twin && !b.strips && b.SL != 64 && std::getenv("MI355_SW_NO_F16") == nullptr) b.sem = kSemU8H;
     } else {
       // packed 16-bit cells when scores are small integers and the score bound fits; float32 cells otherwise
       const bool fits = t.integral && (int64_t)t.smax * std::min<int64_t>(b.maxlen, std::max<int64_t>(n, 1)) + t.smax <= 32000;
@@ -199,10 +204,11 @@ int launch_score_twin(int R, bool strips, dim3 grid, size_t shmem, hipStream_t s
 }
 
 // packed float16 cells: short reads only (scores within +-2048), 8- and 16-lane tiles
+template <int SEM>
 int launch_score_f16(int R, int SL, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
   if (SL == 8) {
     switch (R) {
-#define CASE_H8(r) case r: launch_score(sw_score_kernel<r, kSemF16, false, 8>, grid, shmem, st, a); return 0;
+#define CASE_H8(r) case r: launch_score(sw_score_kernel<r, SEM, false, 8>, grid, shmem, st, a); return 0;
       CASE_H8(7) CASE_H8(10) CASE_H8(13) CASE_H8(16) CASE_H8(19) CASE_H8(26) CASE_H8(32)
 #undef CASE_H8
     }
@@ -210,7 +216,7 @@ int launch_score_f16(int R, int SL, dim3 grid, size_t shmem, hipStream_t st, con
   }
   if (SL != 16) return -1;
   switch (R) {
-#define CASE_H(r) case r: launch_score(sw_score_kernel<r, kSemF16, false>, grid, shmem, st, a); return 0;
+#define CASE_H(r) case r: launch_score(sw_score_kernel<r, SEM, false>, grid, shmem, st, a); return 0;
     CASE_H(2) CASE_H(4) CASE_H(6) CASE_H(8) CASE_H(10) CASE_H(12) CASE_H(16) CASE_H(20) CASE_H(24) CASE_H(32)
 #undef CASE_H
   }
@@ -338,10 +344,11 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   a.qfirst = b.first;
   a.qcount = b.count;
   a.nq = (int)q.nq;
-  a.stab = sem_is_float(b.sem) ? ctx->ftab.p : (b.sem == kSemF16 ? ctx->htab.p : ctx->stab.p);
+  a.stab = sem_is_float(b.sem) ? ctx->ftab.p : ((b.sem == kSemF16 || b.sem == kSemU8H) ? ctx->htab.p : ctx->stab.p);
   a.ncodes = ref.ncodes;
   if (sem_is_float(b.sem)) memcpy(&a.gap2, &t.gapf, 4);
   else if (b.sem == kSemF16) a.gap2 = (uint32_t)half_bits(-(float)t.gap) * 0x00010001u;
+  else if (b.sem == kSemU8H) a.gap2 = (uint32_t)half_bits(-(float)t.gap / 256.0f) * 0x00010001u;
   else a.gap2 = (uint32_t)t.gap * 0x00010001u;
   a.clamp2 = 255u * 0x00010001u;
   a.keys = ctx->keys.as<unsigned long long>();
@@ -377,7 +384,8 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   HIPCHK(ctx, hipEventRecord(ctx->score_ev[ctx->score_ev_used], ctx->stream));
   int rc = b.twin ? (b.sem == kSemU8 ? launch_score_twin<kSemU8>(b.R, b.strips, grid, shmem, ctx->stream, a)
                                      : launch_score_twin<kSemI16>(b.R, b.strips, grid, shmem, ctx->stream, a))
-           : b.sem == kSemF16 ? launch_score_f16(b.R, b.SL, grid, shmem, ctx->stream, a)
+           : b.sem == kSemF16 ? launch_score_f16<kSemF16>(b.R, b.SL, grid, shmem, ctx->stream, a)
+           : b.sem == kSemU8H ? launch_score_f16<kSemU8H>(b.R, b.SL, grid, shmem, ctx->stream, a)
            : b.sem == kSemU8 ? launch_score_R<kSemU8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
            : b.sem == kSemF32U8 ? launch_score_R<kSemF32U8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
            : b.sem == kSemF32 ? launch_score_R<kSemF32>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)

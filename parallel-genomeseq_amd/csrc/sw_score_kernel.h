@@ -46,6 +46,10 @@ constexpr int kSemF32U8 = 3;           // Similarity_Matrix_Skewed cell rule on 
 constexpr int kSemF16 = 4;             // Similarity_Matrix semantics on small integer scores in packed FLOAT16 cells (exact while
                                        // every value stays within +-2048), two queries per register: gfx950's three-input
                                        // packed maximum folds the zero floor into the cell and halves the running-maximum ops
+constexpr int kSemU8H = 5;             // Similarity_Matrix_Skewed semantics in packed float16 cells holding (H + 1) / 256: the
+                                       // [0, 1] clamp of v_pk_add_f16 is then the saturation at 255 (the lower clamp, H = -1,
+                                       // lies below the explicit floor 1/256), so a cell costs the same four ops as kSemF16
+constexpr uint32_t kU8HZero = 0x1C001C00u;   // float16 1/256 in both halves: H = 0
 constexpr float kPadScoreF = -1.0e30f;
 __host__ __device__ constexpr bool sem_is_float(int sem) { return sem == kSemF32 || sem == kSemF32U8; }
 
@@ -140,12 +144,25 @@ template <> struct Cell<kSemF16> {
     T r; asm("v_pk_maximum3_f16 %0, %1, %2, 0" : "=v"(r) : "v"(x), "v"(y)); return r;
   }
 };
+template <> struct Cell<kSemU8H> : Cell<kSemF16> {
+  // adds(nw, +M) saturating at 255 / subs(nw, X): one clamped add in the (H + 1) / 256 representation
+  static __device__ __forceinline__ T add(T d, T sc, uint32_t) {
+    T r; asm("v_pk_add_f16 %0, %1, %2 clamp" : "=v"(r) : "v"(d), "v"(sc)); return r;
+  }
+  // max(x, w - g, n - g, 0): the floor H = 0 is the constant 1/256
+  static __device__ __forceinline__ T cell(T x, T y) {
+    T r; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "s"(kU8HZero)); return r;
+  }
+};
 template <> struct Cell<kSemF32> : CellF<kSemF32> {};
 template <> struct Cell<kSemF32U8> : CellF<kSemF32U8> {};
 
+// bit pattern of H = 0 in a cell register
+template <int SEM> __host__ __device__ constexpr uint32_t zero_bits() { return SEM == kSemU8H ? kU8HZero : 0u; }
+
 // three-input maximum where the cell type has one (packed float16), else two steps
 template <int SEM> __device__ __forceinline__ typename Cell<SEM>::T cell_max3(typename Cell<SEM>::T a, typename Cell<SEM>::T b, typename Cell<SEM>::T c) {
-  if constexpr (SEM == kSemF16) return Cell<SEM>::vmax3(a, b, c);
+  if constexpr (SEM == kSemF16 || SEM == kSemU8H) return Cell<SEM>::vmax3(a, b, c);
   else return Cell<SEM>::vmax(Cell<SEM>::vmax(a, b), c);
 }
 
@@ -222,7 +239,8 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
       } else {
         // 16-bit table entries: int16 scores, or float16 bit patterns for the packed float16 instance
         const int16_t *st = static_cast<const int16_t *>(a.stab);
-        constexpr int kPadEntry = SEM == kSemF16 ? (int)(int16_t)0xF400 /* float16 -16384 */ : kPadScore;
+        constexpr int kPadEntry = SEM == kSemF16 ? (int)(int16_t)0xF400 /* float16 -16384 */
+                                  : (SEM == kSemU8H ? (int)(int16_t)0xD400 /* float16 -64 = -16384 / 256 */ : kPadScore);
         const int sa = (i < mA) ? st[(int)xA[i] * a.ncodes + c] : kPadEntry;
         const int sb = (i < mB) ? st[(int)xB[i] * a.ncodes + c] : kPadEntry;
         e32 = (uint32_t)(uint16_t)sa | ((uint32_t)(uint16_t)sb << 16);
@@ -325,7 +343,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   // per-sub-chunk maximum -> per-query key.  Lanes lag lane 0 by up to SL-1 columns, so up to SL-1 trailing
   // columns of a sub-chunk are reported with the next one; the host widens its search accordingly.
   const int64_t subs_per_tile = a.chunk_len / a.sub_len;
-  uint32_t best_a = 0, best_b = 0;                                 // this tile's best published value per query
+  uint32_t best_a = zero_bits<SEM>() & 0xFFFFu, best_b = best_a;   // this tile's best published value per query (H = 0: nothing to report)
   auto slot_max = [&]() -> uint32_t {                              // maximum of mx over the slot's lanes
     uint32_t m32 = C::bits(mx);
 #pragma unroll
@@ -416,8 +434,8 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
 
     T H[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) H[r] = C::from_bits(0u);
-    uint32_t up_prev = 0;
+    for (int r = 0; r < R; ++r) H[r] = C::from_bits(zero_bits<SEM>());
+    uint32_t up_prev = zero_bits<SEM>();
 
     for (int seg = 0; seg < nseg; ++seg) {
 #pragma unroll 4
@@ -451,9 +469,15 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
           up = shift_in(C::bits(H[R - 1]), bin_w[k]);
         } else {
           // zero border row H(0, .): bound_ctrl supplies it (no `old` operand to set up)
-          if (SL == 64) up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C::bits(H[R - 1]), 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
-          else up = row_shr1(C::bits(H[R - 1]));
-          if (SL == 8) up &= first_lane_zero;                      // lane 8 of the DPP row starts another tile
+          if (SEM == kSemU8H) {
+            // the border row is the bit pattern of H = 0, not zero: `old` operand, and a bit-select for 8-lane tiles
+            up = shift_in(C::bits(H[R - 1]), kU8HZero);
+            if (SL == 8) up = (up & first_lane_zero) | (kU8HZero & ~first_lane_zero);
+          } else {
+            if (SL == 64) up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C::bits(H[R - 1]), 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+            else up = row_shr1(C::bits(H[R - 1]));
+            if (SL == 8) up &= first_lane_zero;                    // lane 8 of the DPP row starts another tile
+          }
         }
         T diag = C::from_bits(up_prev);                            // H(i0-1, j-1)
         T north = C::from_bits(up);
@@ -465,7 +489,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
           const T w = H[r];
           const T x = C::add(diag, C::from_bits(p[r]), a.clamp2);
           const T t = C::vmax(w, north);
-          if (SEM == kSemF16) {
+          if (SEM == kSemF16 || SEM == kSemU8H) {
             // three-input maximum: two odd rows per running-maximum op (t covers cells (r, j-1) and (r-1, j))
             if ((r & 3) == 1) { if (r + 2 < R) tpend = t; else mx = C::vmax(mx, t); }
             if ((r & 3) == 3) mx = cell_max3<SEM>(mx, tpend, t);
