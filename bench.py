@@ -53,6 +53,10 @@ def ops_per_cell(sl, r, sem, f16=False):
 def uses_f16(args):
     """The library's choice (host_score.h make_buckets): float32 engine, integer scores, every value within the
     exactly representable float16 integers."""
+    if os.environ.get("MI355_SW_NO_F16") is not None or args.read_len > 512:
+        return False
+    if args.semantics == "u8":       # values never leave 0..255: held as (H + 1) / 256 in float16
+        return args.reads >= 2
     ints = all(float(v) == int(v) for v in (args.match, args.mismatch, args.gap))
     return (args.semantics == "f32" and ints and args.gap >= 1 and abs(args.mismatch) <= 2048 and
             args.match * (args.read_len + 1) <= 2040 and args.gap <= 2040 and args.read_len <= 512 and
@@ -235,7 +239,7 @@ def main():
             "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if (args.match != int(args.match) or args.mismatch != int(args.mismatch) or args.gap != int(args.gap)) else ("f16" if f16 else "i16")) if sem == pgs.F32 else "u8",
-            "dtype_note": "f16 = packed 2x float16 cells (every value an integer within +-2048: exact); i16 = packed 2x16-bit integer cells; both exact for the float32 engine's integer scores; u8 = saturating uint8 semantics held in packed 16-bit lanes; f32 = float32 cells (fractional scoring)",
+            "dtype_note": "f16 = packed 2x float16 cells (every value an integer within +-2048: exact); i16 = packed 2x16-bit integer cells; both exact for the float32 engine's integer scores; u8 = saturating uint8 semantics held in packed float16 lanes as (H + 1) / 256 (exact), in packed 16-bit integer lanes for queries beyond 512 rows; f32 = float32 cells (fractional scoring)",
             "data": "synthetic",
             "config": {"workload": "configs[2]: %d x %d bp reads per GPU per step vs %d bp reference (one batch of the 100k-read set)"
                                    % (args.reads, args.read_len, args.ref_len),
