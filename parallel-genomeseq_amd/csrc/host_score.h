@@ -137,8 +137,9 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       // lone query: two of its tiles per packed register on whole-wavefront tiles, else one query per register
       b.twin = twin_ok;
       b.sem = b.count == 1 && !b.twin ? kSemF32U8 : kSemU8;
-      // short reads: the same rule in packed float16 cells scaled by 1/256 (4.25 instead of 5.5 ops per cell)
-      if (b.sem == kSemU8 && !b.twin && !b.strips && b.SL != 64 && std::getenv("MI355_SW_NO_F16") == nullptr) b.sem = kSemU8H;
+      // the same rule in packed float16 cells scaled by 1/256 (4.25 instead of 5.5 ops per cell); values never leave
+      // 0..255, so this holds for every query length
+      if (b.sem == kSemU8 && std::getenv("MI355_SW_NO_F16") == nullptr) b.sem = kSemU8H;
     } else {
       // packed 16-bit cells when scores are small integers and the score bound fits; float32 cells otherwise
       const bool fits = t.integral && (int64_t)t.smax * std::min<int64_t>(b.maxlen, std::max<int64_t>(n, 1)) + t.smax <= 32000;
@@ -374,7 +375,9 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     const size_t bytes = slots * 2 * (size_t)a.brow_stride * 4;
     if (bytes > ((size_t)64 << 30)) return fail(ctx, MI355_SW_ENOTSUP, "strip-mined sweep needs more than 64 GiB of boundary scratch");
     if (ctx->brow.ensure(bytes)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(strip boundary rows) failed");
-    HIPCHK(ctx, hipMemsetAsync(ctx->brow.p, 0, bytes, ctx->stream));
+    // boundary rows start as H = 0 (a non-zero bit pattern in the scaled float16 instance)
+    if (b.sem == kSemU8H) HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->brow.p, (int)kU8HZero, bytes / 4, ctx->stream));
+    else HIPCHK(ctx, hipMemsetAsync(ctx->brow.p, 0, bytes, ctx->stream));
     a.brow = ctx->brow.as<uint32_t>();
     shmem += (size_t)2 * nslot * kSeg * 4 + (size_t)nslot * 64 * 4;   // boundary windows + per-sub-chunk maxima
   }
@@ -382,10 +385,11 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     for (int e = 0; e < 2; ++e) { hipEvent_t ev; HIPCHK(ctx, hipEventCreate(&ev)); ctx->score_ev.push_back(ev); }
   }
   HIPCHK(ctx, hipEventRecord(ctx->score_ev[ctx->score_ev_used], ctx->stream));
-  int rc = b.twin ? (b.sem == kSemU8 ? launch_score_twin<kSemU8>(b.R, b.strips, grid, shmem, ctx->stream, a)
-                                     : launch_score_twin<kSemI16>(b.R, b.strips, grid, shmem, ctx->stream, a))
+  int rc = b.twin ? (b.sem == kSemU8H ? launch_score_twin<kSemU8H>(b.R, b.strips, grid, shmem, ctx->stream, a)
+                     : b.sem == kSemU8 ? launch_score_twin<kSemU8>(b.R, b.strips, grid, shmem, ctx->stream, a)
+                                       : launch_score_twin<kSemI16>(b.R, b.strips, grid, shmem, ctx->stream, a))
            : b.sem == kSemF16 ? launch_score_f16<kSemF16>(b.R, b.SL, grid, shmem, ctx->stream, a)
-           : b.sem == kSemU8H ? launch_score_f16<kSemU8H>(b.R, b.SL, grid, shmem, ctx->stream, a)
+           : b.sem == kSemU8H ? launch_score_R<kSemU8H>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
            : b.sem == kSemU8 ? launch_score_R<kSemU8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
            : b.sem == kSemF32U8 ? launch_score_R<kSemF32U8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
            : b.sem == kSemF32 ? launch_score_R<kSemF32>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)

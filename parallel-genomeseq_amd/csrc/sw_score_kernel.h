@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
       uint32_t e32;
       if (TWIN) {
         const int16_t *st = static_cast<const int16_t *>(a.stab);
-        const int sa = (i < mA) ? st[(int)xA[i] * a.ncodes + c] : kPadScore;
+        const int sa = (i < mA) ? st[(int)xA[i] * a.ncodes + c]
+                                : (SEM == kSemU8H ? (int)(int16_t)0xD400 /* float16 -64 */ : kPadScore);
         reinterpret_cast<uint16_t *>(prof)[((c * PL + ll) * LS) * 2 + r] = (uint16_t)sa;
         continue;
       }
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
     const bool rd = STRIPS && strip > 0, wr = STRIPS && strip + 1 < nstrips;
     // boundary values of stream positions seg*64 + VPL*ls .. +VPL-1
     auto bin_load = [&](int seg) -> uint4 {
-      if (!rd) return make_uint4(0, 0, 0, 0);
+      if (!rd) return make_uint4(zero_bits<SEM>(), zero_bits<SEM>(), zero_bits<SEM>(), zero_bits<SEM>());
       if (VPL == 4) return *reinterpret_cast<const uint4 *>(bin_g + (size_t)seg * kSeg + 4 * ls);
       return make_uint4(bin_g[(size_t)seg * kSeg + ls], 0, 0, 0);
     };
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
       buf2[HIST + ls] = (uint8_t)stage_load(0, true).w[0];
       nextcodes2 = stage_load(1, true);
     }
-    uint4 nextb = make_uint4(0, 0, 0, 0);
+    uint4 nextb = make_uint4(zero_bits<SEM>(), zero_bits<SEM>(), zero_bits<SEM>(), zero_bits<SEM>());
     if (STRIPS) {
       bin_put(bin_load(0));
       nextb = bin_load(1);
