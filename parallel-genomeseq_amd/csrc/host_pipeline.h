@@ -394,7 +394,15 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
   HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
   std::vector<Located> loc(nq);
   std::vector<TraceOut> tout(nq);
-  if (n >= 1 && nq > 0) {
+  // No score can be positive (uint8 engine whose match score saturates to 0; float engine whose best substitution
+  // score is <= 0 with a positive gap): every cell of the matrix is 0 and the defined no-match result stands.
+  bool all_zero = false;
+  if (p.semantics == MI355_SW_U8SAT) all_zero = u8_params(p).M == 0;
+  if (n >= 1 && nq > 0 && !all_zero) {
+    const ScoreTable table = plan_table(ref, p);
+    if (p.semantics == MI355_SW_F32 && table.ok && !(table.smaxf > 0)) all_zero = true;
+  }
+  if (n >= 1 && nq > 0 && !all_zero) {
     const ScoreTable table = plan_table(ref, p);
     // references shorter than 1024 columns never take the score kernel (bucket_fast_ok): skip the length classes
     std::vector<Bucket> buckets;

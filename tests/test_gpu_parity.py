@@ -547,3 +547,15 @@ def test_resident_reference_is_rechecked(ctx, oracle, pgs):
         assert sp["score"] == rb["score"] and sp["pos"] == rb["pos"]
         sp_a = ctx.align_split(q, ref_a.tobytes(), 5, 2.0, sem, sem)
         assert sp_a["score"] == ra["score"]
+
+
+def test_no_positive_score_possible(ctx, oracle, pgs):
+    """Scoring that cannot produce a positive cell (uint8 engine with a match score that truncates to 0; float engine
+    with non-positive scores): the defined no-match result, whatever the problem size."""
+    ref = pgs.synth.dna(601, 20_000).tobytes()
+    q = pgs.synth.dna(602, 15_000).tobytes()
+    for sem, sc in ((1, (0.5, -0.25, 0.25)), (0, (0.0, -1.0, 1.0)), (0, (-1.0, -2.0, 2.0))):
+        got = ctx.align(q, ref, sem, *sc)
+        assert got["score"] == 0 and got["pos"] == 0 and got["cons_x"] == "" and got["end_x"] == 0
+        small = oracle.align(q[:300], ref[:2000], sem, *sc)
+        assert small["score"] == 0 and small["cons_x"] == ""
