@@ -481,6 +481,12 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   const size_t nq = q.nq, nr = ranges.size();
   if (nq == 0 || nr == 0) return 0;
   const ScoreTable table = plan_table(ref, p);
+  // no positive score possible (see align_range): every maximum is 0
+  if ((p.semantics == MI355_SW_U8SAT && u8_params(p).M == 0) ||
+      (p.semantics == MI355_SW_F32 && table.ok && !(table.smaxf > 0))) {
+    for (size_t k = 0; k < nr * nq; ++k) maxima[k] = 0.0f;
+    return 0;
+  }
   int64_t maxn = 0;
   for (auto &r : ranges) maxn = std::max(maxn, r.hi - r.lo);
   std::vector<Bucket> buckets = make_buckets(ref, q, table, p, maxn);
