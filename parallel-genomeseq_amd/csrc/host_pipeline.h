@@ -255,7 +255,7 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
   const bool wave_keyed = p.semantics == MI355_SW_U8SAT;
   auto key_score = [&](size_t k) {
     float score;
-    if (qfloat[k] == 2) score = half_value((uint16_t)(keys[k] >> 32));
+    if (qfloat[k] == 2) score = half_value((uint16_t)(keys[k] >> 32)) * kF16Scale;
     else if (qfloat[k] == 3) score = (uint16_t)(keys[k] >> 32) ? half_value((uint16_t)(keys[k] >> 32)) * 256.0f - 1.0f : 0.0f;
     else if (qfloat[k]) { const uint32_t bits = (uint32_t)(keys[k] >> 32); memcpy(&score, &bits, 4); }
     else score = (float)(int)(keys[k] >> 32);
@@ -517,7 +517,7 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
         if (qfast[k]) {
           const uint32_t hi32 = (uint32_t)(keys[r * nq + k] >> 32);
           float v;
-          if (qfloat[k] == 2) v = half_value((uint16_t)hi32);
+          if (qfloat[k] == 2) v = half_value((uint16_t)hi32) * kF16Scale;
           else if (qfloat[k] == 3) v = (uint16_t)hi32 ? half_value((uint16_t)hi32) * 256.0f - 1.0f : 0.0f;
           else if (qfloat[k]) memcpy(&v, &hi32, 4); else v = (float)hi32;
           maxima[(lo + r) * nq + k] = v;

@@ -100,7 +100,7 @@ ScoreTable plan_table(const RefData &ref, const mi355_sw_params &p) {
     for (int16_t v : f.stab) fits = fits && (v == (int16_t)kPadScore || (v >= -2048 && v <= 2048));
     if (fits) {
       f.htab.resize(f.stab.size());
-      for (size_t k = 0; k < f.stab.size(); ++k) f.htab[k] = half_bits((float)f.stab[k]);
+      for (size_t k = 0; k < f.stab.size(); ++k) f.htab[k] = half_bits((float)f.stab[k] / kF16Scale);   // cells hold H / 2048
     }
   }
   return f;
@@ -348,7 +348,7 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   a.stab = sem_is_float(b.sem) ? ctx->ftab.p : ((b.sem == kSemF16 || b.sem == kSemU8H) ? ctx->htab.p : ctx->stab.p);
   a.ncodes = ref.ncodes;
   if (sem_is_float(b.sem)) memcpy(&a.gap2, &t.gapf, 4);
-  else if (b.sem == kSemF16) a.gap2 = (uint32_t)half_bits(-(float)t.gap) * 0x00010001u;
+  else if (b.sem == kSemF16) a.gap2 = (uint32_t)half_bits(-(float)t.gap / kF16Scale) * 0x00010001u;
   else if (b.sem == kSemU8H) a.gap2 = (uint32_t)half_bits(-(float)t.gap / 256.0f) * 0x00010001u;
   else a.gap2 = (uint32_t)t.gap * 0x00010001u;
   a.clamp2 = 255u * 0x00010001u;

@@ -43,9 +43,11 @@ constexpr int kSemF32 = 2;             // Similarity_Matrix semantics in float32
                                        // one query per register: the general instance behind the packed ones
 constexpr int kSemF32U8 = 3;           // Similarity_Matrix_Skewed cell rule on integer-valued float32 cells, one query per
                                        // register: a lone uint8-engine query (the packed instance would carry it twice)
-constexpr int kSemF16 = 4;             // Similarity_Matrix semantics on small integer scores in packed FLOAT16 cells (exact while
-                                       // every value stays within +-2048), two queries per register: gfx950's three-input
-                                       // packed maximum folds the zero floor into the cell and halves the running-maximum ops
+constexpr int kSemF16 = 4;             // Similarity_Matrix semantics on small integer scores in packed FLOAT16 cells holding
+                                       // H / 2048 (exact while every value stays within +-2048), two queries per register:
+                                       // the [0, 1] clamp of v_pk_add_f16 is the zero floor of the diagonal term and gfx950's
+                                       // three-input packed maximum takes the two gap terms, kept as H - g: 3.5 ops per cell
+constexpr float kF16Scale = 2048.0f;   // cell value = H / kF16Scale
 constexpr int kSemU8H = 5;             // Similarity_Matrix_Skewed semantics in packed float16 cells holding (H + 1) / 256: the
                                        // [0, 1] clamp of v_pk_add_f16 is then the saturation at 255 (the lower clamp, H = -1,
                                        // lies below the explicit floor 1/256), so a cell costs the same four ops as kSemF16
@@ -127,8 +129,9 @@ template <> struct Cell<kSemF16> {
   static constexpr int kQueries = 2;
   static __device__ __forceinline__ T from_bits(uint32_t v) { return v; }
   static __device__ __forceinline__ uint32_t bits(T v) { return v; }
+  // max(diag + score, 0): values are scaled into [0, 1), so the clamp modifier is exactly the zero floor
   static __device__ __forceinline__ T add(T d, T sc, uint32_t) {
-    T r; asm("v_pk_add_f16 %0, %1, %2" : "=v"(r) : "v"(d), "v"(sc)); return r;
+    T r; asm("v_pk_add_f16 %0, %1, %2 clamp" : "=v"(r) : "v"(d), "v"(sc)); return r;
   }
   static __device__ __forceinline__ T vmax(T a, T b) {
     T r; asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
       } else {
         // 16-bit table entries: int16 scores, or float16 bit patterns for the packed float16 instance
         const int16_t *st = static_cast<const int16_t *>(a.stab);
-        constexpr int kPadEntry = SEM == kSemF16 ? (int)(int16_t)0xF400 /* float16 -16384 */
+        constexpr int kPadEntry = SEM == kSemF16 ? (int)(int16_t)0xC800 /* float16 -8 = -16384 / 2048 */
                                   : (SEM == kSemU8H ? (int)(int16_t)0xD400 /* float16 -64 = -16384 / 256 */ : kPadScore);
         const int sa = (i < mA) ? st[(int)xA[i] * a.ncodes + c] : kPadEntry;
         const int sb = (i < mB) ? st[(int)xB[i] * a.ncodes + c] : kPadEntry;
@@ -437,6 +440,9 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) H[r] = C::from_bits(zero_bits<SEM>());
     uint32_t up_prev = zero_bits<SEM>();
+    T Hg[SEM == kSemF16 ? R : 1];                                  // packed float16 instance: H - g of every cell
+#pragma unroll
+    for (int r = 0; r < (SEM == kSemF16 ? R : 1); ++r) Hg[r] = C::from_bits(a.gap2);   // 0 - g
 
     for (int seg = 0; seg < nseg; ++seg) {
 #pragma unroll 4
@@ -485,12 +491,30 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
         up_prev = up;
         T tpend = C::from_bits(0u);
         (void)tpend;
+        if constexpr (SEM == kSemF16) {
+          // H = max(clamp0(NW + s), W - g, N - g): the cell keeps H (next step's diagonal) and H - g (this row's west
+          // term next step, the row below's north term now) — add, maximum3, add per cell; the running maximum takes
+          // two cells per maximum3
+          T ng = C::sub_gap(north, a.gap2);                        // (row above the lane's first) - g
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const T w = H[r];
+            const T x = C::add(diag, C::from_bits(p[r]), a.clamp2);
+            const T h = C::vmax3(x, Hg[r], ng);
+            if (r & 1) mx = C::vmax3(mx, tpend, h);
+            else if (r + 1 < R) tpend = h;
+            else mx = C::vmax(mx, h);
+            diag = w;
+            H[r] = h;
+            ng = Hg[r] = C::sub_gap(h, a.gap2);
+          }
+        } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const T w = H[r];
           const T x = C::add(diag, C::from_bits(p[r]), a.clamp2);
           const T t = C::vmax(w, north);
-          if (SEM == kSemF16 || SEM == kSemU8H) {
+          if (SEM == kSemU8H) {
             // three-input maximum: two odd rows per running-maximum op (t covers cells (r, j-1) and (r-1, j))
             if ((r & 3) == 1) { if (r + 2 < R) tpend = t; else mx = C::vmax(mx, t); }
             if ((r & 3) == 3) mx = cell_max3<SEM>(mx, tpend, t);
@@ -502,6 +526,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
           north = h;
         }
         if (R & 1) mx = C::vmax(mx, H[R - 1]);                     // odd R: the last (even) row is in no tracked t
+        }
         if (STRIPS) {
           if (ls == SL - 1) bout_w[k] = C::bits(H[R - 1]);         // bottom row at stream position seg*64+k-(SL-1)
         }
