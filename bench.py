@@ -41,8 +41,12 @@ def kernel_shape(read_len):
 
 
 def ops_per_cell(sl, r, sem, f16=False):
+    """VALU instructions per cell of the instance that runs: packed ops per step and lane
+    plus DPP / border mask / profile address, for 2R cells."""
     over = 4 if sl == 8 else 3
-    if f16:      # three-input packed maximum: one running-maximum op per two odd rows
+    if f16 and sem == 0:   # float engine, float16 cells: add(clamp), maximum3, add(-g) per cell; one maximum3 per two
+        core = 3 * r + (r + 1) // 2 + 1 + over          # cells for the running maximum; one add for the row above
+    elif f16:              # uint8 engine, float16 cells: add(clamp), max, add(-g), maximum3; one maximum3 per two odd rows
         odd = r // 2
         core = 4 * r + odd // 2 + odd % 2 + (r % 2) + over
     else:
@@ -239,7 +243,7 @@ def main():
             "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if (args.match != int(args.match) or args.mismatch != int(args.mismatch) or args.gap != int(args.gap)) else ("f16" if f16 else "i16")) if sem == pgs.F32 else "u8",
-            "dtype_note": "f16 = packed 2x float16 cells (every value an integer within +-2048: exact); i16 = packed 2x16-bit integer cells; both exact for the float32 engine's integer scores; u8 = saturating uint8 semantics held in packed float16 lanes as (H + 1) / 256 (exact), in packed 16-bit integer lanes for queries beyond 512 rows; f32 = float32 cells (fractional scoring)",
+            "dtype_note": "f16 = packed 2x float16 cells holding H / 2048 (every H an integer within +-2048: exact); i16 = packed 2x16-bit integer cells; both exact for the float32 engine's integer scores; u8 = saturating uint8 semantics held in packed float16 lanes as (H + 1) / 256 (exact), in packed 16-bit integer lanes for queries beyond 512 rows; f32 = float32 cells (fractional scoring)",
             "data": "synthetic",
             "config": {"workload": "configs[2]: %d x %d bp reads per GPU per step vs %d bp reference (one batch of the 100k-read set)"
                                    % (args.reads, args.read_len, args.ref_len),
