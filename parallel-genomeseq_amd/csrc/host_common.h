@@ -94,12 +94,13 @@ struct mi355_sw_ctx {
   bool adhoc_valid = false;
   QueryBatch one;                 // the single query of such a call
   // scratch
-  DevBuf keys, ranges, stab, ftab, htab, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs;
+  DevBuf keys, ranges, stab, ftab, ftab_s, htab, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs;
   // host sides of small per-call uploads: they must outlive the asynchronous copies, and the tables are only
   // sent again when they change
   std::vector<int64_t> h_ranges;
   std::vector<int16_t> h_stab;
-  std::vector<float> h_ftab;
+  std::vector<float> h_ftab, h_ftab_s;
+  int fshift = 0;                 // float32 score instance: cells hold H * 2^-fshift in this call
   std::vector<uint16_t> h_htab;
   // event pairs around the score launches of a call, read back after the call's first synchronisation
   std::vector<hipEvent_t> score_ev;

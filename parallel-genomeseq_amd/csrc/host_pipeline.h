@@ -257,6 +257,7 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
     float score;
     if (qfloat[k] == 2) score = half_value((uint16_t)(keys[k] >> 32)) * kF16Scale;
     else if (qfloat[k] == 3) score = (uint16_t)(keys[k] >> 32) ? half_value((uint16_t)(keys[k] >> 32)) * 256.0f - 1.0f : 0.0f;
+    else if (qfloat[k] == 4) { const uint32_t bits = (uint32_t)(keys[k] >> 32); memcpy(&score, &bits, 4); score = std::ldexp(score, ctx->fshift); }
     else if (qfloat[k]) { const uint32_t bits = (uint32_t)(keys[k] >> 32); memcpy(&score, &bits, 4); }
     else score = (float)(int)(keys[k] >> 32);
     return score;
@@ -421,7 +422,7 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
         if (rc) return rc;
         for (int k = 0; k < b.count; ++k) {
           const int id = q.order[b.first + k];
-          qfast[id] = 1; qchunk[id] = b.sub_len; qwarm[id] = b.warm; qfloat[id] = b.sem == kSemF16 ? 2 : (b.sem == kSemU8H ? 3 : (sem_is_float(b.sem) ? 1 : 0));
+          qfast[id] = 1; qchunk[id] = b.sub_len; qwarm[id] = b.warm; qfloat[id] = b.sem == kSemF16 ? 2 : (b.sem == kSemU8H ? 3 : (b.sem == kSemF32 ? 4 : (sem_is_float(b.sem) ? 1 : 0)));
         }
       }
       std::vector<unsigned long long> keys;
@@ -507,7 +508,7 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
       if (!b.fast) continue;
       rc = score_launch(ctx, ref, q, sub, p, table, b);
       if (rc) return rc;
-      for (int k = 0; k < b.count; ++k) { qfast[q.order[b.first + k]] = 1; qfloat[q.order[b.first + k]] = b.sem == kSemF16 ? 2 : (b.sem == kSemU8H ? 3 : (sem_is_float(b.sem) ? 1 : 0)); }
+      for (int k = 0; k < b.count; ++k) { qfast[q.order[b.first + k]] = 1; qfloat[q.order[b.first + k]] = b.sem == kSemF16 ? 2 : (b.sem == kSemU8H ? 3 : (b.sem == kSemF32 ? 4 : (sem_is_float(b.sem) ? 1 : 0))); }
     }
     std::vector<unsigned long long> keys;
     rc = score_fetch(ctx, nq * sub.size(), keys);
@@ -519,6 +520,7 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
           float v;
           if (qfloat[k] == 2) v = half_value((uint16_t)hi32) * kF16Scale;
           else if (qfloat[k] == 3) v = (uint16_t)hi32 ? half_value((uint16_t)hi32) * 256.0f - 1.0f : 0.0f;
+          else if (qfloat[k] == 4) { memcpy(&v, &hi32, 4); v = std::ldexp(v, ctx->fshift); }
           else if (qfloat[k]) memcpy(&v, &hi32, 4); else v = (float)hi32;
           maxima[(lo + r) * nq + k] = v;
         }

@@ -297,6 +297,21 @@ int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range>
     ctx->h_ftab = t.ftab;
     HIPCHK(ctx, hipMemcpyAsync(ctx->ftab.p, ctx->h_ftab.data(), ctx->h_ftab.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   }
+  // float32 instance: table and gap scaled by 2^-k, 2^k above every value a cell of this call can take
+  if (!t.ftab.empty()) {
+    int64_t maxrange = 1;
+    for (auto &r : ranges) maxrange = std::max(maxrange, r.hi - r.lo);
+    const double bound = (double)t.smaxf * (double)std::min<int64_t>(std::max(1, q.maxlen), maxrange) + (double)t.smaxf + 1.0;
+    ctx->fshift = std::max(1, std::min(100, std::ilogb(bound) + 2));
+    std::vector<float> scaled(t.ftab.size());
+    for (size_t k = 0; k < scaled.size(); ++k) scaled[k] = std::ldexp(t.ftab[k], -ctx->fshift);
+    const void *was = ctx->ftab_s.p;
+    if (ctx->ftab_s.ensure(scaled.size() * 4 + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
+    if (ctx->ftab_s.p != was || ctx->h_ftab_s != scaled) {
+      ctx->h_ftab_s.swap(scaled);
+      HIPCHK(ctx, hipMemcpyAsync(ctx->ftab_s.p, ctx->h_ftab_s.data(), ctx->h_ftab_s.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+  }
   if (!t.htab.empty()) {
     const void *htab_was = ctx->htab.p;
     if (ctx->htab.ensure(t.htab.size() * 2 + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
@@ -345,9 +360,11 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   a.qfirst = b.first;
   a.qcount = b.count;
   a.nq = (int)q.nq;
-  a.stab = sem_is_float(b.sem) ? ctx->ftab.p : ((b.sem == kSemF16 || b.sem == kSemU8H) ? ctx->htab.p : ctx->stab.p);
+  a.stab = b.sem == kSemF32 ? ctx->ftab_s.p
+           : (sem_is_float(b.sem) ? ctx->ftab.p : ((b.sem == kSemF16 || b.sem == kSemU8H) ? ctx->htab.p : ctx->stab.p));
   a.ncodes = ref.ncodes;
-  if (sem_is_float(b.sem)) memcpy(&a.gap2, &t.gapf, 4);
+  if (b.sem == kSemF32) { const float gs = std::ldexp(t.gapf, -ctx->fshift); memcpy(&a.gap2, &gs, 4); }
+  else if (sem_is_float(b.sem)) memcpy(&a.gap2, &t.gapf, 4);
   else if (b.sem == kSemF16) a.gap2 = (uint32_t)half_bits(-(float)t.gap / kF16Scale) * 0x00010001u;
   else if (b.sem == kSemU8H) a.gap2 = (uint32_t)half_bits(-(float)t.gap / 256.0f) * 0x00010001u;
   else a.gap2 = (uint32_t)t.gap * 0x00010001u;

@@ -157,7 +157,17 @@ template <> struct Cell<kSemU8H> : Cell<kSemF16> {
     T r; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "s"(kU8HZero)); return r;
   }
 };
-template <> struct Cell<kSemF32> : CellF<kSemF32> {};
+// float32 cells hold H * 2^-k with 2^k above every value of the call (a pure exponent shift: every add, subtract
+// and maximum commutes with it exactly), so that the [0, 1] clamp of the add is the zero floor and the cell takes the
+// same three ops as the packed float16 instance: add clamp, max3 with the two kept (H - g) terms, subtract g.
+template <> struct Cell<kSemF32> : CellF<kSemF32> {
+  static __device__ __forceinline__ T add(T d, T sc, uint32_t) {
+    T r; asm("v_add_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(d), "v"(sc)); return r;
+  }
+  static __device__ __forceinline__ T vmax3(T a, T b, T c) {
+    T r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+  }
+};
 template <> struct Cell<kSemF32U8> : CellF<kSemF32U8> {};
 
 // bit pattern of H = 0 in a cell register
@@ -440,9 +450,10 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) H[r] = C::from_bits(zero_bits<SEM>());
     uint32_t up_prev = zero_bits<SEM>();
-    T Hg[SEM == kSemF16 ? R : 1];                                  // packed float16 instance: H - g of every cell
+    constexpr bool kKeepsHg = SEM == kSemF16 || SEM == kSemF32;    // instances that keep H - g of every cell
+    T Hg[kKeepsHg ? R : 1];
 #pragma unroll
-    for (int r = 0; r < (SEM == kSemF16 ? R : 1); ++r) Hg[r] = C::from_bits(a.gap2);   // 0 - g
+    for (int r = 0; r < (kKeepsHg ? R : 1); ++r) Hg[r] = C::sub_gap(C::from_bits(0u), a.gap2);   // 0 - g
 
     for (int seg = 0; seg < nseg; ++seg) {
 #pragma unroll 4
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
         up_prev = up;
         T tpend = C::from_bits(0u);
         (void)tpend;
-        if constexpr (SEM == kSemF16) {
+        if constexpr (SEM == kSemF16 || SEM == kSemF32) {
           // H = max(clamp0(NW + s), W - g, N - g): the cell keeps H (next step's diagonal) and H - g (this row's west
           // term next step, the row below's north term now) — add, maximum3, add per cell; the running maximum takes
           // two cells per maximum3
