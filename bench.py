@@ -44,6 +44,8 @@ def ops_per_cell(sl, r, sem, f16=False):
     """VALU instructions per cell of the instance that runs: packed ops per step and lane
     plus DPP / border mask / profile address, for 2R cells."""
     over = 4 if sl == 8 else 3
+    if sem == "f32cells":  # float32 cells, one query per slot: add(clamp), max3, sub per cell; max3 per two cells
+        return (3 * r + (r + 1) // 2 + 1 + over) / float(r)
     if f16 and sem == 0:   # float engine, float16 cells: add(clamp), maximum3, add(-g) per cell; one maximum3 per two
         core = 3 * r + (r + 1) // 2 + 1 + over          # cells for the running maximum; one add for the row above
     elif f16:              # uint8 engine, float16 cells: add(clamp), max, add(-g), maximum3; one maximum3 per two odd rows
@@ -237,7 +239,8 @@ def main():
                 traffic = None
         kern_cells_per_s = cells_per_step / avg_launch_s
         f16 = uses_f16(args)
-        opc = ops_per_cell(kshape[0], kshape[1], sem, f16)
+        fractional = any(float(v) != int(v) for v in (args.match, args.mismatch, args.gap))
+        opc = ops_per_cell(kshape[0], kshape[1], "f32cells" if (sem == pgs.F32 and fractional) else sem, f16)
         line = {
             "metric": "GCUPS (cell updates/s), 150 bp reads vs 50 Mbp reference, whole job (score + argmax + traceback)",
             "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
