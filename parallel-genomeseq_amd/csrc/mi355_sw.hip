@@ -42,7 +42,7 @@ using namespace mi355sw;
 // ================================= C-ABI ======================================================
 extern "C" {
 
-const char *mi355_sw_build_info(void) { return "mi355_sw gfx950 hip; score kernel 16-lane R={2..32}, 8-lane R={7..32}, 64-lane R={16,32} (+strips, twin) x {i16 pairs, u8sat pairs, f32}; wave/strip/exact kernels"; }
+const char *mi355_sw_build_info(void) { return "mi355_sw gfx950 hip; score kernel 16-lane R={2..32}, 8-lane R={7..32}, 64-lane R={16,32} (+strips, twin) x {f16 pairs, u8 as f16 pairs, i16 pairs, u8sat pairs, f32}; wave/strip/exact kernels"; }
 
 void mi355_sw_default_params(mi355_sw_params *p) {
   if (!p) return;
