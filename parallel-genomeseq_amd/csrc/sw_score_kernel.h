@@ -3,24 +3,28 @@
 // Replaces, for the score pass, Similarity_Matrix::iterate / Similarity_Matrix_Skewed::iterate
 // plus the value half of find_index_of_maximum (reference src/aligner/similaritymatrix.cpp:99-264,
 // :386-561, :21-28, :291-299).  The argmax POSITION and the traceback are recovered afterwards by
-// sw_exact_kernel.h on the one or two tiles that hold the maximum.
+// sw_wave_kernel.h / sw_strip_kernel.h / sw_exact_kernel.h on the one or two sub-chunks that hold the maximum.
 //
 // Layout:
 //   * a tile = (query pair, reference chunk).  16 lanes of a wavefront (one DPP row) own one tile;
 //     lane l owns R consecutive query rows, so a 16-lane slot covers 16*R rows.  A wavefront runs
 //     4 tiles (4 chunks of the same query pair), a 256-thread workgroup 16.
 //   * every VGPR holds TWO cells: low half = query A, high half = query B, same reference column.
-//     All arithmetic is packed 16-bit (v_pk_add_i16 / v_pk_max_i16 / v_pk_sub_u16 clamp).
+//     All arithmetic is packed 16-bit: float16 (v_pk_add_f16 clamp / v_pk_maximum3_f16) where every value fits
+//     +-2048 and for the uint8 engine, integer (v_pk_add_i16 / v_pk_max_i16 / v_pk_sub_u16 clamp) beyond; one
+//     float32 instance (one query per register) covers everything else.
 //   * cells of one anti-diagonal live in the 16 lanes: at step t lane l is at column t - l.  The
 //     only cross-lane traffic is ONE v_mov_b32_dpp row_shr:1 per step (last row of the lane above).
 //   * the substitution scores come from a per-workgroup query profile in LDS,
 //     prof[ref code][lane][row] (packed A|B), read with ds_read_b128; the reference chunk is
 //     streamed through a small per-slot LDS byte window (coalesced global loads, once per 64 steps).
-//   * the running maximum is folded into t = max(W, N), which the recurrence needs anyway, on odd
-//     rows only: t_r covers cell (r, j-1) and cell (r-1, j), so R/2 extra ops per step suffice.
+//   * float16 / float32 cells: H = max3(clamp(NW + s), W - g, N - g) with H - g kept per cell — add, maximum3, add,
+//     and one maximum3 per two cells for the running maximum: 3.5 ops per cell.
+//     Integer cells: add, max(W, N), sat-sub, max — the running maximum is folded into t = max(W, N), which the
+//     recurrence needs anyway, on odd rows only (t_r covers cell (r, j-1) and cell (r-1, j)): 4.5 ops per cell.
 //
-// Per pair of cells: add, max, sub(clamp), max  (+ min for U8SAT)  + 1/2 max  => 2.25 (2.75)
-// lane-ops per cell, against 157 T lane-ops/s/2 of the chip (MI355X_MICROARCH.md).
+// One op = one VOP3P instruction = 4 cycles per wave64 on a SIMD (profiles/r01_valu_instruction_rates*.txt);
+// the kernel is VALU-issue-bound.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
