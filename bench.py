@@ -33,6 +33,8 @@ def kernel_shape(read_len):
     """(SL, R) the library picks for this read length (mi355_sw.hip pick_shape) and the VALU instructions per
     cell of that sw_score_kernel instance: per step and lane 4R (5R uint8) recurrence ops +
     R/2 max-fold + DPP/mask/address/extract, for 2R cells."""
+    if read_len > 512:      # whole-wavefront tiles: one strip up to 2048 rows, 2048-row strips beyond
+        return 64, (16 if read_len <= 1024 else 32)
     r16 = next(r for r in (2, 4, 6, 8, 10, 12, 16, 20, 24, 32) if r >= (read_len + 15) // 16)
     r8 = next((r for r in (7, 10, 13, 16, 19, 26, 32) if r >= (read_len + 7) // 8), 0) if read_len >= 36 else 0
     if r8 and 8 * r8 <= 16 * r16:
