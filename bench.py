@@ -33,8 +33,15 @@ def kernel_shape(read_len):
     """(SL, R) the library picks for this read length (mi355_sw.hip pick_shape) and the VALU instructions per
     cell of that sw_score_kernel instance: per step and lane 4R (5R uint8) recurrence ops +
     R/2 max-fold + DPP/mask/address/extract, for 2R cells."""
-    if read_len > 512:      # whole-wavefront tiles: one strip up to 2048 rows, 2048-row strips beyond
-        return 64, (16 if read_len <= 1024 else 32)
+    if read_len > 2048:     # whole-wavefront tiles in strips: the rows per lane with the fewest padded rows
+        best = None
+        for r in (20, 24, 32):
+            rows = -(-read_len // (64 * r)) * 64 * r
+            if best is None or rows <= best[0]:
+                best = (rows, r)
+        return 64, best[1]
+    if read_len > 512:      # one whole-wavefront strip
+        return 64, next(r for r in (10, 12, 16, 20, 24, 32) if 64 * r >= read_len)
     r16 = next(r for r in (2, 4, 6, 8, 10, 12, 16, 20, 24, 32) if r >= (read_len + 15) // 16)
     r8 = next((r for r in (7, 10, 13, 16, 19, 26, 32) if r >= (read_len + 7) // 8), 0) if read_len >= 36 else 0
     if r8 and 8 * r8 <= 16 * r16:
@@ -61,7 +68,7 @@ def ops_per_cell(sl, r, sem, f16=False):
 def uses_f16(args):
     """The library's choice (host_score.h make_buckets): float32 engine, integer scores, every value within the
     exactly representable float16 integers."""
-    if os.environ.get("MI355_SW_NO_F16") is not None or args.read_len > 512:
+    if os.environ.get("MI355_SW_NO_F16") is not None or args.read_len > 2048:
         return False
     if args.semantics == "u8":       # values never leave 0..255: held as (H + 1) / 256 in float16
         return args.reads >= 2

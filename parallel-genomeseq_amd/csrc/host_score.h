@@ -47,6 +47,22 @@ int pick_R8(int maxlen) {
   return 0;
 }
 
+// Whole-wavefront tiles (queries beyond 512 rows): rows per lane of one strip up to 2048 rows, or of the strips of
+// a longer query — the choice with the fewest padded rows (more rows per lane on ties: fewer strips).
+void pick_shape64(int len, int &R, bool &strips) {
+  static const int one[] = {10, 12, 16, 20, 24, 32};
+  strips = len > 2048;
+  if (!strips) {
+    for (int r : one) if (64 * r >= len) { R = r; return; }
+  }
+  static const int many[] = {20, 24, 32};
+  int64_t best = -1;
+  for (int r : many) {
+    const int64_t rows = (int64_t)((len + 64 * r - 1) / (64 * r)) * 64 * r;
+    if (best < 0 || rows <= best) { best = rows; R = r; }
+  }
+}
+
 // (SL, R) with the fewest padded rows; ties go to 8 lanes (fewer per-step overhead ops per cell)
 void pick_shape(int len, int &SL, int &R) {
   SL = 16; R = len < 1 ? 2 : pick_R(len);
@@ -121,7 +137,7 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
     bool strips = false;
     int SL = 16, R = 32;
     if (len <= kMaxRowsFast) pick_shape(len, SL, R);
-    else if (wide_ok) { SL = 64; R = len <= 1024 ? 16 : 32; strips = len > 2048; }
+    else if (wide_ok) { SL = 64; pick_shape64(len, R, strips); }
     else strips = true;
     if (out.empty() || out.back().R != R || out.back().SL != SL || out.back().strips != strips) {
       Bucket b;
@@ -145,7 +161,7 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       const bool fits = t.integral && (int64_t)t.smax * std::min<int64_t>(b.maxlen, std::max<int64_t>(n, 1)) + t.smax <= 32000;
       b.sem = fits ? kSemI16 : kSemF32;
       // small scores on short reads: packed float16 cells (three-input maximum: 4.25 instead of 4.5 ops per cell)
-      if (fits && !t.htab.empty() && !b.strips && b.SL != 64 && b.count >= 2 &&
+      if (fits && !t.htab.empty() && !b.strips && b.SL != 64 && b.count >= 2 &&   // (on 64-lane tiles it measured no faster)
           (int64_t)t.smax * b.maxlen + t.smax <= 2040 && std::getenv("MI355_SW_NO_F16") == nullptr)
         b.sem = kSemF16;
       // a lone query would fill both halves of every packed register with itself: the float32 instance (one query per
@@ -193,17 +209,22 @@ void launch_score(K kernel, dim3 grid, size_t shmem, hipStream_t st, const Score
 template <int SEM>
 int launch_score_twin(int R, bool strips, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
   if (strips) {
-    if (R != 32) return -1;
-    launch_score(sw_score_kernel<32, SEM, true, 64, true>, grid, shmem, st, a);
-    return 0;
+    switch (R) {
+#define CASE_TS(r) case r: launch_score(sw_score_kernel<r, SEM, true, 64, true>, grid, shmem, st, a); return 0;
+      CASE_TS(20) CASE_TS(24) CASE_TS(32)
+#undef CASE_TS
+    }
+    return -1;
   }
-  if (R == 16) launch_score(sw_score_kernel<16, SEM, false, 64, true>, grid, shmem, st, a);
-  else if (R == 32) launch_score(sw_score_kernel<32, SEM, false, 64, true>, grid, shmem, st, a);
-  else return -1;
-  return 0;
+  switch (R) {
+#define CASE_T(r) case r: launch_score(sw_score_kernel<r, SEM, false, 64, true>, grid, shmem, st, a); return 0;
+    CASE_T(10) CASE_T(12) CASE_T(16) CASE_T(20) CASE_T(24) CASE_T(32)
+#undef CASE_T
+  }
+  return -1;
 }
 
-// packed float16 cells: short reads only (scores within +-2048), 8- and 16-lane tiles
+// packed float16 cells: reads whose scores stay within +-2048, one strip
 template <int SEM>
 int launch_score_f16(int R, int SL, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
   if (SL == 8) {
@@ -211,6 +232,14 @@ int launch_score_f16(int R, int SL, dim3 grid, size_t shmem, hipStream_t st, con
 #define CASE_H8(r) case r: launch_score(sw_score_kernel<r, SEM, false, 8>, grid, shmem, st, a); return 0;
       CASE_H8(7) CASE_H8(10) CASE_H8(13) CASE_H8(16) CASE_H8(19) CASE_H8(26) CASE_H8(32)
 #undef CASE_H8
+    }
+    return -1;
+  }
+  if (SL == 64) {
+    switch (R) {
+#define CASE_HW(r) case r: launch_score(sw_score_kernel<r, SEM, false, 64>, grid, shmem, st, a); return 0;
+      CASE_HW(10) CASE_HW(12) CASE_HW(16) CASE_HW(20) CASE_HW(24) CASE_HW(32)
+#undef CASE_HW
     }
     return -1;
   }
@@ -226,17 +255,22 @@ int launch_score_f16(int R, int SL, dim3 grid, size_t shmem, hipStream_t st, con
 template <int SEM>
 int launch_score_R(int R, int SL, bool strips, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
   if (strips) {
-    if (R != 32) return -1;
-    if (SL == 64) launch_score(sw_score_kernel<32, SEM, true, 64>, grid, shmem, st, a);
-    else if (SL == 16) launch_score(sw_score_kernel<32, SEM, true, 16>, grid, shmem, st, a);
-    else return -1;
-    return 0;
+    if (SL == 16) { if (R != 32) return -1; launch_score(sw_score_kernel<32, SEM, true, 16>, grid, shmem, st, a); return 0; }
+    if (SL != 64) return -1;
+    switch (R) {
+#define CASE_S(r) case r: launch_score(sw_score_kernel<r, SEM, true, 64>, grid, shmem, st, a); return 0;
+      CASE_S(20) CASE_S(24) CASE_S(32)
+#undef CASE_S
+    }
+    return -1;
   }
   if (SL == 64) {
-    if (R == 16) launch_score(sw_score_kernel<16, SEM, false, 64>, grid, shmem, st, a);
-    else if (R == 32) launch_score(sw_score_kernel<32, SEM, false, 64>, grid, shmem, st, a);
-    else return -1;
-    return 0;
+    switch (R) {
+#define CASE_W(r) case r: launch_score(sw_score_kernel<r, SEM, false, 64>, grid, shmem, st, a); return 0;
+      CASE_W(10) CASE_W(12) CASE_W(16) CASE_W(20) CASE_W(24) CASE_W(32)
+#undef CASE_W
+    }
+    return -1;
   }
   if (SL == 8) {
     switch (R) {
