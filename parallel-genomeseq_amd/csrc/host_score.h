@@ -224,7 +224,7 @@ int launch_score_twin(int R, bool strips, dim3 grid, size_t shmem, hipStream_t s
   return -1;
 }
 
-// packed float16 cells: reads whose scores stay within +-2048, one strip
+// packed float16 cells: reads whose scores stay within +-2048, 8- and 16-lane tiles
 template <int SEM>
 int launch_score_f16(int R, int SL, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
   if (SL == 8) {
@@ -232,14 +232,6 @@ int launch_score_f16(int R, int SL, dim3 grid, size_t shmem, hipStream_t st, con
 #define CASE_H8(r) case r: launch_score(sw_score_kernel<r, SEM, false, 8>, grid, shmem, st, a); return 0;
       CASE_H8(7) CASE_H8(10) CASE_H8(13) CASE_H8(16) CASE_H8(19) CASE_H8(26) CASE_H8(32)
 #undef CASE_H8
-    }
-    return -1;
-  }
-  if (SL == 64) {
-    switch (R) {
-#define CASE_HW(r) case r: launch_score(sw_score_kernel<r, SEM, false, 64>, grid, shmem, st, a); return 0;
-      CASE_HW(10) CASE_HW(12) CASE_HW(16) CASE_HW(20) CASE_HW(24) CASE_HW(32)
-#undef CASE_HW
     }
     return -1;
   }
