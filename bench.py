@@ -203,7 +203,7 @@ def main():
 
     # PCIe-inclusive diagnostic (never the headline): host buffers handed over per call
     pcie = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         tp = time.perf_counter()
         ctx.set_reference(ref)
         ctx.batch_upload([r.tobytes() for r in reads])
@@ -277,7 +277,7 @@ def main():
         if pcie is not None:
             line["pcie_inclusive"] = {"gcups": cells_per_step / pcie * 1e-9, "s_per_step": pcie,
                                       "note": "set_reference + batch_upload from host buffers + batch_run, one cold step"}
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:          # rank 0 at N = 1 only
             try:
                 line["cpu_baseline"] = cpu_baseline(pgs, ref, args.read_len)
             except Exception as e:  # the baseline is reported, never required
