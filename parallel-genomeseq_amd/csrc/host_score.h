@@ -160,7 +160,7 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       // packed 16-bit cells when scores are small integers and the score bound fits; float32 cells otherwise
       const bool fits = t.integral && (int64_t)t.smax * std::min<int64_t>(b.maxlen, std::max<int64_t>(n, 1)) + t.smax <= 32000;
       b.sem = fits ? kSemI16 : kSemF32;
-      // small scores on short reads: packed float16 cells (three-input maximum: 4.25 instead of 4.5 ops per cell)
+      // small scores on short reads: packed float16 cells (clamped add + three-input maximum: 3.5 instead of 4.5 ops per cell)
       if (fits && !t.htab.empty() && !b.strips && b.SL != 64 && b.count >= 2 &&   // (on 64-lane tiles it measured no faster)
           (int64_t)t.smax * b.maxlen + t.smax <= 2040 && std::getenv("MI355_SW_NO_F16") == nullptr)
         b.sem = kSemF16;
