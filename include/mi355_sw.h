@@ -87,7 +87,10 @@ void mi355_sw_destroy(mi355_sw_ctx *ctx);
 const char *mi355_sw_last_error(const mi355_sw_ctx *ctx);
 void mi355_sw_default_params(mi355_sw_params *p); /* 3 / -3 / 2, F32, no table */
 
-/* One alignment of x (rows) against y (columns). */
+/* One alignment of x (rows) against y (columns).  The last y of such calls stays resident on the device and is
+ * used again when a later call passes the same bytes (re-hashed on every call, on helper threads, while the call
+ * already runs on the resident copy; a changed buffer costs one extra upload).  A context serves one host thread
+ * at a time; use one context per thread. */
 int mi355_sw_align(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, size_t ny,
                    const mi355_sw_params *params, mi355_sw_result *out);
 
