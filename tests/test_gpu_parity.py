@@ -559,3 +559,18 @@ def test_no_positive_score_possible(ctx, oracle, pgs):
         assert got["score"] == 0 and got["pos"] == 0 and got["cons_x"] == "" and got["end_x"] == 0
         small = oracle.align(q[:300], ref[:2000], sem, *sc)
         assert small["score"] == 0 and small["cons_x"] == ""
+
+
+def test_float16_cells_at_their_exactness_bound(ctx, oracle, pgs):
+    """Packed float16 cells are used while match * (|x| + 1) <= 2040 (integers up to 2048 are exact in float16).
+    Perfect-match reads right at and just past that bound — past it the packed integer instance takes over —
+    must give the exact scores, positions and consensus either way."""
+    ref = pgs.synth.dna(701, 30_000)
+    refb = ref.tobytes()
+    for match, length in ((4.0, 509), (4.0, 510), (5.0, 407), (5.0, 408), (7.0, 290), (7.0, 291), (3.0, 512), (15.0, 135)):
+        reads = [ref[o:o + length].tobytes() for o in (100, 7_777, 20_000)]
+        reads.append(pgs.synth.read_from_ref(ref, 710 + length, length, sub_rate=0.02, indel_rate=0.004)[0].tobytes())
+        got = ctx.align_batch(reads, refb, semantics=0, match=match, mismatch=-2.0, gap=1.0)
+        for q, g in zip(reads, got):
+            _cmp(g, oracle.align(q, refb, 0, match, -2.0, 1.0), "bound match=%g |q|=%d" % (match, length))
+        assert got[0]["score"] == match * length
