@@ -574,3 +574,17 @@ def test_float16_cells_at_their_exactness_bound(ctx, oracle, pgs):
         for q, g in zip(reads, got):
             _cmp(g, oracle.align(q, refb, 0, match, -2.0, 1.0), "bound match=%g |q|=%d" % (match, length))
         assert got[0]["score"] == match * length
+
+
+def test_float32_cells_scaling_extremes(ctx, oracle, pgs):
+    """The float32 score instance holds H * 2^-k (a pure exponent shift, exact): large and tiny fractional scorings
+    must reproduce the oracle's float results bit for bit."""
+    ref = pgs.synth.dna(801, 25_000)
+    refb = ref.tobytes()
+    reads = [pgs.synth.read_from_ref(ref, 810 + k, 150 + 37 * k, sub_rate=0.03, indel_rate=0.006)[0].tobytes() for k in range(5)]
+    for sc in ((1234.5, -777.25, 333.125), (0.001953125, -0.0009765625, 0.00048828125), (98765.0, -43210.5, 12345.75)):
+        got = ctx.align_batch(reads, refb, semantics=0, match=sc[0], mismatch=sc[1], gap=sc[2])
+        for q, g in zip(reads, got):
+            _cmp(g, oracle.align(q, refb, 0, *sc), "scaling %r |q|=%d" % (sc, len(q)))
+        one = ctx.align(reads[0], refb, 0, *sc)
+        _cmp(one, oracle.align(reads[0], refb, 0, *sc), "scaling lone %r" % (sc,))
