@@ -7,9 +7,17 @@ traceback + results on the host, inputs resident in HBM when the timed region st
 
 One "step" = one pass of the hot path over one batch of --reads reads per GPU (default 2048; the
 full 100 000-read set is 49 such batches — 7.5e14 cells — and the per-batch rate is size-normalised).
-Multi-GPU: one process per GPU (torch.distributed / RCCL), reads sharded across ranks, reference
-replicated, no data-path collective; one 8-byte all-reduce per step merges the per-rank best
-(score, read) — weak scaling.
+
+Launch:  python bench.py --gpus N --steps K --warmup W
+  * N = 1: runs in this process.
+  * N > 1: this process touches no GPU; it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    as a CHILD (never exec), relays rank 0's JSON line and exits with the child's code.
+  * already under torch.distributed.run (RANK in the environment — the way the round-end driver starts the N > 1
+    runs): this process is one of the N ranks.
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL over xGMI), reads sharded across ranks,
+reference replicated, no data-path collective; one 8-byte all-reduce(MAX) per step merges the per-rank best
+(score, read) — `value` is weak scaling (per-GPU work fixed); `strong_scaling` times a fixed total (config 3 reads
+split over the ranks; config 5's reference pieces dealt to the ranks, src/aligner/plocalaligner.cpp:110-129).
 
 Prints ONE JSON line on rank 0.
 """
@@ -17,6 +25,7 @@ import argparse
 import importlib.util
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -27,55 +36,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (packed op = 1 lane-op)
-
-
-def kernel_shape(read_len):
-    """(SL, R) the library picks for this read length (mi355_sw.hip pick_shape) and the VALU instructions per
-    cell of that sw_score_kernel instance: per step and lane 4R (5R uint8) recurrence ops +
-    R/2 max-fold + DPP/mask/address/extract, for 2R cells."""
-    if read_len > 2048:     # whole-wavefront tiles in strips: the rows per lane with the fewest padded rows
-        best = None
-        for r in (20, 24, 32):
-            rows = -(-read_len // (64 * r)) * 64 * r
-            if best is None or rows <= best[0]:
-                best = (rows, r)
-        return 64, best[1]
-    if read_len > 512:      # one whole-wavefront strip
-        return 64, next(r for r in (10, 12, 16, 20, 24, 32) if 64 * r >= read_len)
-    r16 = next(r for r in (2, 4, 6, 8, 10, 12, 16, 20, 24, 32) if r >= (read_len + 15) // 16)
-    r8 = next((r for r in (7, 10, 13, 16, 19, 26, 32) if r >= (read_len + 7) // 8), 0) if read_len >= 36 else 0
-    if r8 and 8 * r8 <= 16 * r16:
-        return 8, r8
-    return 16, r16
-
-
-def ops_per_cell(sl, r, sem, f16=False):
-    """VALU instructions per cell of the instance that runs: packed ops per step and lane
-    plus DPP / border mask / profile address, for 2R cells."""
-    over = 4 if sl == 8 else 3
-    if sem == "f32cells":  # float32 cells, one query per slot: add(clamp), max3, sub per cell; max3 per two cells
-        return (3 * r + (r + 1) // 2 + 1 + over) / float(r)
-    if f16 and sem == 0:   # float engine, float16 cells: add(clamp), maximum3, add(-g) per cell; one maximum3 per two
-        core = 3 * r + (r + 1) // 2 + 1 + over          # cells for the running maximum; one add for the row above
-    elif f16:              # uint8 engine, float16 cells: add(clamp), max, add(-g), maximum3; one maximum3 per two odd rows
-        odd = r // 2
-        core = 4 * r + odd // 2 + odd % 2 + (r % 2) + over
-    else:
-        core = (5 if sem == 1 else 4) * r + (r + 1) // 2 + (r % 2) + over
-    return core / (2.0 * r)
-
-
-def uses_f16(args):
-    """The library's choice (host_score.h make_buckets): float32 engine, integer scores, every value within the
-    exactly representable float16 integers."""
-    if os.environ.get("MI355_SW_NO_F16") is not None or args.read_len > 2048:
-        return False
-    if args.semantics == "u8":       # values never leave 0..255: held as (H + 1) / 256 in float16
-        return args.reads >= 2
-    ints = all(float(v) == int(v) for v in (args.match, args.mismatch, args.gap))
-    return (args.semantics == "f32" and ints and args.gap >= 1 and abs(args.mismatch) <= 2048 and
-            args.match * (args.read_len + 1) <= 2040 and args.gap <= 2040 and args.read_len <= 512 and
-            os.environ.get("MI355_SW_NO_F16") is None)
 
 
 def load_package():
@@ -149,6 +109,432 @@ def cpu_baseline(pgs, ref, read_len, seconds_hint=20.0):
             "sample": "4 reads x %d bp vs first %d bp, scalar uint8 score-only port (oracle/sw_oracle.c)" % (read_len, n)}
 
 
+# ------------------------------------------------------------------------------------------------
+# launcher: N > 1 asked for, not yet under torch.distributed.run
+# ------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(args, argv):
+    """Parent of the N ranks: no GPU call, no torch import.  Child = torch.distributed.run with one rank per GPU."""
+    port = int(os.environ.get("MASTER_PORT", "0")) or free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, text=True)
+    line = None
+    for out in child.stdout:                                  # relay; remember the result line
+        s = out.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        else:
+            sys.stderr.write(out)
+    rc = child.wait()
+    if rc != 0 or line is None:
+        sys.stderr.write("bench.py: %d-rank run failed (torch.distributed.run exit code %d, result line %s)\n"
+                         % (args.gpus, rc, "present" if line else "missing"))
+        sys.exit(rc if rc != 0 else 1)
+    rec = json.loads(line)
+    if rec.get("n_gpus") != args.gpus:
+        sys.stderr.write("bench.py: asked for %d ranks, the job reports %r\n" % (args.gpus, rec.get("n_gpus")))
+        sys.exit(1)
+    rec["launcher"] = "bench.py spawned torch.distributed.run --nproc-per-node %d as a child process" % args.gpus
+    print(json.dumps(rec))
+    sys.exit(0)
+
+
+# ------------------------------------------------------------------------------------------------
+# worker
+# ------------------------------------------------------------------------------------------------
+class Dist:
+    """The process group of this job (or none at N = 1): barrier, max-over-ranks, object gather."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.backend = args.dist_backend
+        self.dist = None
+        if self.backend == "gloo":
+            self.local_rank = self.local_rank % max(1, torch.cuda.device_count())   # rehearsal on fewer GPUs than ranks
+        torch.cuda.set_device(self.local_rank)
+        self.cdev = "cuda" if self.backend == "nccl" else "cpu"
+        if self.world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:      # under torch.distributed.run even one rank joins a group
+            import torch.distributed as dist
+            self.dist = dist
+            if self.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(backend="gloo")
+            if dist.get_world_size() != self.world:
+                raise RuntimeError("process group has %d ranks, WORLD_SIZE says %d" % (dist.get_world_size(), self.world))
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def max_float(self, v):
+        if self.dist is None:
+            return float(v)
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.cdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def max_key(self, key):
+        if self.dist is None:
+            return int(key)
+        t = self.torch.tensor([key], dtype=self.torch.int64, device=self.cdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)           # per-rank best (score, index) over xGMI: 8 bytes
+        return int(t.item())
+
+    def gather_objects(self, obj):
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def describe(self):
+        """Per-rank device identity + proof that the collective library saw every rank."""
+        torch = self.torch
+        p = torch.cuda.get_device_properties(self.local_rank)
+        me = {"rank": self.rank, "device": self.local_rank, "name": p.name,
+              "pci_bus_id": "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0)),
+              "host": socket.gethostname(), "pid": os.getpid()}
+        ranks = self.gather_objects(me)
+        info = {"backend": self.backend if self.dist is not None else "none (single process)", "ranks": ranks}
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:
+            info["rccl_version"] = "unavailable: %r" % (e,)
+        if self.dist is not None:
+            t = torch.ones(1, dtype=torch.int64, device=self.cdev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            info["allreduce_sum_of_ones"] = int(t.item())            # == world size iff every rank took part
+            info["distinct_devices"] = len({(r["host"], r["pci_bus_id"]) for r in ranks})
+        return info
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed(D, fn, steps):
+    """barrier + synchronize, `steps` calls, synchronize + barrier; max over ranks of the wall time."""
+    D.barrier(); D.sync()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = fn()
+    D.sync(); D.barrier()
+    return D.max_float(time.perf_counter() - t0), out
+
+
+def engine_rate(pgs, ctx, D, nreads, read_len, ref_len, steps, **kw):
+    """Whole-job rate of another engine / cell type on the resident workload (1 warm-up + `steps` timed)."""
+    ctx.batch_run(raw=True, **kw)
+    dt, _ = timed(D, lambda: ctx.batch_run(raw=True, **kw), steps)
+    tm = ctx.last_timings()
+    ki = ctx.last_kernel()
+    cells = float(nreads) * read_len * ref_len
+    return {"gcups": cells * steps / dt * 1e-9, "ms_per_step": dt / steps * 1e3, "kernel": ki["name"],
+            "kernel_gcups": cells / (tm["score_us"] / max(1, tm["score_launches"]) * 1e-6) * 1e-9 if tm["score_us"] > 0 else None,
+            "valu_ops_per_cell": ki["valu_ops_per_cell"], "steps": steps}
+
+
+def extra_config4(pgs, device, nseq):
+    """configs[3] shape on one GPU: nseq UniProt-shaped protein sequences (first argument) against the 144-aa P02232
+    query (second), identity scoring 3/-3, gap 2, float engine (src/mpi_sw_solve_uniprot.cpp:120)."""
+    lens = pgs.synth.lognormal_lengths(5, nseq)
+    tot = int(lens.sum())
+    allres = pgs.synth.protein(5, tot)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    seqs = [allres[offs[k]:offs[k + 1]].tobytes() for k in range(nseq)]
+    cells = float(tot) * len(pgs.synth.P02232)
+    ctx = pgs.Context(device)
+    try:
+        ctx.set_reference(pgs.synth.P02232)
+        t0 = time.perf_counter()
+        ctx.batch_upload(seqs)
+        up = time.perf_counter() - t0
+        out = {"sequences": nseq, "cells": cells, "upload_s": up}
+        for flags, name in ((pgs.capi.SCORE_ONLY, "score_argmax"), (0, "with_traceback")):
+            ctx.batch_run(semantics=pgs.F32, flags=flags, raw=True)          # first call of a mode sizes its staging buffers
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ctx.batch_run(semantics=pgs.F32, flags=flags, raw=True)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            tm = ctx.last_timings()
+            out[name] = {"wall_ms": best * 1e3, "device_ms": tm["total_us"] * 1e-3, "gcups_wall": cells / best * 1e-9}
+        return out
+    finally:
+        ctx.close()
+
+
+def config5_inputs(pgs, ref_len, qlen):
+    """The 10 kbp query of configs[4]: a substring of the seed-6 reference with 1 % substitutions and 0.1 % indels."""
+    r0 = int(pgs.synth.splitmix64(7, 1)[0] % np.uint64(max(1, ref_len - (qlen + 16))))
+    window = pgs.synth.dna(6, qlen + 16, start=r0)
+    # read_from_ref draws its offset from the same first output of SplitMix64(7): give it a stand-in of the right length
+    class _Ref:
+        def __len__(self): return ref_len
+        def __getitem__(self, sl): return window[sl.start - r0: sl.stop - r0]
+    q, off = pgs.synth.read_from_ref(_Ref(), 7, qlen, sub_rate=0.01, indel_rate=0.001)
+    assert off == r0
+    return q.tobytes(), off
+
+
+def extra_config5(pgs, device, ref_len, qlen):
+    """configs[4] shape on one GPU: one 10 kbp query against the whole 250 Mbp reference, end to end."""
+    q, off = config5_inputs(pgs, ref_len, qlen)
+    ref = pgs.synth.dna(6, ref_len)
+    ctx = pgs.Context(device)
+    try:
+        ctx.set_reference(ref)
+        ctx.batch_upload([q])
+        out = {"ref_len": ref_len, "query_len": qlen, "planted_at": off + 1}
+        for sem, name in ((pgs.F32, "f32"), (pgs.U8SAT, "u8")):
+            ctx.batch_run(semantics=sem)
+            t0 = time.perf_counter()
+            r = ctx.batch_run(semantics=sem)[0]
+            dt = time.perf_counter() - t0
+            tm = ctx.last_timings()
+            cells = float(qlen) * ref_len
+            out[name] = {"wall_ms": dt * 1e3, "gcups": cells / dt * 1e-9, "score_kernel_ms": tm["score_us"] * 1e-3,
+                         "locate_ms": tm["locate_us"] * 1e-3, "traceback_ms": tm["trace_us"] * 1e-3,
+                         "kernel": ctx.last_kernel()["name"], "score": r["score"], "pos": r["pos"]}
+        return out
+    finally:
+        ctx.close()
+
+
+def extra_latency(pgs, device):
+    """One-by-one calls, the unchanged-driver loop (src/sw_solve_big.cpp:78-92): one 150 bp read per mi355_sw_align."""
+    ctx = pgs.Context(device)
+    out = {}
+    try:
+        for n in (1_000_000, 50_000_000):
+            refa = pgs.synth.dna(1, n)
+            ref = refa.tobytes()
+            reads = [pgs.synth.read_from_ref(refa, 2 + k, 150)[0].tobytes() for k in range(8)]
+            for sem, name in ((pgs.F32, "f32"), (pgs.U8SAT, "u8")):
+                ctx.align(reads[0], ref, sem)
+                ctx.align(reads[1], ref, sem)
+                t0 = time.perf_counter()
+                for k in range(32):
+                    ctx.align(reads[k % 8], ref, sem)
+                dt = (time.perf_counter() - t0) / 32
+                tm = ctx.last_timings()
+                out["%s_150bp_x_%dMbp" % (name, n // 1_000_000)] = {"ms_per_align": dt * 1e3, "score_kernel_ms": tm["score_us"] * 1e-3,
+                                                                   "gcups": 150.0 * n / dt * 1e-9}
+        return out
+    finally:
+        ctx.close()
+
+
+def strong_config3(pgs, ctx, D, ref, args, sem):
+    """Fixed total: --strong-reads reads of configs[2] split over the ranks (block partition), one pass."""
+    total = args.strong_reads
+    reads, _ = pgs.synth.fast_reads_from_ref(ref, 4242, total, args.read_len)
+    base, rem = divmod(total, D.world)
+    lo = D.rank * base + min(D.rank, rem)
+    hi = lo + base + (1 if D.rank < rem else 0)
+    ctx.batch_upload([r.tobytes() for r in reads[lo:hi]])
+
+    def step():
+        out = ctx.batch_run(semantics=sem, match=args.match, mismatch=args.mismatch, gap=args.gap, raw=True)
+        best = 0
+        if hi > lo:
+            k = int(out["score"].argmax())
+            best = int(np.float32(out["score"][k]).view(np.uint32)) << 32 | (0xFFFFFFFF - (lo + k))
+        return D.max_key(best)
+    dt, best = timed(D, step, 1)
+    cells = float(total) * args.read_len * args.ref_len
+    return {"workload": "%d x %d bp reads in total (block-partitioned over %d rank(s)) vs %d bp" % (total, args.read_len, D.world, args.ref_len),
+            "s": dt, "gcups": cells / dt * 1e-9, "best_read": 0xFFFFFFFF - (best & 0xFFFFFFFF),
+            "best_score": float(np.uint32(best >> 32).view(np.float32))}
+
+
+def strong_config5(pgs, D, args, device):
+    """configs[4]: the pieces of _make_string_range(npiece, |q|, |ref|, 2.0) dealt round-robin to the ranks
+    (plocalaligner.cpp:110-129).  Every rank generates and holds ONLY its own pieces; per-piece maxima by the score
+    kernel; one 8-byte all-reduce(MAX) of (score bits << 32 | ~piece) so that the lowest piece wins ties (:125);
+    the owner re-aligns its piece with default scoring (:135) and the result is broadcast."""
+    n, m, npiece = args.c5_ref_len, args.c5_query_len, args.c5_pieces
+    q, off = config5_inputs(pgs, n, m)
+    ranges = pgs.capi.make_string_range(npiece, m, n, 2.0)
+    mine = list(range(D.rank, npiece, D.world))
+    local, parts, at = [], [], 0
+    for p in mine:
+        l, r = ranges[p]
+        parts.append(pgs.synth.dna(6, r - l, start=l))
+        local.append((at, at + (r - l)))
+        at += r - l
+    ctx = pgs.Context(device)
+    try:
+        if mine:
+            ctx.set_reference(np.concatenate(parts))
+            ctx.batch_upload([q])
+            ctx.score_ranges(local[:1], semantics=pgs.F32)                 # warm-up: scratch buffers, code objects
+
+        def step():
+            key = 0
+            if mine:
+                mx = ctx.score_ranges(local, semantics=pgs.F32)[:, 0]
+                for p, v in zip(mine, mx):
+                    key = max(key, int(np.float32(v).view(np.uint32)) << 32 | (0xFFFFFFFF - p))
+            key = D.max_key(key)
+            piece = 0xFFFFFFFF - (key & 0xFFFFFFFF)
+            res = None
+            if piece in mine:
+                r = ctx.align(q, parts[mine.index(piece)].tobytes(), pgs.F32)
+                res = {"score": r["score"], "pos": r["pos"] + ranges[piece][0], "piece": piece, "cons_len": len(r["cons_x"])}
+            got = [g for g in D.gather_objects(res) if g is not None]
+            return got[0]
+        dt, res = timed(D, step, 1)
+    finally:
+        ctx.close()
+    return {"workload": "1 x %d bp query vs %d bp reference in %d pieces (overlap 2.0) dealt to %d rank(s); each rank holds only its pieces"
+                        % (m, n, npiece, D.world), "s": dt, "gcups": float(m) * n / dt * 1e-9, "winning_piece": res["piece"],
+            "score": res["score"], "pos": res["pos"], "planted_at": off + 1}
+
+
+def worker(args):
+    D = Dist(args)
+    rank, world, local_rank = D.rank, D.world, D.local_rank
+    if "RANK" in os.environ and args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    pgs = load_package()
+    sem = pgs.F32 if args.semantics == "f32" else pgs.U8SAT
+    ctx = pgs.Context(local_rank)
+    ref = pgs.synth.dna(3, args.ref_len)                                   # seed 3 (SURVEY §8d cfg 3)
+    reads, _ = pgs.synth.fast_reads_from_ref(ref, 4 + 7919 * rank, args.reads, args.read_len)
+    ctx.set_reference(ref)
+    ctx.batch_upload([r.tobytes() for r in reads])
+    flags = pgs.capi.SCORE_ONLY if args.score_only else 0
+    cells_per_step = float(args.reads) * args.read_len * args.ref_len
+    group = D.describe()
+
+    def step():
+        out = ctx.batch_run(semantics=sem, match=args.match, mismatch=args.mismatch, gap=args.gap, flags=flags, raw=True)
+        k = int(out["score"].argmax())
+        best = int(np.float32(out["score"][k]).view(np.uint32)) << 32 | (0xFFFFFFFF - (k + rank * args.reads))
+        return out, D.max_key(best)
+
+    # PCIe-inclusive diagnostic (never the headline): host buffers handed over per call
+    pcie = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        tp = time.perf_counter()
+        ctx.set_reference(ref)
+        ctx.batch_upload([r.tobytes() for r in reads])
+        ctx.batch_run(semantics=sem, match=args.match, mismatch=args.mismatch, gap=args.gap, flags=flags, raw=True)
+        pcie = time.perf_counter() - tp
+    for _ in range(args.warmup):
+        step()
+    acc = {"kern_us": 0.0, "launches": 0, "locate_us": 0.0, "trace_us": 0.0}
+
+    def timed_step():
+        r = step()
+        tm = ctx.last_timings()
+        acc["kern_us"] += tm["score_us"]; acc["launches"] += tm["score_launches"]
+        acc["locate_us"] += tm["locate_us"]; acc["trace_us"] += tm["trace_us"]
+        return r
+    dt, _ = timed(D, timed_step, args.steps)
+    ki = ctx.last_kernel()                                                  # the instance the library chose (not re-derived here)
+
+    strong = None
+    if not args.no_strong:
+        strong = {"config3": strong_config3(pgs, ctx, D, ref, args, sem)}
+        ctx.batch_upload([r.tobytes() for r in reads])                      # the weak-scaling batch again
+    extras = None
+    if world == 1 and not args.no_extras:
+        extras = {}
+        extras["u8_engine"] = engine_rate(pgs, ctx, D, args.reads, args.read_len, args.ref_len, 2, semantics=pgs.U8SAT)
+        extras["f32_cells_fractional_scoring"] = dict(
+            engine_rate(pgs, ctx, D, args.reads, args.read_len, args.ref_len, 2, semantics=pgs.F32, match=3.5, mismatch=-3.25, gap=2.0),
+            scoring="3.5 / -3.25 / 2")
+    ctx.close()
+    del ref
+    if strong is not None and not args.no_config5:
+        strong["config5"] = strong_config5(pgs, D, args, local_rank)
+    if extras is not None:
+        extras["one_by_one_calls"] = extra_latency(pgs, local_rank)
+        extras["config4_uniprot_shape"] = extra_config4(pgs, local_rank, args.c4_sequences)
+        if not args.no_config5:
+            extras["config5_whole_reference"] = extra_config5(pgs, local_rank, args.c5_ref_len, args.c5_query_len)
+
+    if rank == 0:
+        total_cells = cells_per_step * args.steps * world
+        gcups = total_cells / dt * 1e-9
+        avg_launch_s = acc["kern_us"] / max(1, acc["launches"]) * 1e-6
+        alg_bytes = float(args.reads) * (args.read_len + args.ref_len + 16)   # SURVEY §8(d): |x|+|y|+16 per alignment
+        achieved = alg_bytes / avg_launch_s * 1e-9
+        traffic, traffic_source = None, None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if (rec.get("reads") == args.reads and rec.get("ref_len") == args.ref_len and rec.get("semantics") == args.semantics
+                        and rec.get("kernel", ki["name"]) == ki["name"]):
+                    traffic = rec["hbm_bytes_per_launch"]
+                    traffic_source = "replay:profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command on this kernel; not measured in this run)"
+            except Exception:
+                traffic = None
+        kern_cells_per_s = cells_per_step / avg_launch_s
+        opc = ki["valu_ops_per_cell"]
+        line = {
+            "metric": "GCUPS (cell updates/s), 150 bp reads vs 50 Mbp reference, whole job (score + argmax + traceback)",
+            "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ki["dtype"] if sem == pgs.F32 else "u8",
+            "dtype_note": "f16 = packed 2x float16 cells holding H / 2048 (every H an integer within +-2048: exact); i16 = packed 2x16-bit integer cells; both exact for the float32 engine's integer scores; u8 = saturating uint8 semantics held in packed float16 lanes as (H + 1) / 256 (exact); f32 = float32 cells (fractional scoring); the instance is the library's choice, reported by mi355_sw_last_kernel",
+            "data": "synthetic",
+            "config": {"workload": "configs[2]: %d x %d bp reads per GPU per step vs %d bp reference (one batch of the 100k-read set)"
+                                   % (args.reads, args.read_len, args.ref_len),
+                       "semantics": "Similarity_Matrix (float32)" if sem == pgs.F32 else "Similarity_Matrix_Skewed (uint8 saturating)",
+                       "reads_per_gpu_per_step": args.reads, "read_len": args.read_len, "ref_len": args.ref_len,
+                       "parallelism": "reads sharded x%d, reference replicated" % world, "score_only": bool(args.score_only)},
+            "process_group": group,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": ki["name"],
+                         "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
+                         "tile": {"chunk_len": ki["chunk_len"], "sub_len": ki["sub_len"], "warm": ki["warm"]},
+                         "note": "scalar recurrence: VALU-bound, not HBM-bound (DESIGN.md §3.4); see valu"},
+            "valu": {"kernel_gcups": kern_cells_per_s * 1e-9, "lane_ops_per_cell": opc,
+                     "achieved_lane_ops_per_s": kern_cells_per_s * opc,
+                     "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                     "frac": kern_cells_per_s * opc / VALU_PEAK_LANE_OPS,
+                     "note": "peak = 2 cycles per wave64 instruction; packed 16-bit (VOP3P) ops issue at 4 (profiles/r01_valu_instruction_rates.txt)"},
+            "phases_ms_per_step": {"score_kernel": acc["kern_us"] / args.steps * 1e-3, "locate": acc["locate_us"] / args.steps * 1e-3,
+                                   "traceback": acc["trace_us"] / args.steps * 1e-3},
+        }
+        if strong is not None:
+            line["strong_scaling"] = strong
+        if extras is not None:
+            line["extras"] = extras
+        if pcie is not None:
+            line["pcie_inclusive"] = {"gcups": cells_per_step / pcie * 1e-9, "s_per_step": pcie,
+                                      "note": "set_reference + batch_upload from host buffers + batch_run, one cold step"}
+        if world == 1 and not args.no_cpu_baseline:          # rank 0 at N = 1 only
+            try:
+                line["cpu_baseline"] = cpu_baseline(pgs, pgs.synth.dna(3, min(args.ref_len, 5_000_000)), args.read_len)
+            except Exception as e:  # the baseline is reported, never required
+                line["cpu_baseline"] = {"value": None, "unit": "GCUPS", "cores": 0, "kind": "reference", "sample": "failed: %r" % (e,)}
+        print(json.dumps(line), flush=True)
+    D.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,130 +549,21 @@ def main():
     ap.add_argument("--mismatch", type=float, default=-3.0)
     ap.add_argument("--gap", type=float, default=2.0, help="non-integer scoring selects the float32-cell kernel instance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the N = 1 side measurements (other engines, configs 4 / 5, one-by-one calls)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling passes")
+    ap.add_argument("--no-config5", action="store_true", help="skip everything that needs the 250 Mbp reference")
+    ap.add_argument("--strong-reads", type=int, default=8192, help="total reads of the strong-scaling pass (all ranks together)")
+    ap.add_argument("--c4-sequences", type=int, default=561_356)
+    ap.add_argument("--c5-ref-len", type=int, default=250_000_000)
+    ap.add_argument("--c5-query-len", type=int, default=10_000)
+    ap.add_argument("--c5-pieces", type=int, default=16)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (rehearsal: ranks may share GPU 0)")
     args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    dist = None
-    if args.dist_backend == "gloo":
-        local_rank = local_rank % max(1, torch.cuda.device_count())   # rehearsal on fewer GPUs than ranks
-    torch.cuda.set_device(local_rank)
-    cdev = "cuda" if args.dist_backend == "nccl" else "cpu"
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:          # under torch.distributed.run even one rank joins a group
-        import torch.distributed as dist
-        if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend="gloo")
-
-    pgs = load_package()
-    sem = pgs.F32 if args.semantics == "f32" else pgs.U8SAT
-    ctx = pgs.Context(local_rank)
-    ref = pgs.synth.dna(3, args.ref_len)                                   # seed 3 (SURVEY §8d cfg 3)
-    reads, _ = pgs.synth.fast_reads_from_ref(ref, 4 + 7919 * rank, args.reads, args.read_len)
-    ctx.set_reference(ref)
-    ctx.batch_upload([r.tobytes() for r in reads])
-    flags = pgs.capi.SCORE_ONLY if args.score_only else 0
-    cells_per_step = float(args.reads) * args.read_len * args.ref_len
-
-    def step():
-        out = ctx.batch_run(semantics=sem, match=args.match, mismatch=args.mismatch, gap=args.gap, flags=flags, raw=True)
-        best = int(out["score"].max()) << 32 | (0xFFFFFFFF - (int(out["score"].argmax()) + rank * args.reads))
-        if dist is not None:
-            t = torch.tensor([best], dtype=torch.int64, device=cdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)                      # per-rank best (score, read) over xGMI
-            best = int(t.item())
-        return out, best
-
-    # PCIe-inclusive diagnostic (never the headline): host buffers handed over per call
-    pcie = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        tp = time.perf_counter()
-        ctx.set_reference(ref)
-        ctx.batch_upload([r.tobytes() for r in reads])
-        ctx.batch_run(semantics=sem, match=args.match, mismatch=args.mismatch, gap=args.gap, flags=flags, raw=True)
-        pcie = time.perf_counter() - tp
-    for _ in range(args.warmup):
-        step()
-    kern_us, kern_launches, locate_us, trace_us = 0.0, 0, 0.0, 0.0
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, best = step()
-        tm = ctx.last_timings()
-        kern_us += tm["score_us"]; kern_launches += tm["score_launches"]
-        locate_us += tm["locate_us"]; trace_us += tm["trace_us"]
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    kshape = kernel_shape(args.read_len)
-    if rank == 0:
-        total_cells = cells_per_step * args.steps * world
-        gcups = total_cells / dt * 1e-9
-        avg_launch_s = kern_us / max(1, kern_launches) * 1e-6
-        alg_bytes = float(args.reads) * (args.read_len + args.ref_len + 16)   # |x|+|y|+16 per alignment
-        achieved = alg_bytes / avg_launch_s * 1e-9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("reads") == args.reads and rec.get("ref_len") == args.ref_len and rec.get("semantics") == args.semantics:
-                    traffic = rec["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
-        kern_cells_per_s = cells_per_step / avg_launch_s
-        f16 = uses_f16(args)
-        fractional = any(float(v) != int(v) for v in (args.match, args.mismatch, args.gap))
-        opc = ops_per_cell(kshape[0], kshape[1], "f32cells" if (sem == pgs.F32 and fractional) else sem, f16)
-        line = {
-            "metric": "GCUPS (cell updates/s), 150 bp reads vs 50 Mbp reference, whole job (score + argmax + traceback)",
-            "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32" if (args.match != int(args.match) or args.mismatch != int(args.mismatch) or args.gap != int(args.gap)) else ("f16" if f16 else "i16")) if sem == pgs.F32 else "u8",
-            "dtype_note": "f16 = packed 2x float16 cells holding H / 2048 (every H an integer within +-2048: exact); i16 = packed 2x16-bit integer cells; both exact for the float32 engine's integer scores; u8 = saturating uint8 semantics held in packed float16 lanes as (H + 1) / 256 (exact), in packed 16-bit integer lanes for queries beyond 512 rows; f32 = float32 cells (fractional scoring)",
-            "data": "synthetic",
-            "config": {"workload": "configs[2]: %d x %d bp reads per GPU per step vs %d bp reference (one batch of the 100k-read set)"
-                                   % (args.reads, args.read_len, args.ref_len),
-                       "semantics": "Similarity_Matrix (float32)" if sem == pgs.F32 else "Similarity_Matrix_Skewed (uint8 saturating)",
-                       "reads_per_gpu_per_step": args.reads, "read_len": args.read_len, "ref_len": args.ref_len,
-                       "parallelism": "reads sharded x%d, reference replicated" % world, "score_only": bool(args.score_only)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "sw_score_kernel<R=%d, SL=%d>" % (kshape[1], kshape[0]),
-                         "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "scalar recurrence: VALU-bound, not HBM-bound (DESIGN.md §5); see valu"},
-            "valu": {"kernel_gcups": kern_cells_per_s * 1e-9, "lane_ops_per_cell": opc,
-                     "achieved_lane_ops_per_s": kern_cells_per_s * opc,
-                     "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                     "frac": kern_cells_per_s * opc / VALU_PEAK_LANE_OPS,
-                     "note": "peak = 2 cycles per wave64 instruction; packed 16-bit (VOP3P) ops issue at 4 (profiles/r01_valu_instruction_rates.txt)"},
-            "phases_ms_per_step": {"score_kernel": kern_us / args.steps * 1e-3, "locate": locate_us / args.steps * 1e-3,
-                                   "traceback": trace_us / args.steps * 1e-3},
-        }
-        if pcie is not None:
-            line["pcie_inclusive"] = {"gcups": cells_per_step / pcie * 1e-9, "s_per_step": pcie,
-                                      "note": "set_reference + batch_upload from host buffers + batch_run, one cold step"}
-        if world == 1 and not args.no_cpu_baseline:          # rank 0 at N = 1 only
-            try:
-                line["cpu_baseline"] = cpu_baseline(pgs, ref, args.read_len)
-            except Exception as e:  # the baseline is reported, never required
-                line["cpu_baseline"] = {"value": None, "unit": "GCUPS", "cores": 0, "kind": "reference", "sample": "failed: %r" % (e,)}
-        print(json.dumps(line))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    ctx.close()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and args.gpus > 1:
+        launch(args, sys.argv[1:])
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -88,9 +88,10 @@ const char *mi355_sw_last_error(const mi355_sw_ctx *ctx);
 void mi355_sw_default_params(mi355_sw_params *p); /* 3 / -3 / 2, F32, no table */
 
 /* One alignment of x (rows) against y (columns).  The last y of such calls stays resident on the device and is
- * used again when a later call passes the same bytes (re-hashed on every call, on helper threads, while the call
- * already runs on the resident copy; a changed buffer costs one extra upload).  A context serves one host thread
- * at a time; use one context per thread. */
+ * used again when a later call passes the same bytes: same length and same 128-bit content hash (two independent
+ * 64-bit hashes; re-hashed on every call, on helper threads, while the call already runs on the resident copy; a
+ * changed buffer costs one extra upload).  MI355_SW_NO_REF_CACHE=1 in the environment switches the reuse off (every
+ * call uploads y).  A context serves one host thread at a time; use one context per thread. */
 int mi355_sw_align(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, size_t ny,
                    const mi355_sw_params *params, mi355_sw_result *out);
 
@@ -144,6 +145,32 @@ int mi355_sw_argmax(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, 
  * [0] score kernel(s), [1] argmax rescan, [2] traceback window + walk, [3] whole call (device),
  * [4] number of score-kernel launches, [5] cells swept by the score kernel(s). */
 int mi355_sw_last_timings(const mi355_sw_ctx *ctx, double out[6]);
+
+/* Which sw_score_kernel instance swept the most cells in the last call (what the `iterate` of
+ * similaritymatrix.cpp:99-264 / :386-561 became for this input): reporting aid for drivers and bench.py, so
+ * that nobody re-derives the library's choice.  cells == 0 when the call did not use the score kernel. */
+enum {
+  MI355_SW_CELL_I16 = 0,   /* two queries per register, packed 16-bit integers */
+  MI355_SW_CELL_U8 = 1,    /* uint8 engine, packed 16-bit integers with explicit saturation */
+  MI355_SW_CELL_F32 = 2,   /* one query per register, float32 cells scaled by 2^-k */
+  MI355_SW_CELL_F32U8 = 3, /* uint8 engine rule on integer-valued float32 cells, one query per register */
+  MI355_SW_CELL_F16 = 4,   /* two queries per register, packed float16 cells holding H / 2048 */
+  MI355_SW_CELL_U8H = 5    /* uint8 engine, packed float16 cells holding (H + 1) / 256 */
+};
+typedef struct {
+  int cell;                 /* MI355_SW_CELL_* */
+  int lanes;                /* lanes per tile: 8, 16 or 64 */
+  int rows_per_lane;        /* R */
+  int strips;               /* query swept in strips of lanes * rows_per_lane rows */
+  int twin;                 /* two tiles of one query per packed register */
+  int64_t chunk_len;        /* own columns per tile */
+  int64_t sub_len;          /* columns per reported sub-chunk maximum */
+  int64_t warm;             /* warm-up columns in front of a tile */
+  double cells;             /* cells this instance swept in the call */
+  double valu_ops_per_cell; /* VALU instructions per cell and lane of the inner loop (cost model) */
+  char name[96];            /* e.g. "sw_score_kernel<R=19, f16x2, SL=8>" */
+} mi355_sw_kernel_info;
+int mi355_sw_last_kernel(const mi355_sw_ctx *ctx, mi355_sw_kernel_info *out);
 
 void mi355_sw_free_result(mi355_sw_result *r);
 void mi355_sw_free_results(mi355_sw_result *r, size_t n);

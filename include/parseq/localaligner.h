@@ -22,7 +22,7 @@ struct AlignerInterface {
   virtual unsigned int getPos() const = 0;
   virtual std::string_view getConsensus_x() const = 0;
   virtual std::string_view getConsensus_y() const = 0;
-  virtual Timings getTimings() const = 0;
+  virtual TimingsVec getTimings() const = 0;
 };
 
 }  // namespace parseq

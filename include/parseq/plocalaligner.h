@@ -66,7 +66,7 @@ class OMPParallelLocalAligner : public ParallelLocalAligner<Similarity_Matrix_Ty
   unsigned int getPos() const override { return pos; }
   std::string_view getConsensus_x() const override { return consensus_x; }
   std::string_view getConsensus_y() const override { return consensus_y; }
-  parseq::Timings getTimings() const override { return sm_timings; }
+  parseq::TimingsVec getTimings() const override { return sm_timings; }
   int getWinningPiece() const { return winning_piece; }
 
  private:

@@ -3,16 +3,28 @@
 //   Abstract_Similarity_Matrix, Similarity_Matrix (float32 engine), Similarity_Matrix_Skewed (uint8
 //   saturating engine), iterate(), find_index_of_maximum(), operator()(row, col), getTimings().
 // Differences, by design:
-//   * the matrix is never materialised by iterate(): it runs the GPU score pass + argmax.  operator()
-//     fills the full matrix on first use through mi355_sw_fill_matrix and is meant for small problems
-//     (throws std::length_error above 2^28 cells);
-//   * getTimings() returns parseq::Timings (two floats, indexable with [] and ()) instead of
-//     Eigen::VectorXf; when <Eigen/Dense> was included first it converts implicitly to VectorXf;
+//   * the matrix is never materialised by iterate(): it runs the GPU score pass + argmax.  operator(),
+//     get_matrix(), print_matrix() and print_matrix_raw() fill the full matrix on first use through
+//     mi355_sw_fill_matrix and are meant for small problems (std::length_error above 2^28 cells);
+//   * Eigen is optional.  When <Eigen/Dense> is on the include path (the reference vendors 3.3.7) the signatures are
+//     the reference's: getTimings() returns Eigen::VectorXf, Similarity_Matrix::get_matrix() a
+//     const Eigen::MatrixXf &, Similarity_Matrix_Skewed::get_matrix() a const MatrixX8u & in the skewed RAW layout
+//     (nrows + 32 pad rows, similaritymatrix.cpp:287).  Without Eigen the same members return parseq::Timings /
+//     parseq::DenseMatrix<T> (column-major, (i, j), rows(), cols(), data(), operator<<).  -DPARSEQ_NO_EIGEN forces that;
 //   * Index types are std::ptrdiff_t (what Eigen::Index is).
 #ifndef PARSEQ_SIMILARITY_MATRIX_H_
 #define PARSEQ_SIMILARITY_MATRIX_H_
 
+#if !defined(PARSEQ_NO_EIGEN) && defined(__has_include)
+#if __has_include(<Eigen/Dense>)
+#include <Eigen/Dense>
+#define PARSEQ_HAVE_EIGEN 1
+#endif
+#endif
+
 #include <cstddef>
+#include <cstdint>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -22,6 +34,7 @@
 #include <string>
 #include <string_view>
 #include <tuple>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -38,10 +51,48 @@ struct Timings {
   float operator()(int i) const { return v[i]; }
   float sum() const { return v[0] + v[1]; }
   int size() const { return 2; }
-#ifdef EIGEN_CORE_H
+#ifdef PARSEQ_HAVE_EIGEN
   operator Eigen::VectorXf() const { Eigen::VectorXf r(2); r(0) = v[0]; r(1) = v[1]; return r; }
 #endif
 };
+
+// Column-major dense matrix: what get_matrix() returns when Eigen is not available.
+template <class T>
+class DenseMatrix {
+ public:
+  DenseMatrix() = default;
+  DenseMatrix(Index rows, Index cols) : nr(rows), nc(cols), buf((size_t)rows * (size_t)cols, T(0)) {}
+  void resize(Index rows, Index cols) { nr = rows; nc = cols; buf.assign((size_t)rows * (size_t)cols, T(0)); }
+  void setZero() { std::fill(buf.begin(), buf.end(), T(0)); }
+  Index rows() const { return nr; }
+  Index cols() const { return nc; }
+  Index size() const { return nr * nc; }
+  T *data() { return buf.data(); }
+  const T *data() const { return buf.data(); }
+  T &operator()(Index i, Index j) { return buf[(size_t)j * (size_t)nr + (size_t)i]; }
+  const T &operator()(Index i, Index j) const { return buf[(size_t)j * (size_t)nr + (size_t)i]; }
+  friend std::ostream &operator<<(std::ostream &os, const DenseMatrix &m) {
+    for (Index i = 0; i < m.nr; ++i) {
+      for (Index j = 0; j < m.nc; ++j) os << (j ? " " : "") << +m(i, j);
+      if (i + 1 < m.nr) os << "\n";
+    }
+    return os;
+  }
+
+ private:
+  Index nr = 0, nc = 0;
+  std::vector<T> buf;
+};
+
+#ifdef PARSEQ_HAVE_EIGEN
+typedef Eigen::VectorXf TimingsVec;      // localaligner.h:16,27 / similaritymatrix.h:23
+typedef Eigen::MatrixXf MatrixF;
+typedef Eigen::Matrix<uint8_t, Eigen::Dynamic, Eigen::Dynamic, Eigen::ColMajor> Matrix8u;
+#else
+typedef Timings TimingsVec;
+typedef DenseMatrix<float> MatrixF;
+typedef DenseMatrix<uint8_t> Matrix8u;
+#endif
 
 // One engine context per host thread (contexts are not thread-safe; independent aligner objects may
 // run concurrently from different threads, as in the reference).  Device from MI355_SW_DEVICE (default 0).
@@ -79,6 +130,7 @@ inline std::shared_ptr<std::vector<float>> tabulate(const scoring_fn &f) {
 }  // namespace parseq
 
 typedef std::pair<parseq::Index, parseq::Index> index_tuple;
+typedef parseq::Matrix8u MatrixX8u;      // similaritymatrix.h:9
 
 class Abstract_Similarity_Matrix {
  public:
@@ -87,10 +139,13 @@ class Abstract_Similarity_Matrix {
   virtual std::tuple<parseq::Index, parseq::Index, float> find_index_of_maximum() const = 0;
   virtual void print_matrix() const = 0;
   virtual float operator()(parseq::Index row, parseq::Index col) const = 0;
-  virtual parseq::Timings getTimings() const = 0;
+  virtual parseq::TimingsVec getTimings() const = 0;
 };
 
 namespace parseq {
+
+constexpr Index kSkewedPadRows = 32;     // N_PACK pad rows of the skewed storage (similaritymatrix.cpp:287)
+
 
 template <int SEMANTICS>
 class Similarity_Matrix_HIP : public Abstract_Similarity_Matrix {
@@ -111,22 +166,40 @@ class Similarity_Matrix_HIP : public Abstract_Similarity_Matrix {
     mi355_sw_last_timings(context(), t);
     timings.v[0] = (float)t[3];
     max_x = ix; max_y = iy; max_v = mx;
-    cells.clear();
+    filled = false;
     iterated = true;
   }
   std::tuple<Index, Index, float> find_index_of_maximum() const override { return {max_x, max_y, max_v}; }
   float operator()(Index row, Index col) const override {
     fill();
-    return cells[(size_t)col * (sequence_x.size() + 1) + (size_t)row];
+    return cells(row, col);
   }
+  // similaritymatrix.cpp:37-39 / :301-311: the (|x|+1) x (|y|+1) matrix, rows = first sequence
   void print_matrix() const override {
     fill();
-    for (size_t i = 0; i <= sequence_x.size(); ++i) {
-      for (size_t j = 0; j <= sequence_y.size(); ++j) std::cout << (*this)((Index)i, (Index)j) << " ";
-      std::cout << "\n";
+    if (SEMANTICS == MI355_SW_U8SAT) std::cout << "\n";
+    std::cout << cells << std::endl;
+  }
+  // similaritymatrix.h:44 (Similarity_Matrix: the float matrix itself) / :73 (Similarity_Matrix_Skewed: the RAW skewed
+  // uint8 storage, raw(ri, rj) with (ri, rj) = trueindex2rawindex(column of y, row of x), 32 zero pad rows)
+  const std::conditional_t<SEMANTICS == MI355_SW_U8SAT, Matrix8u, MatrixF> &get_matrix() const {
+    fill();
+    if constexpr (SEMANTICS == MI355_SW_U8SAT) { fill_raw(); return raw; }
+    else return cells;
+  }
+  // similaritymatrix.cpp:313-321 (skewed engine only in the reference; here the float engine prints its matrix)
+  virtual void print_matrix_raw() const {
+    if constexpr (SEMANTICS == MI355_SW_U8SAT) {
+      fill(); fill_raw();
+      MatrixF m(raw.rows(), raw.cols());
+      for (Index j = 0; j < raw.cols(); ++j)
+        for (Index i = 0; i < raw.rows(); ++i) m(i, j) = (float)raw(i, j);
+      std::cout << "\n" << m << std::endl;
+    } else {
+      print_matrix();
     }
   }
-  Timings getTimings() const override { return timings; }
+  TimingsVec getTimings() const override { return timings; }
   // skewed index maps (similaritymatrix.cpp:330-369); meaningful for the uint8 engine's storage order
   index_tuple rawindex2trueindex(index_tuple raw_index) const {
     size_t a, b;
@@ -140,19 +213,37 @@ class Similarity_Matrix_HIP : public Abstract_Similarity_Matrix {
   }
   // used by SWAligner to publish what its own device call already computed
   void set_result(Index ix, Index iy, float mx, float iterate_us, std::shared_ptr<std::vector<float>> l, float g) {
-    max_x = ix; max_y = iy; max_v = mx; timings.v[0] = iterate_us; lut = std::move(l); gap = g; cells.clear(); iterated = true;
+    max_x = ix; max_y = iy; max_v = mx; timings.v[0] = iterate_us; lut = std::move(l); gap = g; filled = false; iterated = true;
   }
 
  private:
   void fill() const {
-    if (!cells.empty()) return;
+    if (filled) return;
     const size_t n = (sequence_x.size() + 1) * (sequence_y.size() + 1);
     if (n > ((size_t)1 << 28)) throw std::length_error("Similarity_Matrix::operator(): matrix too large to materialise");
-    cells.assign(n, 0.0f);
+    cells.resize((Index)sequence_x.size() + 1, (Index)sequence_y.size() + 1);
+    cells.setZero();
+    raw_filled = false;
+    filled = true;
     if (!iterated) return;   // zero-initialised matrix before iterate(), as the reference
     mi355_sw_params p{lut ? lut->data() : nullptr, 3.0f, -3.0f, gap, SEMANTICS};
+    // column-major over y with |x|+1 rows: exactly the layout mi355_sw_fill_matrix writes
     check(mi355_sw_fill_matrix(context(), sequence_x.data(), sequence_x.size(), sequence_y.data(), sequence_y.size(), &p, cells.data()),
           "Similarity_Matrix::operator()");
+  }
+  // the skewed class's raw storage rebuilt from the true cells (similaritymatrix.cpp:274-289, :353-364)
+  void fill_raw() const {
+    if (raw_filled) return;
+    const Index len_x = (Index)sequence_y.size() + 1, len_y = (Index)sequence_x.size() + 1;   // constructor swap
+    const Index nrows = len_x < len_y ? len_x : len_y, ncols = len_x < len_y ? len_y : len_x;
+    raw.resize(nrows + kSkewedPadRows, ncols);
+    raw.setZero();
+    for (Index ti = 0; ti < len_x; ++ti)
+      for (Index tj = 0; tj < len_y; ++tj) {
+        const index_tuple r = trueindex2rawindex(index_tuple(ti, tj));
+        raw(r.first, r.second) = (uint8_t)cells(tj, ti);
+      }
+    raw_filled = true;
   }
   std::string_view sequence_x, sequence_y;
   std::shared_ptr<std::vector<float>> lut;
@@ -161,7 +252,9 @@ class Similarity_Matrix_HIP : public Abstract_Similarity_Matrix {
   Index max_x = 0, max_y = 0;
   float max_v = 0.0f;
   Timings timings;
-  mutable std::vector<float> cells;
+  mutable MatrixF cells;                   // (|x|+1) x (|y|+1), column-major
+  mutable Matrix8u raw;
+  mutable bool filled = false, raw_filled = false;
 };
 
 }  // namespace parseq

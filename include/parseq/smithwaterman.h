@@ -52,7 +52,7 @@ class SWAligner : public LocalAligner<Similarity_Matrix_Type> {
   std::string_view getConsensus_x() const override { return consensus_x; }
   std::string_view getConsensus_y() const override { return consensus_y; }
   const Similarity_Matrix_Type &getSimilarity_matrix() const override { return similarity_matrix; }
-  parseq::Timings getTimings() const override { return sm_timings; }
+  parseq::TimingsVec getTimings() const override { return sm_timings; }
 
  private:
   parseq::Timings sm_timings;

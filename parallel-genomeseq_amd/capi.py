@@ -16,7 +16,7 @@ EXPORTS = [
     "mi355_sw_align", "mi355_sw_set_reference", "mi355_sw_align_batch", "mi355_sw_batch_upload",
     "mi355_sw_batch_run", "mi355_sw_score_ranges", "mi355_sw_align_split", "mi355_sw_make_string_range", "mi355_sw_fill_matrix",
     "mi355_sw_argmax", "mi355_sw_true2raw", "mi355_sw_raw2true", "mi355_sw_last_timings", "mi355_sw_free_result", "mi355_sw_free_results",
-    "mi355_sw_build_info",
+    "mi355_sw_build_info", "mi355_sw_last_kernel",
 ]
 
 
@@ -30,6 +30,14 @@ class Result(C.Structure):
                 ("cons_x", C.c_void_p), ("cons_y", C.c_void_p), ("cons_len", C.c_size_t),
                 ("timings_us", C.c_float * 2)]
 
+
+class KernelInfo(C.Structure):
+    _fields_ = [("cell", C.c_int), ("lanes", C.c_int), ("rows_per_lane", C.c_int), ("strips", C.c_int), ("twin", C.c_int),
+                ("chunk_len", C.c_int64), ("sub_len", C.c_int64), ("warm", C.c_int64), ("cells", C.c_double),
+                ("valu_ops_per_cell", C.c_double), ("name", C.c_char * 96)]
+
+
+CELL_NAMES = {0: "i16", 1: "u8", 2: "f32", 3: "u8", 4: "f16", 5: "u8"}      # arithmetic type of the cells ("dtype" of bench.py)
 
 _RESULT_DTYPE = np.dtype({"names": ["score", "pos", "end_x", "end_y", "cons_x", "cons_y", "cons_len", "t0", "t1"],
                           "formats": ["<f4", "<u4", "<i8", "<i8", "<u8", "<u8", "<u8", "<f4", "<f4"],
@@ -204,6 +212,15 @@ class Context:
         t = (C.c_double * 6)()
         self._L.mi355_sw_last_timings(self._ctx, t)
         return dict(score_us=t[0], locate_us=t[1], trace_us=t[2], total_us=t[3], score_launches=int(t[4]), cells=t[5])
+
+
+    def last_kernel(self):
+        """The sw_score_kernel instance that swept the most cells in the last call (mi355_sw_last_kernel)."""
+        k = KernelInfo()
+        self._L.mi355_sw_last_kernel(self._ctx, C.byref(k))
+        return dict(cell=k.cell, dtype=CELL_NAMES.get(k.cell, "?"), lanes=k.lanes, rows_per_lane=k.rows_per_lane,
+                    strips=bool(k.strips), twin=bool(k.twin), chunk_len=k.chunk_len, sub_len=k.sub_len, warm=k.warm,
+                    cells=k.cells, valu_ops_per_cell=k.valu_ops_per_cell, name=k.name.decode())
 
 
 def make_string_range(npiece, shortlen, longlen, ratio):

@@ -74,6 +74,13 @@ struct QueryBatch {
 
 struct Range { int64_t lo, hi; };
 
+struct Hash128 {
+  uint64_t a = 0, b = 0;
+  bool operator==(const Hash128 &o) const { return a == o.a && b == o.b; }
+  bool operator!=(const Hash128 &o) const { return !(*this == o); }
+};
+
+
 // One alignment's intermediate state on the host
 struct Located {
   float score = 0;
@@ -90,7 +97,7 @@ struct mi355_sw_ctx {
   RefData ref;                    // resident reference (set_reference)
   QueryBatch batch;               // resident queries (batch_upload)
   RefData adhoc;                  // reference of the last mi355_sw_align-style call, kept while its content hash
-  uint64_t adhoc_hash = 0;        // matches (one-by-one driver loops pass the same reference every time)
+  Hash128 adhoc_hash;             // matches (one-by-one driver loops pass the same reference every time)
   bool adhoc_valid = false;
   QueryBatch one;                 // the single query of such a call
   // scratch
@@ -113,6 +120,7 @@ struct mi355_sw_ctx {
   std::vector<PinBuf> pin_cons;
   size_t cons_used = 0;
   double timings[6] = {0, 0, 0, 0, 0, 0};
+  mi355_sw_kernel_info last_kernel = {};   // score-kernel instance that swept the most cells in the running call
 };
 
 namespace {
@@ -138,6 +146,11 @@ inline float lut_or(const mi355_sw_params &p, uint8_t a, uint8_t b) {
 
 // similaritymatrix.cpp:376-384
 inline int sat8(float a) { return a < 0 ? 0 : (a > 255 ? 255 : (int)(uint8_t)a); }
+
+// Column counts derived from smax / gap ratios are computed in double and clamped before the integer cast: a tiny
+// positive gap penalty (1e-20) would otherwise overflow it (undefined behaviour; INT64_MIN on x86).
+constexpr int64_t kColsMax = (int64_t)1 << 50;
+inline int64_t clamp_cols(double v) { return v >= (double)kColsMax ? kColsMax : (v <= 0 ? 0 : (int64_t)v); }
 
 struct U8Params { int M, X, G; };
 U8Params u8_params(const mi355_sw_params &p) {
@@ -210,19 +223,33 @@ int upload_reference(mi355_sw_ctx *ctx, RefData &r, const char *y, size_t ny) {
   return 0;
 }
 
-// 64-bit content hash, four independent multiply-rotate lanes (memory-bound; ~3 ms for 50 MB)
-uint64_t content_hash_part(const char *p, size_t n) {
+// 128-bit content hash of the caller's reference buffer: two structurally different 64-bit hashes computed in the same
+// pass (xor-multiply-rotate lanes, and add-multiply-xorshift lanes with other constants), memory-bound (~3 ms for 50 MB).
+// Both halves and the length must agree before a resident copy is used.
+Hash128 content_hash_part(const char *p, size_t n) {
   uint64_t h[4] = {0x9E3779B97F4A7C15ull ^ n, 0xBF58476D1CE4E5B9ull, 0x94D049BB133111EBull, 0xD6E8FEB86659FD93ull};
+  uint64_t g[4] = {0xA0761D6478BD642Full + n, 0xE7037ED1A0B428DBull, 0x8EBC6AF09C88C6E3ull, 0x589965CC75374CC3ull};
   size_t k = 0;
   for (; k + 32 <= n; k += 32) {
     uint64_t w[4];
     memcpy(w, p + k, 32);
-    for (int l = 0; l < 4; ++l) { h[l] = (h[l] ^ w[l]) * 0x9FB21C651E98DF25ull; h[l] = (h[l] << 29) | (h[l] >> 35); }
+    for (int l = 0; l < 4; ++l) {
+      h[l] = (h[l] ^ w[l]) * 0x9FB21C651E98DF25ull; h[l] = (h[l] << 29) | (h[l] >> 35);
+      g[l] = (g[l] + w[l]) * 0xD6E8FEB86659FD93ull; g[l] ^= g[l] >> 32;
+    }
   }
-  for (; k < n; ++k) { h[k & 3] = (h[k & 3] ^ (uint8_t)p[k]) * 0x9FB21C651E98DF25ull; h[k & 3] = (h[k & 3] << 29) | (h[k & 3] >> 35); }
-  uint64_t r = h[0];
-  for (int l = 1; l < 4; ++l) r = (r ^ h[l]) * 0xBF58476D1CE4E5B9ull + (r >> 31);
-  return r ^ (r >> 32);
+  for (; k < n; ++k) {
+    h[k & 3] = (h[k & 3] ^ (uint8_t)p[k]) * 0x9FB21C651E98DF25ull; h[k & 3] = (h[k & 3] << 29) | (h[k & 3] >> 35);
+    g[k & 3] = (g[k & 3] + (uint8_t)p[k] + 1) * 0xD6E8FEB86659FD93ull; g[k & 3] ^= g[k & 3] >> 32;
+  }
+  Hash128 r;
+  r.a = h[0]; r.b = g[0];
+  for (int l = 1; l < 4; ++l) {
+    r.a = (r.a ^ h[l]) * 0xBF58476D1CE4E5B9ull + (r.a >> 31);
+    r.b = (r.b + g[l]) * 0x94D049BB133111EBull; r.b ^= r.b >> 29;
+  }
+  r.a ^= r.a >> 32;
+  return r;
 }
 
 // Per-item host loops over a big batch (half a million small alignments per call): four-way on helper threads.
@@ -238,26 +265,36 @@ void parallel_for(size_t n, F fn) {
 }
 
 // Hash of a whole buffer: four independent quarters (hashed on helper threads when the buffer is large), combined.
-uint64_t content_hash(const char *p, size_t n) {
+Hash128 content_hash(const char *p, size_t n) {
   if (n < ((size_t)4 << 20)) return content_hash_part(p, n);
   const size_t q = (n / 4) & ~(size_t)31;
-  std::future<uint64_t> f[3];
+  std::future<Hash128> f[3];
   for (int k = 0; k < 3; ++k) f[k] = std::async(std::launch::async, content_hash_part, p + (size_t)(k + 1) * q, k == 2 ? n - 3 * q : q);
-  uint64_t r = content_hash_part(p, q);
-  for (int k = 0; k < 3; ++k) r = (r ^ f[k].get()) * 0xBF58476D1CE4E5B9ull + (r >> 29);
+  Hash128 r = content_hash_part(p, q);
+  for (int k = 0; k < 3; ++k) {
+    const Hash128 o = f[k].get();
+    r.a = (r.a ^ o.a) * 0xBF58476D1CE4E5B9ull + (r.a >> 29);
+    r.b = (r.b + o.b) * 0x94D049BB133111EBull; r.b ^= r.b >> 31;
+  }
   return r;
 }
 
-// Reference of a single-alignment call: re-used from the previous call when its bytes are identical.
+// MI355_SW_NO_REF_CACHE=1: never reuse the resident copy of a single-alignment call's reference (every call uploads).
+bool adhoc_cache_enabled() {
+  static const bool on = std::getenv("MI355_SW_NO_REF_CACHE") == nullptr;
+  return on;
+}
+
+// Reference of a single-alignment call: re-used from the previous call when length and 128-bit content hash match.
 // `known_hash`: the caller has already hashed y.
-int adhoc_reference(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData **out, const uint64_t *known_hash = nullptr) {
-  const uint64_t h = known_hash ? *known_hash : content_hash(y, ny);
-  if (!(ctx->adhoc_valid && ctx->adhoc.n == ny && ctx->adhoc_hash == h)) {
+int adhoc_reference(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData **out, const Hash128 *known_hash = nullptr) {
+  const Hash128 h = known_hash ? *known_hash : (adhoc_cache_enabled() ? content_hash(y, ny) : Hash128());
+  if (!(adhoc_cache_enabled() && ctx->adhoc_valid && ctx->adhoc.n == ny && ctx->adhoc_hash == h)) {
     ctx->adhoc_valid = false;
     int rc = upload_reference(ctx, ctx->adhoc, y, ny);
     if (rc) return rc;
     ctx->adhoc_hash = h;
-    ctx->adhoc_valid = true;
+    ctx->adhoc_valid = adhoc_cache_enabled();
   }
   *out = &ctx->adhoc;
   return 0;
@@ -267,11 +304,11 @@ int adhoc_reference(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData *
 // hashing 50 MB costs as much as aligning against it, so the call starts on the resident copy while a helper
 // thread re-hashes the caller's buffer, and is repeated on a fresh upload in the rare case the content changed.
 struct AdhocSpeculation {
-  std::future<uint64_t> hash;
+  std::future<Hash128> hash;
   bool active = false;
 };
 int adhoc_begin(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData **out, AdhocSpeculation &sp) {
-  if (ctx->adhoc_valid && ctx->adhoc.n == ny && ny >= ((size_t)1 << 20)) {
+  if (adhoc_cache_enabled() && ctx->adhoc_valid && ctx->adhoc.n == ny && ny >= ((size_t)1 << 20)) {
     sp.hash = std::async(std::launch::async, content_hash, y, ny);
     sp.active = true;
     *out = &ctx->adhoc;
@@ -284,7 +321,7 @@ int adhoc_begin(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData **out
 bool adhoc_confirm(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData **out, AdhocSpeculation &sp, int &rc) {
   if (!sp.active) return true;
   sp.active = false;
-  const uint64_t h = sp.hash.get();
+  const Hash128 h = sp.hash.get();
   if (h == ctx->adhoc_hash) return true;
   ctx->adhoc_valid = false;
   rc = adhoc_reference(ctx, y, ny, out, &h);

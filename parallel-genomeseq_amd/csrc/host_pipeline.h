@@ -26,7 +26,7 @@ int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, co
   // §3.3 for a path that can only use rows 1..i), so the window needs that margin at the argmax row plus room
   // for the horizontal excursions of the walk; the walk kernel checks every cell it visits against the bound.
   const float slope = table.gapf > 0 ? table.smaxf / table.gapf : 0.0f;
-  auto row_need = [&](int64_t i) { return i + (int64_t)std::ceil((double)i * (double)slope) + 2; };
+  auto row_need = [&](int64_t i) { return clamp_cols((double)i + std::ceil((double)i * (double)slope) + 2.0); };
   std::vector<size_t> todo;
   // short reads with identity scoring: decisions by the register-wavefront kernel (lanes = rows of x);
   // long queries (identity scoring, or any table in the float engine): the pipelined strip kernel
@@ -279,7 +279,7 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
     int64_t warm = qwarm[k];
     if (table.gapf > 0) {
       const double spare = std::max(0.0, (double)table.smaxf * (double)q.len[k] - (double)score);
-      warm = std::min<int64_t>(warm, (int64_t)q.len[k] + (int64_t)std::ceil(spare / (double)table.gapf) + 2);
+      warm = std::min<int64_t>(warm, clamp_cols((double)q.len[k] + std::ceil(spare / (double)table.gapf) + 2.0));
     }
     const int64_t first = (int64_t)(0xFFFFFFFFull - (key & 0xFFFFFFFFull));
     loc[k].score = score;
@@ -544,6 +544,10 @@ int check_params(mi355_sw_ctx *ctx, const mi355_sw_params *p) {
   return 0;
 }
 
-void reset_timings(mi355_sw_ctx *ctx) { for (double &t : ctx->timings) t = 0; ctx->score_ev_used = 0; ctx->arenas.clear(); ctx->cons_used = 0; }
+void reset_timings(mi355_sw_ctx *ctx) {
+  for (double &t : ctx->timings) t = 0;
+  ctx->score_ev_used = 0; ctx->arenas.clear(); ctx->cons_used = 0;
+  ctx->last_kernel = mi355_sw_kernel_info{};
+}
 
 }  // namespace

@@ -173,7 +173,7 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
     const double smax = sem_is_float(b.sem) ? (double)t.smaxf : (double)t.smax;
     const double gap = sem_is_float(b.sem) ? (double)t.gapf : (double)t.gap;
     if (smax <= 0 || gap <= 0) b.warm = 0;
-    else b.warm = (int64_t)b.maxlen + (int64_t)std::ceil(smax * b.maxlen / gap);
+    else b.warm = clamp_cols((double)b.maxlen + std::ceil(smax * b.maxlen / gap));
     b.warm = (b.warm + 63) / 64 * 64;
   }
   return out;
@@ -183,6 +183,8 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
 bool bucket_fast_ok(const RefData &ref, const ScoreTable &t, const Bucket &b, int64_t n, const mi355_sw_params &p) {
   if (!t.ok || n < 1 || b.maxlen < 1) return false;
   if (profile_lds_bytes(ref.ncodes, b.R, b.SL) > kProfileLdsMax) return false;  // alphabet too large for this shape
+  // codes travel as bytes: with all 256 byte values present the pad code (256) would alias code 0
+  if (ref.ncodes > 256) return false;
   // the uint8 engine's storage order is only bounded to a few tiles when the reference is the longer side;
   // shorter references take the whole-matrix path (which also holds the |x| == |y| quirk)
   if (p.semantics == MI355_SW_U8SAT && n <= (int64_t)b.maxlen + 1) return false;
@@ -196,6 +198,26 @@ bool bucket_fast_ok(const RefData &ref, const ScoreTable &t, const Bucket &b, in
   // pass of the exact kernel does score + argmax + decisions at once; the tile machinery would idle
   if (n < 1024) return false;
   return true;
+}
+
+// VALU instructions per cell and lane of the instance's inner loop (cost model of DESIGN.md §3.4): per step and
+// lane the recurrence ops of R rows, the running-maximum ops, and the per-step overhead (DPP move, profile address,
+// code extract, border mask on 8-lane tiles), over the cells a register row holds (two for the packed instances).
+double valu_ops_per_cell(const Bucket &b) {
+  const int R = b.R;
+  const double over = b.SL == 8 ? 4.0 : 3.0;
+  double per_step;
+  int cells_per_row = 2;
+  switch (b.sem) {
+    case kSemF32:   per_step = 3.0 * R + (R + 1) / 2 + 1 + over; cells_per_row = 1; break;      // add clamp, max3, sub; max3 per two cells
+    case kSemF32U8: per_step = 6.0 * R + (R + 1) / 2 + over; cells_per_row = 1; break;          // add, min, max, sub, max, max
+    case kSemF16:   per_step = 3.0 * R + (R + 1) / 2 + 1 + over; break;
+    case kSemU8H:   { const int odd = R / 2; per_step = 4.0 * R + odd / 2 + odd % 2 + R % 2 + over; break; }
+    case kSemU8:    per_step = 5.0 * R + (R + 1) / 2 + R % 2 + over; break;
+    default:        per_step = 4.0 * R + (R + 1) / 2 + R % 2 + over; break;
+  }
+  if (b.twin) per_step += R;                                                                    // one v_perm_b32 per row
+  return per_step / (double)(cells_per_row * R);
 }
 
 template <class K>
@@ -446,6 +468,15 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   for (int k = 0; k < b.count; ++k)
     for (auto &r : ranges) cells += (double)q.len[q.order[b.first + k]] * (double)(r.hi - r.lo);
   ctx->timings[5] += cells;
+  if (cells > ctx->last_kernel.cells) {
+    mi355_sw_kernel_info &ki = ctx->last_kernel;
+    ki.cell = b.sem; ki.lanes = b.SL; ki.rows_per_lane = b.R; ki.strips = b.strips; ki.twin = b.twin;
+    ki.chunk_len = b.chunk_len; ki.sub_len = b.sub_len; ki.warm = a.warm; ki.cells = cells;
+    ki.valu_ops_per_cell = valu_ops_per_cell(b);
+    static const char *cellname[] = {"i16x2", "u8 as i16x2", "f32", "u8 as f32", "f16x2", "u8 as f16x2"};
+    std::snprintf(ki.name, sizeof ki.name, "sw_score_kernel<R=%d, %s, SL=%d%s%s>", b.R, cellname[b.sem], b.SL,
+                  b.strips ? ", strips" : "", b.twin ? ", twin" : "");
+  }
   return 0;
 }
 

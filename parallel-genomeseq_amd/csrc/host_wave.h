@@ -256,12 +256,12 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
   // positions into the window: the window needs that margin at the argmax plus room for the walk's excursions
   // along the stream; the walk kernel checks every cell it visits
   const float slope = g > 0 ? (float)(smax / g) : 0.0f;
-  auto lane_need = [&](int64_t a) { return a + (int64_t)std::ceil((double)a * (double)slope) + 2; };
+  auto lane_need = [&](int64_t a) { return clamp_cols((double)a + std::ceil((double)a * (double)slope) + 2.0); };
   std::vector<int64_t> budget(qidx.size()), warm(qidx.size());
   for (size_t k : todo) {
     const int64_t na = orient == 0 ? q.len[qidx[k]] : nref;
     budget[k] = na / 8 + 64;
-    warm[k] = g > 0 ? na + (int64_t)std::ceil(smax * (double)na / g) : (int64_t)1 << 40;
+    warm[k] = g > 0 ? clamp_cols((double)na + std::ceil(smax * (double)na / g)) : (int64_t)1 << 40;
   }
   while (!todo.empty()) {
     std::vector<size_t> next;

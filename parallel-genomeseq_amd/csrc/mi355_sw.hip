@@ -315,6 +315,12 @@ int mi355_sw_last_timings(const mi355_sw_ctx *ctx, double out[6]) {
   return 0;
 }
 
+int mi355_sw_last_kernel(const mi355_sw_ctx *ctx, mi355_sw_kernel_info *out) {
+  if (!ctx || !out) return MI355_SW_EINVAL;
+  *out = ctx->last_kernel;
+  return 0;
+}
+
 void mi355_sw_free_result(mi355_sw_result *r) {
   if (!r) return;
   free(r->cons_x);                    // cons_y points into the same allocation

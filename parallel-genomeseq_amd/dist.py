@@ -48,12 +48,17 @@ def shard_lpt(weights, size):
 
 
 def pack_key(score, index):
-    """(score, index) -> int64 so that MAX picks the highest score, then the LOWEST index."""
-    return (int(score) << 32) | (0xFFFFFFFF - int(index))
+    """(score, index) -> int64 so that MAX picks the highest score, then the LOWEST index.
+    The score travels as its float32 bit pattern (non-negative floats order like their bits — the device keys of
+    sw_score_kernel do the same), so fractional scorings (12.5 against 12.0) keep their order."""
+    s = np.float32(score)
+    if not s >= 0:
+        raise ValueError("scores are maxima of cells >= 0")
+    return (int(s.view(np.uint32)) << 32) | (0xFFFFFFFF - int(index))
 
 
 def unpack_key(key):
-    return key >> 32, 0xFFFFFFFF - (key & 0xFFFFFFFF)
+    return float(np.uint32(key >> 32).view(np.float32)), 0xFFFFFFFF - (key & 0xFFFFFFFF)
 
 
 def allreduce_best(score, index):
@@ -81,15 +86,20 @@ def align_queries_sharded(align_fn, queries, weights=None, gather=True):
     res = align_fn([queries[i] for i in idx]) if len(idx) else []
     gathered = None
     if gather:
-        full = torch.zeros((4, n), dtype=torch.int64, device=_dev())
+        # disjoint shards: SUM == gather (x + 0 is exact in both types); the scores stay float32
+        full = torch.zeros((3, n), dtype=torch.int64, device=_dev())
+        fsc = torch.zeros(n, dtype=torch.float32, device=_dev())
         if len(idx):
-            loc = torch.tensor([[int(r["score"]) for r in res], [r["pos"] for r in res], [r["end_x"] for r in res],
-                                [r["end_y"] for r in res]], dtype=torch.int64, device=_dev())
-            full[:, torch.as_tensor(idx, device=_dev())] = loc
+            loc = torch.tensor([[r["pos"] for r in res], [r["end_x"] for r in res], [r["end_y"] for r in res]],
+                               dtype=torch.int64, device=_dev())
+            at = torch.as_tensor(idx, device=_dev())
+            full[:, at] = loc
+            fsc[at] = torch.tensor([r["score"] for r in res], dtype=torch.float32, device=_dev())
         if size > 1:
-            dist.all_reduce(full, op=dist.ReduceOp.SUM)       # disjoint shards: SUM == gather, one collective
+            dist.all_reduce(full, op=dist.ReduceOp.SUM)
+            dist.all_reduce(fsc, op=dist.ReduceOp.SUM)
         full = full.cpu().numpy()
-        gathered = dict(score=full[0].astype(np.float32), pos=full[1], end_x=full[2], end_y=full[3])
+        gathered = dict(score=fsc.cpu().numpy(), pos=full[0], end_x=full[1], end_y=full[2])
     return idx, res, gathered
 
 
@@ -101,10 +111,10 @@ def align_split_sharded(ranges, piece_maxima_fn, final_align_fn):
     rank, size = world()
     mine = list(range(rank, len(ranges), size))
     maxima = piece_maxima_fn(mine) if mine else []
-    key = 0
+    key = 0                                                   # "no piece": below every packed key (index < 2^32 - 1)
     # serial rule (plocalaligner.cpp:122-129): max_score_l starts at -1, strict '>' -> first piece with the max
     for p, v in zip(mine, maxima):
-        key = max(key, pack_key(int(v) + 1, p))               # +1: a score of 0 still beats "no piece"
+        key = max(key, pack_key(v, p))
     if size > 1:
         t = torch.tensor([key], dtype=torch.int64, device=_dev())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

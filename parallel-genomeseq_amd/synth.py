@@ -19,25 +19,54 @@ def splitmix64(seed, count, start=0):
         return z ^ (z >> np.uint64(31))
 
 
+def _chunks(fn, starts):
+    """Independent chunks of a long sequence on a few threads (numpy releases the GIL inside its loops)."""
+    starts = list(starts)
+    if len(starts) < 4:
+        for s in starts:
+            fn(s)
+        return
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    nthreads = max(1, min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4))
+    with ThreadPoolExecutor(nthreads) as ex:
+        list(ex.map(fn, starts))
+
+
 _DNA = np.frombuffer(b"ACGT", dtype=np.uint8)
 # 20 amino acids, rough UniProt background frequencies (per mille)
 _AA = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
 _AA_W = np.array([83, 14, 55, 68, 39, 71, 23, 59, 58, 97, 24, 41, 47, 39, 55, 66, 54, 69, 11, 29], dtype=np.float64)
 
 
-def dna(seed, length, chunk=1 << 24):
-    """Uniform ACGT: base = "ACGT"[x >> 62]."""
+# public UniProt entry P02232 (LGB1_VICFA), the reference's data/query/P02232.fasta (144 aa), re-typed: the query
+# of the UniProt-shaped batch (src/mpi_sw_solve_uniprot.cpp:52-63,120)
+P02232 = ("MGFTEKQEALVNSSSQLFKQNPSNYSVLFYTIILQKAPTAKAMFSFLKDSAGVVDSPKLGAHAEKVFGMVRDSAVQLRATGEVVLDGKDGSIHIQKGVLDPHFVVVKEALLKTIKEASGD"
+          "KWSEELSAAWEVAYDGLATAIKAA")
+
+
+def dna(seed, length, chunk=1 << 22, start=0):
+    """Uniform ACGT: base = "ACGT"[x >> 62].  `start`: positions [start, start + length) of the same stream, so that
+    a rank can generate only its own piece of a sharded reference."""
     out = np.empty(length, dtype=np.uint8)
-    for s in range(0, length, chunk):
+
+    def part(s):
         n = min(chunk, length - s)
-        out[s:s + n] = _DNA[(splitmix64(seed, n, s) >> np.uint64(62)).astype(np.intp)]
+        out[s:s + n] = _DNA[(splitmix64(seed, n, start + s) >> np.uint64(62)).astype(np.intp)]
+    _chunks(part, range(0, length, chunk))
     return out
 
 
-def protein(seed, length):
+def protein(seed, length, chunk=1 << 22):
     cdf = np.cumsum(_AA_W) / _AA_W.sum()
-    u = (splitmix64(seed, length) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
-    return _AA[np.minimum(np.searchsorted(cdf, u, side="right"), 19)]
+    out = np.empty(length, dtype=np.uint8)
+
+    def part(s):                                              # chunked: 200 M residues would take GBs of temporaries
+        n = min(chunk, length - s)
+        u = (splitmix64(seed, n, s) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+        out[s:s + n] = _AA[np.minimum(np.searchsorted(cdf, u, side="right"), 19)]
+    _chunks(part, range(0, length, chunk))
+    return out
 
 
 def read_from_ref(ref, seed, length, sub_rate=0.01, indel_rate=0.001):

@@ -70,6 +70,44 @@ int main() {
         EXPECT(idx2 == skewed2.trueindex2rawindex(skewed2.rawindex2trueindex(idx2)));
       }
   }
+  {  // get_matrix() (similaritymatrix.h:44,73), print_matrix_raw() (:72), getTimings() as the reference types them
+    std::string sequence_x = "GGTTGACTA";
+    std::string sequence_y = "TGTTACG";
+    auto skewed = Similarity_Matrix_Skewed(sequence_x, sequence_y);
+    auto normal = Similarity_Matrix(sequence_x, sequence_y);
+    auto scoring_function = [](const char &a, const char &b) { return a == b ? 3.0 : -3.0; };
+    skewed.iterate(scoring_function, 2.0);
+    normal.iterate(scoring_function, 2.0);
+    const auto &M = normal.get_matrix();
+    const MatrixX8u &R = skewed.get_matrix();
+    EXPECT(M.rows() == 10 && M.cols() == 8);
+    EXPECT(R.rows() == 8 + 32 && R.cols() == 10);            // nrows + N_PACK pad rows, ncols (similaritymatrix.cpp:287)
+    long used = 0;
+    for (int j = 0; j < 8; j++)
+      for (int i = 0; i < 10; i++) {
+        EXPECT(M(i, j) == normal(i, j));
+        auto [ri, rj] = skewed.trueindex2rawindex(index_tuple(j, i));
+        EXPECT(R(ri, rj) == (uint8_t)M(i, j));
+        used += R(ri, rj) != 0;
+      }
+    long nonzero = 0;
+    for (int j = 0; j < R.cols(); j++)
+      for (int i = 0; i < R.rows(); i++) nonzero += R(i, j) != 0;
+    EXPECT(nonzero == used && used > 10);                     // nothing outside the mapped cells, pad rows are zero
+    auto t = skewed.getTimings();
+    EXPECT(t.size() == 2 && t(0) > 0);
+#ifdef PARSEQ_HAVE_EIGEN
+    const Eigen::MatrixXf &E = normal.get_matrix();
+    Eigen::VectorXf tv = normal.getTimings();
+    Eigen::Index ex, ey;
+    EXPECT(E.maxCoeff(&ex, &ey) == std::get<2>(normal.find_index_of_maximum()));   // similaritymatrix.cpp:21-28
+    EXPECT(ex == std::get<0>(normal.find_index_of_maximum()) && ey == std::get<1>(normal.find_index_of_maximum()));
+    EXPECT(tv.size() == 2);
+    std::printf("Eigen signatures: ok\n");
+#endif
+    skewed.print_matrix_raw();
+    normal.print_matrix();
+  }
   {  // custom scoring through std::function, float engine (SURVEY App. B probe: 9 / pos 2)
     SWAligner<Similarity_Matrix> la("GGTTGACTA", "TGTTACGG", [](const char &a, const char &b) { return a == b ? 2.0f : -1.0f; }, 1.0f);
     EXPECT(la.calculateScore() == 9 && la.getPos() == 2);

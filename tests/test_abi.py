@@ -49,14 +49,14 @@ def test_aligner_mirror_defaults(pgs):
 
 
 def test_cpp_dropin_headers_compile():
-    """include/parseq/*.h (the C++ mirror of the reference classes) compile and link against the C-ABI."""
+    """include/parseq/*.h (the C++ mirror of the reference classes) compile and link against the C-ABI — with the
+    POD fallbacks, and (where the reference's vendored Eigen zip is available) with the reference's Eigen signatures:
+    Eigen::VectorXf getTimings(), const Eigen::MatrixXf &get_matrix(), const MatrixX8u &get_matrix()."""
     import subprocess
-    out = os.path.join(ROOT, "tests", "cpp", "test_dropin.bin")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"),
-                           "-L" + os.path.join(ROOT, "parallel-genomeseq_amd"), "-lmi355_sw",
-                           "-Wl,-rpath," + os.path.join(ROOT, "parallel-genomeseq_amd"), "-o", out])
-    assert os.path.exists(out)
+    subprocess.check_call(["bash", os.path.join(ROOT, "tests", "cpp", "build_dropin.sh")])
+    assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "test_dropin.bin"))
+    if os.path.exists("/root/reference/cmake/eigen-3.3.7.zip"):
+        assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "test_dropin_eigen.bin"))
 
 
 def test_index_maps_match_reference(pgs, golden):

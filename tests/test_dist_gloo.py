@@ -61,7 +61,7 @@ def test_query_sharding_gloo():
         assert o["pos"] == [e["pos"] for e in o["expect"]]
         assert o["end_y"] == [e["end_y"] for e in o["expect"]]
     scores = [e["score"] for e in a["expect"]]
-    assert a["best"] == b["best"] == (int(max(scores)), int(np.argmax(scores)))   # ties -> lowest index
+    assert a["best"] == b["best"] == (float(max(scores)), int(np.argmax(scores)))   # ties -> lowest index
 
 
 def _case_ref_sharding(rank, size, pgs, ob):
@@ -96,6 +96,65 @@ def test_ref_sharding_gloo():
                 assert res[k] == exp[k], (rank, npiece, k)
 
 
+def _fractional_case(pgs, ob, seed):
+    """A query with a degraded second copy, fractional scoring 2.5 / -1.5 / 0.5: for seeds 81 and 138 two pieces'
+    maxima differ by 0.5 only (92.0 | 92.5, 89.0 | 89.5), the larger one in the LATER piece — keys that truncate the
+    score would elect the earlier piece."""
+    ref = pgs.synth.dna(100 + seed, 6000).tobytes()
+    q = pgs.synth.read_from_ref(np.frombuffer(ref, dtype=np.uint8), 7 + seed, 40, sub_rate=0.08, indel_rate=0.03)[0].tobytes()
+    rng = np.random.default_rng(seed)
+    q2 = bytearray(q)
+    for k in rng.choice(40, size=3, replace=False):
+        q2[k] = ord("ACGT"[("ACGT".index(chr(q2[k])) + 1) % 4])
+    pos = int(rng.integers(100, 5000))
+    return q, ref[:pos] + bytes(q2) + ref[pos + 40:]
+
+
+def _case_ref_sharding_fractional(rank, size, pgs, ob):
+    from parallel_genomeseq_amd import dist as pd
+    out = {}
+    sc = dict(match=2.5, mismatch=-1.5, gap=0.5)
+    for seed in (81, 138):
+        q, ref = _fractional_case(pgs, ob, seed)
+        ranges = ob.make_string_range(6, len(q), len(ref), 2.0)
+        full = [ob.score_only(q, ref[l:r], ob.F32, **sc) for l, r in ranges]
+
+        def maxima_fn(pieces):
+            return [full[p] for p in pieces]
+
+        def final_fn(piece):
+            l, r = ranges[piece]
+            return ob.align(q, ref[l:r], ob.F32)                  # default scoring (plocalaligner.cpp:135)
+
+        res, piece = pd.align_split_sharded(ranges, maxima_fn, final_fn)
+        exp = ob.align_split(q, ref, 6, 2.0, ob.F32, ob.F32, **sc)
+        out[seed] = (res, piece, exp, full)
+    # fractional scores through the gather and the best-key all-reduce
+    scores = [12.0, 12.5, 12.25, 12.5]
+    lo, hi = pd.shard_block(len(scores), rank, size)
+    idx, res, g = pd.align_queries_sharded(lambda qs: [dict(score=s, pos=1, end_x=1, end_y=1) for s in qs], scores)
+    mine = scores[lo:hi]
+    best = pd.allreduce_best(max(mine), lo + int(np.argmax(mine)))
+    out["gather"] = (g["score"].tolist(), best)
+    return out
+
+
+def test_ref_sharding_fractional_scores_gloo():
+    """scores travel as float32 bit patterns, so 92.5 beats 92.0 across ranks (serial rule
+    plocalaligner.cpp:122-129 compares floats)."""
+    out = _run("_case_ref_sharding_fractional")
+    for rank in (0, 1):
+        for seed in (81, 138):
+            res, piece, exp, full = out[rank][seed]
+            truncated = [int(v) for v in full]
+            assert truncated.index(max(truncated)) != full.index(max(full))       # the case is what it claims to be
+            assert piece == exp["piece"] == full.index(max(full))
+            for k in ("score", "pos", "cons_x", "cons_y"):
+                assert res[k] == exp[k], (rank, seed, k)
+        g, best = out[rank]["gather"]
+        assert g == [12.0, 12.5, 12.25, 12.5] and best == (12.5, 1)
+
+
 def test_partitions():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import load_package
@@ -106,4 +165,6 @@ def test_partitions():
     assert sorted(np.concatenate(bins).tolist()) == list(range(8))
     loads = [sum([9, 1, 1, 1, 8, 2, 2, 3][i] for i in b) for b in bins]
     assert abs(loads[0] - loads[1]) <= 1
-    assert pd.unpack_key(max(pd.pack_key(30, 5), pd.pack_key(30, 2), pd.pack_key(29, 0))) == (30, 2)
+    assert pd.unpack_key(max(pd.pack_key(30, 5), pd.pack_key(30, 2), pd.pack_key(29, 0))) == (30.0, 2)
+    assert pd.unpack_key(max(pd.pack_key(12.0, 1), pd.pack_key(12.5, 3))) == (12.5, 3)
+    assert pd.pack_key(0.0, 0) > 0                                  # a piece whose maximum is 0 still beats "no piece"

@@ -159,6 +159,12 @@ def test_cpp_dropin_binary():
         g.build()
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert p.returncode == 0 and b"ALL OK" in p.stdout, p.stdout.decode()
+    # the same source compiled against the reference's vendored Eigen (tests/cpp/build_dropin.sh): Eigen::VectorXf
+    # getTimings(), const Eigen::MatrixXf &get_matrix(), MatrixX8u raw storage — prebuilt where the reference exists
+    exe2 = os.path.join(root, "tests", "cpp", "test_dropin_eigen.bin")
+    if os.path.exists(exe2):
+        p = subprocess.run([exe2], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+        assert p.returncode == 0 and b"ALL OK" in p.stdout and b"Eigen signatures: ok" in p.stdout, p.stdout.decode()
 
 
 def test_score_ranges_and_ref_sharding(ctx, oracle, pgs):

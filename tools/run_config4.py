@@ -14,9 +14,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g  # noqa: E402
 
 pgs = g._load_package()
-# public UniProt entry P02232 (LGB1_VICFA), the reference's data/query/P02232.fasta, re-typed
-P02232 = ("MGFTEKQEALVNSSSQLFKQNPSNYSVLFYTIILQKAPTAKAMFSFLKDSAGVVDSPKLGAHAEKVFGMVRDSAVQLRATGEVVLDGKDGSIHIQKGVLDPHFVVVKEALLKTIKEASGD"
-          "KWSEELSAAWEVAYDGLATAIKAA")
+P02232 = pgs.synth.P02232
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 561_356
 lens = pgs.synth.lognormal_lengths(5, n)
 tot = int(lens.sum())

@@ -56,7 +56,9 @@ def main():
         t0 = time.time()
         idx, res, gathered = pd.align_queries_sharded(lambda qs: ctx.align_batch(qs, semantics=pgs.F32),
                                                       [r.tobytes() for r in reads], weights=lens * n)
-        best = pd.allreduce_best(max(r["score"] for r in res), int(idx[int(np.argmax([r["score"] for r in res]))]))
+        # a rank with an empty shard (fewer reads than ranks) still joins the all-reduce, with the lowest key
+        best = pd.allreduce_best(*((max(r["score"] for r in res), int(idx[int(np.argmax([r["score"] for r in res]))]))
+                                   if res else (0.0, 0xFFFFFFFF)))
         dt = time.time() - t0
         ok = float((gathered["end_y"] == offs + 150).mean())
         if rank == 0:
