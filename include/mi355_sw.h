@@ -172,6 +172,38 @@ typedef struct {
 } mi355_sw_kernel_info;
 int mi355_sw_last_kernel(const mi355_sw_ctx *ctx, mi355_sw_kernel_info *out);
 
+/* ---- several GPUs of one node behind one handle (one process, one engine context + host thread per device) ----
+ * The reference spreads the same work over OpenMP threads (pieces, src/aligner/plocalaligner.cpp:110-129) and MPI ranks
+ * (independent alignments, src/mpi_sw_solve_uniprot.cpp:95-138).  Results are identical to the single-device calls.
+ * devices == NULL or ndev <= 0: all visible devices.  A device may be listed more than once (the contexts are
+ * independent), except with MI355_SW_MULTI_RCCL. */
+typedef struct mi355_sw_multi mi355_sw_multi;
+enum {
+  MI355_SW_MULTI_RCCL = 1  /* merge the per-device best keys with ncclAllReduce(ncclMax, ncclUint64) over xGMI (RCCL is
+                              loaded at run time) instead of on the host; needs distinct devices */
+};
+int mi355_sw_multi_create(mi355_sw_multi **m, int ndev, const int *devices, int flags);
+void mi355_sw_multi_destroy(mi355_sw_multi *m);
+const char *mi355_sw_multi_last_error(const mi355_sw_multi *m);
+int mi355_sw_multi_device_count(const mi355_sw_multi *m);
+int mi355_sw_multi_rccl_version(const mi355_sw_multi *m);   /* ncclGetVersion code, 0 without MI355_SW_MULTI_RCCL */
+
+/* mi355_sw_align_split with piece p swept by device p mod ndev; the per-device best (score, lowest piece) keys are
+ * merged by MAX (serial rule plocalaligner.cpp:122-129), the owner of the winning piece re-aligns it (:132-141).
+ * Every device keeps a copy of y resident between calls (same reuse rule as mi355_sw_align). */
+int mi355_sw_multi_align_split(mi355_sw_multi *m, const char *x, size_t nx, const char *y, size_t ny,
+                               const mi355_sw_params *params, int sm_semantics, int la_semantics,
+                               int npiece, float overlap_ratio, mi355_sw_result *out, int *winning_piece);
+
+/* mi355_sw_set_reference / mi355_sw_align_batch with the reference replicated and the alignments dealt to the
+ * devices by length; outs[k] belongs to xs[k].  best_index (may be NULL): the alignment with the highest score,
+ * lowest index on ties, -1 for an empty batch — the "best over the database" of the UniProt-shaped run. */
+int mi355_sw_multi_set_reference(mi355_sw_multi *m, const char *y, size_t ny);
+int mi355_sw_multi_align_batch(mi355_sw_multi *m, size_t n, const char *const *xs, const size_t *nxs,
+                               const mi355_sw_params *params, int flags, mi355_sw_result *outs, int64_t *best_index);
+/* as mi355_sw_last_timings: [0..3] maximum over the devices (they run side by side), [4..5] sums */
+int mi355_sw_multi_last_timings(const mi355_sw_multi *m, double out[6]);
+
 void mi355_sw_free_result(mi355_sw_result *r);
 void mi355_sw_free_results(mi355_sw_result *r, size_t n);
 

@@ -2,7 +2,9 @@
 // src/aligner/plocalaligner.h:6-33, plocalaligner.cpp:44-143), SERIAL semantics (the reference's OpenMP
 // build is racy): pieces from _make_string_range, first strictly greater piece maximum wins,
 // the winner is re-aligned by LAT with DEFAULT scoring (plocalaligner.cpp:135), pos += left.
-// On the GPU all pieces are swept by one score-kernel launch (grid.y = pieces).
+// On the GPU all pieces are swept by one score-kernel launch (grid.y = pieces); with MI355_SW_DEVICES set, piece p is
+// swept by device p mod ndev (mi355_sw_multi_align_split) — the devices take the place of the OpenMP threads of
+// plocalaligner.cpp:110-115.
 #ifndef PARSEQ_PLOCALALIGNER_H_
 #define PARSEQ_PLOCALALIGNER_H_
 
@@ -48,10 +50,16 @@ class OMPParallelLocalAligner : public ParallelLocalAligner<Similarity_Matrix_Ty
     mi355_sw_params p{lut ? lut->data() : nullptr, 3.0f, -3.0f, gap_penalty, Similarity_Matrix_Type::semantics};
     mi355_sw_result r;
     int piece = 0;
-    parseq::check(mi355_sw_align_split(parseq::context(), sequence_x.data(), sequence_x.size(), sequence_y.data(),
-                                       sequence_y.size(), &p, Similarity_Matrix_Type::semantics,
-                                       LocalAligner_Type::matrix_type::semantics, npiece, overlap_ratio, &r, &piece),
-                  "OMPParallelLocalAligner::calculateScore");
+    if (mi355_sw_multi *multi = parseq::multi_context())     // MI355_SW_DEVICES: piece p on device p mod ndev
+      parseq::check_multi(mi355_sw_multi_align_split(multi, sequence_x.data(), sequence_x.size(), sequence_y.data(),
+                                                     sequence_y.size(), &p, Similarity_Matrix_Type::semantics,
+                                                     LocalAligner_Type::matrix_type::semantics, npiece, overlap_ratio, &r, &piece),
+                          "OMPParallelLocalAligner::calculateScore");
+    else
+      parseq::check(mi355_sw_align_split(parseq::context(), sequence_x.data(), sequence_x.size(), sequence_y.data(),
+                                         sequence_y.size(), &p, Similarity_Matrix_Type::semantics,
+                                         LocalAligner_Type::matrix_type::semantics, npiece, overlap_ratio, &r, &piece),
+                    "OMPParallelLocalAligner::calculateScore");
     max_score = r.score;
     pos = r.pos;
     consensus_x.assign(r.cons_x, r.cons_len);

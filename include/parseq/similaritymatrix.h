@@ -113,8 +113,44 @@ inline mi355_sw_ctx *context() {
   return h.c;
 }
 
+// Several GPUs for the aligners that split their work (OMPParallelLocalAligner): MI355_SW_DEVICES = "all" or a comma
+// list ("0,1,2,3") selects them, MI355_SW_MULTI_RCCL=1 merges the per-device best keys with an RCCL all-reduce.
+// Unset: nullptr, and everything runs on context()'s single device.  One handle per host thread.
+inline mi355_sw_multi *multi_context() {
+  struct Holder {
+    mi355_sw_multi *m = nullptr;
+    Holder() {
+      const char *e = std::getenv("MI355_SW_DEVICES");
+      if (!e || !*e) return;
+      std::vector<int> devs;
+      const std::string s(e);
+      if (s != "all") {
+        size_t at = 0;
+        while (at < s.size()) {
+          size_t end = s.find(',', at);
+          if (end == std::string::npos) end = s.size();
+          if (end > at) devs.push_back(std::atoi(s.substr(at, end - at).c_str()));
+          at = end + 1;
+        }
+      }
+      const char *r = std::getenv("MI355_SW_MULTI_RCCL");
+      const int flags = (r && *r && *r != '0') ? MI355_SW_MULTI_RCCL : 0;
+      if (mi355_sw_multi_create(&m, (int)devs.size(), devs.empty() ? nullptr : devs.data(), flags) != 0) {
+        std::fprintf(stderr, "parseq: mi355_sw_multi_create failed for MI355_SW_DEVICES=%s; there is no CPU fallback\n", e);
+        std::abort();
+      }
+    }
+    ~Holder() { mi355_sw_multi_destroy(m); }
+  };
+  static thread_local Holder h;
+  return h.m;
+}
+
 inline void check(int rc, const char *what) {
   if (rc != 0) throw std::runtime_error(std::string(what) + ": " + mi355_sw_last_error(context()));
+}
+inline void check_multi(int rc, const char *what) {
+  if (rc != 0) throw std::runtime_error(std::string(what) + ": " + mi355_sw_multi_last_error(multi_context()));
 }
 
 typedef std::function<float(const char &, const char &)> scoring_fn;

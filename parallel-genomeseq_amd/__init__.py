@@ -8,4 +8,4 @@ from . import synth  # noqa: F401
 from . import capi  # noqa: F401
 from .aligner import (LocalAligner, OMPParallelLocalAligner, ParallelLocalAligner, SWAligner,  # noqa: F401
                       Similarity_Matrix, Similarity_Matrix_Skewed, default_context)
-from .capi import F32, U8SAT, Context, MI355Error  # noqa: F401
+from .capi import F32, U8SAT, Context, MI355Error, MultiContext  # noqa: F401

@@ -17,7 +17,11 @@ EXPORTS = [
     "mi355_sw_batch_run", "mi355_sw_score_ranges", "mi355_sw_align_split", "mi355_sw_make_string_range", "mi355_sw_fill_matrix",
     "mi355_sw_argmax", "mi355_sw_true2raw", "mi355_sw_raw2true", "mi355_sw_last_timings", "mi355_sw_free_result", "mi355_sw_free_results",
     "mi355_sw_build_info", "mi355_sw_last_kernel",
+    "mi355_sw_multi_create", "mi355_sw_multi_destroy", "mi355_sw_multi_last_error", "mi355_sw_multi_device_count",
+    "mi355_sw_multi_rccl_version", "mi355_sw_multi_align_split", "mi355_sw_multi_set_reference",
+    "mi355_sw_multi_align_batch", "mi355_sw_multi_last_timings",
 ]
+MULTI_RCCL = 1
 
 
 class Params(C.Structure):
@@ -66,6 +70,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.mi355_sw_last_error.restype = C.c_char_p
         L.mi355_sw_build_info.restype = C.c_char_p
+        L.mi355_sw_multi_last_error.restype = C.c_char_p
         for name in EXPORTS:
             getattr(L, name)
         _LIB = L
@@ -221,6 +226,83 @@ class Context:
         return dict(cell=k.cell, dtype=CELL_NAMES.get(k.cell, "?"), lanes=k.lanes, rows_per_lane=k.rows_per_lane,
                     strips=bool(k.strips), twin=bool(k.twin), chunk_len=k.chunk_len, sub_len=k.sub_len, warm=k.warm,
                     cells=k.cells, valu_ops_per_cell=k.valu_ops_per_cell, name=k.name.decode())
+
+
+class MultiContext:
+    """Several GPUs of one node behind one handle (mi355_sw_multi_*): one engine context and one host thread per
+    device inside this process.  devices=None: all visible devices; a device may be listed twice (rehearsal on a
+    one-GPU box) unless rccl=True."""
+
+    def __init__(self, devices=None, rccl=False):
+        self._L = lib()
+        self._m = C.c_void_p()
+        n = 0 if devices is None else len(devices)
+        arr = (C.c_int * max(1, n))(*(devices or [0]))
+        rc = self._L.mi355_sw_multi_create(C.byref(self._m), C.c_int(n), arr if n else None, C.c_int(MULTI_RCCL if rccl else 0))
+        if rc:
+            raise MI355Error(rc, "mi355_sw_multi_create failed (devices %r, rccl=%r)" % (devices, rccl))
+        self.ndev = self._L.mi355_sw_multi_device_count(self._m)
+        self.rccl_version = self._L.mi355_sw_multi_rccl_version(self._m)
+
+    def close(self):
+        if self._m:
+            self._L.mi355_sw_multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise MI355Error(rc, (self._L.mi355_sw_multi_last_error(self._m) or b"").decode())
+
+    def align_split(self, x, y, npiece, overlap_ratio, sm_semantics=F32, la_semantics=F32, match=3.0,
+                    mismatch=-3.0, gap=2.0, lut=None):
+        x, y = _bytes(x), _bytes(y)
+        p, keep = make_params(sm_semantics, match, mismatch, gap, lut)
+        r = Result()
+        piece = C.c_int(0)
+        self._chk(self._L.mi355_sw_multi_align_split(self._m, x, C.c_size_t(len(x)), y, C.c_size_t(len(y)), C.byref(p),
+                                                     C.c_int(sm_semantics), C.c_int(la_semantics), C.c_int(npiece),
+                                                     C.c_float(overlap_ratio), C.byref(r), C.byref(piece)))
+        out = _take(r)
+        out["piece"] = piece.value
+        self._L.mi355_sw_free_result(C.byref(r))
+        return out
+
+    def set_reference(self, y):
+        y = _bytes(y)
+        self._chk(self._L.mi355_sw_multi_set_reference(self._m, y, C.c_size_t(len(y))))
+
+    def align_batch(self, xs, y=None, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None, flags=0, raw=False):
+        """Returns (results, best_index)."""
+        if y is not None:
+            self.set_reference(y)
+        xs = [_bytes(x) for x in xs]
+        n = len(xs)
+        arr = (C.c_char_p * max(1, n))(*xs)
+        lens = (C.c_size_t * max(1, n))(*[len(x) for x in xs])
+        p, keep = make_params(semantics, match, mismatch, gap, lut)
+        res = (Result * max(1, n))()
+        best = C.c_int64(-1)
+        self._chk(self._L.mi355_sw_multi_align_batch(self._m, C.c_size_t(n), arr, lens, C.byref(p), C.c_int(flags), res,
+                                                     C.byref(best)))
+        if raw:
+            v = np.frombuffer(res, dtype=_RESULT_DTYPE, count=n)
+            out = dict(score=v["score"].astype(np.float32), pos=v["pos"].astype(np.int64),
+                       end_x=v["end_x"].astype(np.int64), end_y=v["end_y"].astype(np.int64))
+        else:
+            out = [_take(res[k]) for k in range(n)]
+        self._L.mi355_sw_free_results(res, C.c_size_t(n))
+        return out, best.value
+
+    def last_timings(self):
+        t = (C.c_double * 6)()
+        self._L.mi355_sw_multi_last_timings(self._m, t)
+        return dict(score_us=t[0], locate_us=t[1], trace_us=t[2], total_us=t[3], score_launches=int(t[4]), cells=t[5])
 
 
 def make_string_range(npiece, shortlen, longlen, ratio):

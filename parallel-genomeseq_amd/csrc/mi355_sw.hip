@@ -38,6 +38,7 @@ using namespace mi355sw;
 #include "host_exact.h"
 #include "host_wave.h"
 #include "host_pipeline.h"
+#include "host_multi.h"   // mi355_sw_multi_*: its own extern "C" block
 
 // ================================= C-ABI ======================================================
 extern "C" {

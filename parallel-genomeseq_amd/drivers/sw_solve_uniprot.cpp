@@ -1,7 +1,10 @@
 // sw_solve_uniprot — the many-alignment batch of the reference driver src/mpi_sw_solve_uniprot.cpp
 // (each database sequence as FIRST argument, the query protein as SECOND, SWAligner<Similarity_Matrix>,
 // default scoring, :120-122) as ONE device batch instead of an MPI task farm with a writer rank.
-//   sw_solve_uniprot [query.fasta] [db] [out.csv] [--count=N]
+//   sw_solve_uniprot [query.fasta] [db] [out.csv] [--count=N] [--devices=all|0,1,...] [--rccl]
+// --devices (or MI355_SW_DEVICES): the database sequences are dealt to several GPUs of the node (query replicated, no
+// exchange during compute) in place of the reference's MPI worker ranks (:95-138); --rccl (or MI355_SW_MULTI_RCCL=1)
+// merges the per-device best (score, index) with ncclAllReduce(ncclMax, ncclUint64) instead of on the host.
 // db = directory with <k>.fasta files (the reference's layout, data/uniprot/<k>.fasta, count from
 // stats.txt or --count) or a single multi-FASTA file.  Output as the writer rank's (:143-170):
 // header `read,pos_pred,score`, rows `<first 126 chars of the sequence>, <pos>, <score>`.
@@ -43,8 +46,12 @@ int main(int argc, char **argv) {
     if (any) seqs.push_back(cur);
   }
   std::cout << seqs.size() << " sequences against a " << fa_string.size() << "-residue query" << std::endl;
-  mi355_sw_ctx *ctx = parseq::context();
-  parseq::check(mi355_sw_set_reference(ctx, fa_string.data(), fa_string.size()), "set_reference");
+  if (a.has("devices")) setenv("MI355_SW_DEVICES", a.get("devices", "all").c_str(), 1);
+  if (a.has("rccl")) setenv("MI355_SW_MULTI_RCCL", "1", 1);
+  mi355_sw_multi *multi = parseq::multi_context();
+  mi355_sw_ctx *ctx = multi ? nullptr : parseq::context();
+  if (multi) parseq::check_multi(mi355_sw_multi_set_reference(multi, fa_string.data(), fa_string.size()), "set_reference");
+  else parseq::check(mi355_sw_set_reference(ctx, fa_string.data(), fa_string.size()), "set_reference");
   std::vector<const char *> xs(seqs.size());
   std::vector<size_t> nxs(seqs.size());
   double cells = 0;
@@ -52,9 +59,18 @@ int main(int argc, char **argv) {
   std::vector<mi355_sw_result> res(seqs.size());
   mi355_sw_params p;
   mi355_sw_default_params(&p);
-  parseq::check(mi355_sw_align_batch(ctx, seqs.size(), xs.data(), nxs.data(), &p, 0, res.data()), "align_batch");
+  int64_t best_index = -1;
   double t[6];
-  mi355_sw_last_timings(ctx, t);
+  if (multi) {
+    parseq::check_multi(mi355_sw_multi_align_batch(multi, seqs.size(), xs.data(), nxs.data(), &p, 0, res.data(), &best_index), "align_batch");
+    mi355_sw_multi_last_timings(multi, t);
+    std::cout << mi355_sw_multi_device_count(multi) << " devices";
+    if (mi355_sw_multi_rccl_version(multi)) std::cout << ", RCCL " << mi355_sw_multi_rccl_version(multi);
+    std::cout << std::endl;
+  } else {
+    parseq::check(mi355_sw_align_batch(ctx, seqs.size(), xs.data(), nxs.data(), &p, 0, res.data()), "align_batch");
+    mi355_sw_last_timings(ctx, t);
+  }
   std::ofstream out(output_file_path);
   out << "read,pos_pred,score\n";
   size_t best = 0;
@@ -64,6 +80,7 @@ int main(int argc, char **argv) {
     out << buff << ", " << res[k].pos << ", " << res[k].score << "\n";
     if (res[k].score > res[best].score) best = k;
   }
+  if (multi && best_index >= 0 && (size_t)best_index != best) { std::cerr << "internal: best index mismatch" << std::endl; return 3; }
   if (!seqs.empty())
     std::cout << "best: sequence " << best << " score " << res[best].score << " pos " << res[best].pos << std::endl;
   std::cout << "[INFO] device time " << t[3] * 1e-6 << "s, GCUPS:" << cells / t[3] * 1e-3 << std::endl;

@@ -1,5 +1,6 @@
 #!/usr/bin/env bash
-# build_dropin.sh — compile tests/cpp/test_dropin.cpp against include/parseq/*.h twice:
+# build_dropin.sh — compile tests/cpp/test_multi.cpp (C-ABI, mi355_sw_multi_*) and tests/cpp/test_dropin.cpp against
+# include/parseq/*.h, the latter twice:
 #   test_dropin.bin        without Eigen on the include path (parseq::Timings / parseq::DenseMatrix signatures)
 #   test_dropin_eigen.bin  with Eigen 3.3.7 (the reference's own vendored zip, cmake/eigen-3.3.7.zip, unpacked to a
 #                          temporary directory for the duration of the compile and removed afterwards): the reference's
@@ -12,6 +13,7 @@ ROOT="$(cd "$HERE/../.." && pwd)"
 FLAGS=(-std=c++17 -O1 -Wall -Werror -pthread "-I$ROOT/include")
 LINK=("-L$ROOT/parallel-genomeseq_amd" -lmi355_sw "-Wl,-rpath,$ROOT/parallel-genomeseq_amd")
 g++ "${FLAGS[@]}" -DPARSEQ_NO_EIGEN "$HERE/test_dropin.cpp" "${LINK[@]}" -o "$HERE/test_dropin.bin"
+g++ "${FLAGS[@]}" "$HERE/test_multi.cpp" "${LINK[@]}" -o "$HERE/test_multi.bin"
 ZIP="$REF/cmake/eigen-3.3.7.zip"
 if [ -f "$ZIP" ]; then
   TMP="$(mktemp -d "${TMPDIR:-/tmp}/parseq_eigen.XXXXXX")"

@@ -159,12 +159,56 @@ def test_cpp_dropin_binary():
         g.build()
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert p.returncode == 0 and b"ALL OK" in p.stdout, p.stdout.decode()
+    # OMPParallelLocalAligner over a device set (MI355_SW_DEVICES -> mi355_sw_multi_align_split): same answers
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120,
+                       env=dict(os.environ, MI355_SW_DEVICES="0,0"))
+    assert p.returncode == 0 and b"ALL OK" in p.stdout, p.stdout.decode()
     # the same source compiled against the reference's vendored Eigen (tests/cpp/build_dropin.sh): Eigen::VectorXf
     # getTimings(), const Eigen::MatrixXf &get_matrix(), MatrixX8u raw storage — prebuilt where the reference exists
     exe2 = os.path.join(root, "tests", "cpp", "test_dropin_eigen.bin")
     if os.path.exists(exe2):
         p = subprocess.run([exe2], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
         assert p.returncode == 0 and b"ALL OK" in p.stdout and b"Eigen signatures: ok" in p.stdout, p.stdout.decode()
+
+
+def test_cpp_multi_device_binary():
+    """mi355_sw_multi_* (one handle, several devices: pieces / alignments dealt to devices, packed-key merge on the
+    host and through RCCL) == the single-device calls; on a one-GPU box with device sets {0}, {0,0}, {0,0,0}."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "test_multi.bin")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        g.build()
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0 and b"ALL OK" in p.stdout, p.stdout.decode()
+
+
+def test_multi_context_vs_oracle(oracle, pgs):
+    """MultiContext (two contexts on this GPU) against the ORACLE: split with ties across pieces and fractional
+    scoring (the winner is picked on float keys), and a ragged batch with its best index."""
+    m = pgs.MultiContext([0, 0])
+    try:
+        ref = pgs.synth.dna(61, 90_000).tobytes()
+        q = ref[20_000:20_300]
+        ref = ref[:70_000] + q + ref[70_300:]                              # second identical hit in a later piece
+        for sm, la, npiece, sc in ((0, 0, 5, {}), (1, 1, 7, {}), (0, 1, 6, dict(match=2.5, mismatch=-1.5, gap=0.5))):
+            got = m.align_split(q, ref, npiece, 2.0, sm, la, **sc)
+            exp = oracle.align_split(q, ref, npiece, 2.0, sm, la, **sc)
+            _cmp(got, exp, ("multi split", sm, la, npiece))
+            assert got["piece"] == exp["piece"]
+        refa = np.frombuffer(ref, dtype=np.uint8)
+        reads = [pgs.synth.read_from_ref(refa, 900 + k, [33, 64, 150, 151, 400, 700][k % 6])[0].tobytes() for k in range(40)]
+        for sem in (0, 1):
+            res, best = m.align_batch(reads, ref, semantics=sem)
+            exp = [oracle.align(r, ref, sem) for r in reads]
+            for g, e in zip(res, exp):
+                _cmp(g, e, ("multi batch", sem))
+            scores = [e["score"] for e in exp]
+            assert best == scores.index(max(scores))
+    finally:
+        m.close()
 
 
 def test_score_ranges_and_ref_sharding(ctx, oracle, pgs):
@@ -283,15 +327,18 @@ def test_driver_sw_solve_big_and_uniprot(pgs, oracle, tmp_path):
     (tmp_path / "q.fasta").write_text(">sp|Q\n" + query[:60] + "\n" + query[60:] + "\n")
     (tmp_path / "db.fasta").write_text("".join(">s%d\n%s\n" % (k, s) for k, s in enumerate(db)))
     out = tmp_path / "u.csv"
-    p = subprocess.run([os.path.join(d, "sw_solve_uniprot.bin"), str(tmp_path / "q.fasta"), str(tmp_path / "db.fasta"), str(out)],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
-    assert p.returncode == 0 and b"best: sequence 2" in p.stdout, p.stdout.decode()
-    rows = out.read_text().splitlines()
-    assert rows[0] == "read,pos_pred,score" and len(rows) == 6
-    for k, s in enumerate(db):
-        e = oracle.align(s, query, oracle.F32)
-        seq, pos, sc = rows[1 + k].split(", ")
-        assert seq == s[:126] and int(pos) == e["pos"] and float(sc) == e["score"]
+    # single device; two contexts dealt the sequences (host merge); one device with the RCCL merge of the best key
+    for extra in ([], ["--devices=0,0"], ["--devices=0", "--rccl"]):
+        p = subprocess.run([os.path.join(d, "sw_solve_uniprot.bin"), str(tmp_path / "q.fasta"), str(tmp_path / "db.fasta"), str(out)] + extra,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 0 and b"best: sequence 2" in p.stdout, p.stdout.decode()
+        assert (b"devices" in p.stdout) == bool(extra) and (b"RCCL" in p.stdout) == ("--rccl" in extra)
+        rows = out.read_text().splitlines()
+        assert rows[0] == "read,pos_pred,score" and len(rows) == 6
+        for k, s in enumerate(db):
+            e = oracle.align(s, query, oracle.F32)
+            seq, pos, sc = rows[1 + k].split(", ")
+            assert seq == s[:126] and int(pos) == e["pos"] and float(sc) == e["score"]
 
 
 def test_protein_alphabet_and_high_bytes(ctx, oracle, pgs):
