@@ -108,6 +108,23 @@ int mi355_sw_batch_upload(mi355_sw_ctx *ctx, size_t n, const char *const *xs, co
 int mi355_sw_batch_run(mi355_sw_ctx *ctx, const mi355_sw_params *params, int flags,
                        mi355_sw_result *outs);
 
+/* mi355_sw_batch_run with the results as a struct of arrays in LIBRARY-OWNED memory (valid until the next call on this
+ * context; nothing to free): for batches of very many small alignments (the 561 356 sequences of
+ * src/mpi_sw_solve_uniprot.cpp's run), where one malloc'ed string pair per alignment costs more than the alignments.
+ * cons_x[k] / cons_y[k]: cons_len[k] bytes each, NOT NUL-terminated, NULL when cons_len[k] == 0. */
+typedef struct {
+  size_t n;
+  const float *score;
+  const uint32_t *pos;
+  const int64_t *end_x;
+  const int64_t *end_y;
+  const char *const *cons_x;
+  const char *const *cons_y;
+  const uint32_t *cons_len;
+  float timings_us[2];
+} mi355_sw_batch_view;
+int mi355_sw_batch_run_view(mi355_sw_ctx *ctx, const mi355_sw_params *params, int flags, mi355_sw_batch_view *out);
+
 /* OMPParallelLocalAligner: split y into npiece overlapping pieces, pick the first piece with the
  * strictly greatest maximum under (params, sm_semantics), re-align it under la_semantics with
  * DEFAULT scoring (plocalaligner.cpp:135), pos += left.  winning_piece may be NULL. */

@@ -108,6 +108,22 @@ def fill(x, y, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None):
     return H.T
 
 
+def trace_from(x, y, semantics, start_x, start_y, match=3.0, mismatch=-3.0, gap=2.0, lut=None):
+    """Traceback from a given start cell over the matrix of (x, y) (y = window ending at the argmax column);
+    result["score"] = H(start) in the window."""
+    x, y = _b(x), _b(y)
+    sc, keep = _scoring(match, mismatch, gap, lut)
+    r = Result()
+    L = lib()
+    L.sw_oracle_trace_from.restype = C.c_int
+    rc = L.sw_oracle_trace_from(x, C.c_size_t(len(x)), y, C.c_size_t(len(y)), C.byref(sc), C.c_int(semantics),
+                                C.c_int64(start_x), C.c_int64(start_y), C.byref(r))
+    if rc:
+        L.sw_oracle_free_result(C.byref(r))
+        raise ValueError("sw_oracle_trace_from: start cell outside the window")
+    return _take(r)
+
+
 def score_only(x, y, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None):
     x, y = _b(x), _b(y)
     sc, keep = _scoring(match, mismatch, gap, lut)

@@ -225,6 +225,39 @@ int sw_oracle_align(const char *x, size_t m, const char *y, size_t n,
   return 0;
 }
 
+/* Traceback (smithwaterman.cpp:40-78) from a GIVEN start cell over the matrix of (x, y): the companion of
+ * sw_oracle_locate for problems whose full matrix does not fit.  y is a window of the full reference that ENDS at the
+ * argmax column; the argmax itself comes from the full-size sw_oracle_locate (the uint8 engine's storage order depends
+ * on the full problem's ncols, SURVEY.md App. A.5: it must never be re-derived on a window), the window supplies
+ * only the H values the walk reads.  out->score = H(start) so the caller can check the window was long enough for
+ * the start cell to be exact; end_x / end_y = the start cell; pos is window-local. */
+int sw_oracle_trace_from(const char *x, size_t m, const char *y, size_t n, const sw_oracle_scoring *sc,
+                         int semantics, int64_t start_x, int64_t start_y, sw_oracle_result *out) {
+  result_init(out);
+  if (start_x < 1 || start_y < 1 || (size_t)start_x > m || (size_t)start_y > n) return -1;
+  const size_t ld = m + 1, cells = ld * (n + 1);
+  int64_t ix = start_x, iy = start_y;
+  strbuf cx = {0, 0, 0}, cy = {0, 0, 0};
+  if (semantics == SW_ORACLE_F32) {
+    float *H = (float *)malloc(sizeof(float) * cells);
+    if (!H) return -1;
+    sw_oracle_fill_f32(x, m, y, n, sc, H);
+    out->score = H[(size_t)iy * ld + (size_t)ix];
+    if (out->score > 0) traceback_f32(H, ld, x, y, &ix, &iy, &cx, &cy, &out->pos);
+    free(H);
+  } else {
+    uint8_t *H = (uint8_t *)malloc(cells);
+    if (!H) return -1;
+    sw_oracle_fill_u8(x, m, y, n, sc, H);
+    out->score = (float)H[(size_t)iy * ld + (size_t)ix];
+    if (out->score > 0) traceback_u8(H, ld, x, y, &ix, &iy, &cx, &cy, &out->pos);
+    free(H);
+  }
+  out->end_x = start_x; out->end_y = start_y;
+  if (cx.p) { free(out->cons_x); free(out->cons_y); out->cons_x = cx.p; out->cons_y = cy.p; out->cons_len = cx.len; }
+  return 0;
+}
+
 /* src/aligner/plocalaligner.cpp:44-67 */
 int sw_oracle_make_string_range(int npiece, int64_t shortlen, int64_t longlen, float overlap_ratio,
                                 int64_t *lefts, int64_t *rights) {

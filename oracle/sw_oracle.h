@@ -87,6 +87,12 @@ int sw_oracle_align_split(const char *x, size_t m, const char *y, size_t n,
 void sw_oracle_locate(const char *x, size_t m, const char *y, size_t n, const sw_oracle_scoring *sc,
                       int semantics, float *mx, int64_t *ix, int64_t *iy);
 
+/* Greedy traceback (smithwaterman.cpp:40-78) from a given start cell of the matrix of (x, y) — y a window of the
+ * full reference ending at the argmax column, the start cell from the full-size sw_oracle_locate.  out->score is
+ * H(start) in the window (equal to the full-size maximum when the window is long enough, App. A.5). */
+int sw_oracle_trace_from(const char *x, size_t m, const char *y, size_t n, const sw_oracle_scoring *sc,
+                         int semantics, int64_t start_x, int64_t start_y, sw_oracle_result *out);
+
 void sw_oracle_free_result(sw_oracle_result *r);
 
 /* Score-only rolling-column pass (no matrix): max cell value.  Used for the

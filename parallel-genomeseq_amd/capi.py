@@ -16,7 +16,7 @@ EXPORTS = [
     "mi355_sw_align", "mi355_sw_set_reference", "mi355_sw_align_batch", "mi355_sw_batch_upload",
     "mi355_sw_batch_run", "mi355_sw_score_ranges", "mi355_sw_align_split", "mi355_sw_make_string_range", "mi355_sw_fill_matrix",
     "mi355_sw_argmax", "mi355_sw_true2raw", "mi355_sw_raw2true", "mi355_sw_last_timings", "mi355_sw_free_result", "mi355_sw_free_results",
-    "mi355_sw_build_info", "mi355_sw_last_kernel",
+    "mi355_sw_build_info", "mi355_sw_last_kernel", "mi355_sw_batch_run_view",
     "mi355_sw_multi_create", "mi355_sw_multi_destroy", "mi355_sw_multi_last_error", "mi355_sw_multi_device_count",
     "mi355_sw_multi_rccl_version", "mi355_sw_multi_align_split", "mi355_sw_multi_set_reference",
     "mi355_sw_multi_align_batch", "mi355_sw_multi_last_timings",
@@ -33,6 +33,12 @@ class Result(C.Structure):
     _fields_ = [("score", C.c_float), ("pos", C.c_uint32), ("end_x", C.c_int64), ("end_y", C.c_int64),
                 ("cons_x", C.c_void_p), ("cons_y", C.c_void_p), ("cons_len", C.c_size_t),
                 ("timings_us", C.c_float * 2)]
+
+
+class BatchView(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("score", C.POINTER(C.c_float)), ("pos", C.POINTER(C.c_uint32)),
+                ("end_x", C.POINTER(C.c_int64)), ("end_y", C.POINTER(C.c_int64)), ("cons_x", C.POINTER(C.c_void_p)),
+                ("cons_y", C.POINTER(C.c_void_p)), ("cons_len", C.POINTER(C.c_uint32)), ("timings_us", C.c_float * 2)]
 
 
 class KernelInfo(C.Structure):
@@ -185,16 +191,32 @@ class Context:
     def batch_run(self, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None, flags=0, raw=False):
         p, keep = make_params(semantics, match, mismatch, gap, lut)
         n = self._nbatch
+        if raw:
+            # struct-of-arrays view in library-owned memory (mi355_sw_batch_run_view): no per-result objects, no
+            # per-result allocations on either side; cons=True adds the strings' lengths and addresses
+            v = BatchView()
+            self._chk(self._L.mi355_sw_batch_run_view(self._ctx, C.byref(p), C.c_int(flags), C.byref(v)))
+            if n == 0:
+                return dict(score=np.zeros(0, np.float32), pos=np.zeros(0, np.int64), end_x=np.zeros(0, np.int64),
+                            end_y=np.zeros(0, np.int64), cons_len=np.zeros(0, np.int64))
+            arr = lambda ptr, dt: np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt)   # copies out of library memory
+            out = dict(score=arr(v.score, np.float32), pos=arr(v.pos, np.int64), end_x=arr(v.end_x, np.int64),
+                       end_y=arr(v.end_y, np.int64), cons_len=arr(v.cons_len, np.int64))
+            self._view = v                                             # consensus(k) reads through it until the next call
+            return out
         res = (Result * n)()
         self._chk(self._L.mi355_sw_batch_run(self._ctx, C.byref(p), C.c_int(flags), res))
-        if raw:
-            v = np.frombuffer(res, dtype=_RESULT_DTYPE, count=n)       # no per-result Python objects
-            out = dict(score=v["score"].astype(np.float32), pos=v["pos"].astype(np.int64),
-                       end_x=v["end_x"].astype(np.int64), end_y=v["end_y"].astype(np.int64))
-        else:
-            out = [_take(r) for r in res]
+        out = [_take(r) for r in res]
         self._L.mi355_sw_free_results(res, C.c_size_t(n))
         return out
+
+    def consensus(self, k):
+        """(cons_x, cons_y) of alignment k of the last batch_run(raw=True) (valid until the next call)."""
+        v = self._view
+        ln = int(v.cons_len[k])
+        if ln == 0:
+            return "", ""
+        return C.string_at(v.cons_x[k], ln).decode("latin-1"), C.string_at(v.cons_y[k], ln).decode("latin-1")
 
     def score_ranges(self, ranges, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None):
         """Per-range maxima of every resident query: array [len(ranges), n_queries]."""

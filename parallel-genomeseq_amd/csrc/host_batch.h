@@ -1,0 +1,143 @@
+// host_batch.h — many small WHOLE problems on device-built job lists (sw_batch_kernels.h): the UniProt-shaped batch
+// Part of the single translation unit mi355_sw.hip (included there, in order; not a standalone header).
+//
+// Float engine, identity scoring, problems whose short side fits the register wavefront (<= 512): sorted positions
+// [first, first + count) of the batch against one range of the reference, all with the same orientation.
+//   one pass of sw_wave_kernel<TRACK, DIRS>: first maximum in storage order + every cell's greedy decision;
+//   walks measured, laid out by a device scan, written; results copied down once.
+// Nothing per-alignment is built on the host before the results arrive (src/mpi_sw_solve_uniprot.cpp:95-138: every
+// database sequence x against the one query y — 561 356 of them in config 4).
+namespace {
+
+// exclusive scan of v[0..n) in place on the stream; the grand total lands in *total_dev (device)
+int device_scan(mi355_sw_ctx *ctx, int64_t *v, int64_t n, int64_t *total_dev) {
+  const int64_t per = (int64_t)kScanBlock * kScanItems;
+  const int nb = (int)std::max<int64_t>(1, (n + per - 1) / per);
+  if (ctx->scan.ensure((size_t)nb * 8 + 64)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(scan) failed");
+  int64_t *partial = ctx->scan.as<int64_t>();
+  hipLaunchKernelGGL(scan_partials, dim3(nb), dim3(kScanBlock), 0, ctx->stream, (const int64_t *)v, n, partial);
+  hipLaunchKernelGGL(scan_of_partials, dim3(1), dim3(kScanBlock), 0, ctx->stream, partial, nb, total_dev);
+  hipLaunchKernelGGL(scan_apply, dim3(nb), dim3(kScanBlock), 0, ctx->stream, v, n, (const int64_t *)partial);
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+
+template <int R, int ORIENT>
+void launch_wave_batch(bool dirs, unsigned blocks, hipStream_t st, const WaveProblem *pr, int n, const WaveScoring &sc) {
+  if (dirs) hipLaunchKernelGGL((sw_wave_kernel<R, ORIENT, false, true, true>), dim3(blocks), dim3(256), 0, st, pr, n, sc);
+  else hipLaunchKernelGGL((sw_wave_kernel<R, ORIENT, false, true, false>), dim3(blocks), dim3(256), 0, st, pr, n, sc);
+}
+
+// loc / tout / handled are indexed by query id.  Long ranges are cut so that a launch's decisions fit the scratch
+// budget; a single problem beyond it is left to the windowed path (handled stays 0).
+int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg, const mi355_sw_params &p,
+                      size_t first, size_t count, int orient, bool want_trace, std::vector<Located> &loc,
+                      std::vector<TraceOut> &tout, std::vector<char> &handled) {
+  if (count == 0) return 0;
+  const int64_t nref = rg.hi - rg.lo;
+  const int maxna = orient == 0 ? q.len[q.order[first + count - 1]] : (int)nref;
+  const int R = wave_R(maxna);
+  const int W = (R + 15) / 16;
+  const int64_t stream_total = orient == 0 ? (int64_t)count * nref : q.cumlen[first + count] - q.cumlen[first];
+  const size_t dirs_total = want_trace ? (size_t)batch_dirs_offset(stream_total, (int64_t)count, W) : 0;
+  if (dirs_total > kDirsBudget || count > ((size_t)1 << 30)) {
+    if (count == 1) return 0;
+    const size_t half = count / 2;
+    int rc = exact_full_device(ctx, ref, q, rg, p, first, half, orient, want_trace, loc, tout, handled);
+    if (rc) return rc;
+    return exact_full_device(ctx, ref, q, rg, p, first + half, count - half, orient, want_trace, loc, tout, handled);
+  }
+  HostTrace trace_("exact_full_device");
+  const size_t n = count;
+  // device scratch: problems, (best, cell), decisions, walk descriptors + (len, pos, status) + consensus offsets + total
+  const size_t walk_bytes = n * sizeof(WaveWalk) + n * 24 + (n + 1) * 8 + 64;
+  if (ctx->wprobs.ensure(n * sizeof(WaveProblem)) || ctx->outs_f.ensure(n * 4) || ctx->outs_i.ensure(n * 16) ||
+      (dirs_total && ctx->dirs.ensure(dirs_total)) || (want_trace && ctx->walkp.ensure(walk_bytes)))
+    return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(batch scratch) failed");
+  BatchWaveArgs a;
+  a.qbytes = q.bytes.as<uint8_t>(); a.qoff = q.offs.as<int64_t>(); a.qlen = q.lens.as<int32_t>();
+  a.qsel = q.sel.as<int32_t>(); a.qcum = q.cum.as<int64_t>();
+  a.ref = ref.bytes.as<uint8_t>() + rg.lo; a.nref = nref;
+  a.first = (int)first; a.count = (int)n; a.orient = orient; a.W = W;
+  a.dirs = want_trace ? ctx->dirs.as<uint32_t>() : nullptr;
+  a.probs = ctx->wprobs.as<WaveProblem>();
+  a.best = ctx->outs_f.as<float>();
+  a.cell = ctx->outs_i.as<int64_t>();
+  const unsigned sblocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(batch_wave_setup, dim3(sblocks), dim3(256), 0, ctx->stream, a);
+  WaveScoring sc;
+  sc.match = p.match; sc.mismatch = p.mismatch; sc.gap = p.gap;
+  sc.u8M = sc.u8X = sc.u8G = 0.0f;
+  const unsigned blocks = (unsigned)((n + 15) / 16);
+  const WaveProblem *dp = ctx->wprobs.as<WaveProblem>();
+#define BATCH_WAVE(r)                                                                                                   \
+  if (orient == 0) launch_wave_batch<r, 0>(want_trace, blocks, ctx->stream, dp, (int)n, sc);                            \
+  else launch_wave_batch<r, 1>(want_trace, blocks, ctx->stream, dp, (int)n, sc);
+  if (R == 10) { BATCH_WAVE(10) } else if (R == 20) { BATCH_WAVE(20) } else { BATCH_WAVE(32) }
+#undef BATCH_WAVE
+  HIPCHK(ctx, hipGetLastError());
+
+  // results land in pinned staging: [best n x 4][cell n x 16][wout n x 24][offs (n + 1) x 8]
+  const size_t o_best = 0, o_cell = (n * 4 + 15) & ~(size_t)15, o_wout = o_cell + n * 16, o_offs = o_wout + n * 24;
+  if (ctx->pin_out.ensure(o_offs + (n + 1) * 8 + 64)) return fail(ctx, MI355_SW_ENOMEM, "hipHostMalloc(batch results) failed");
+  uint8_t *pin = ctx->pin_out.as<uint8_t>();
+  float *h_best = reinterpret_cast<float *>(pin + o_best);
+  int64_t *h_cell = reinterpret_cast<int64_t *>(pin + o_cell);
+  int64_t *h_wout = reinterpret_cast<int64_t *>(pin + o_wout);
+  int64_t *h_offs = reinterpret_cast<int64_t *>(pin + o_offs);
+  HIPCHK(ctx, hipMemcpyAsync(h_best, ctx->outs_f.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(h_cell, ctx->outs_i.p, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  const char *cons_base = nullptr;
+  if (want_trace) {
+    WaveWalk *walks = ctx->walkp.as<WaveWalk>();
+    int64_t *wout = reinterpret_cast<int64_t *>(ctx->walkp.as<uint8_t>() + n * sizeof(WaveWalk));
+    int64_t *offs = wout + 3 * n;                                  // [n] sizes -> offsets, then [1] total
+    BatchWalkArgs b;
+    b.probs = dp; b.qbytes = a.qbytes; b.qoff = a.qoff; b.qsel = a.qsel; b.ref = a.ref;
+    b.first = (int)first; b.count = (int)n; b.orient = orient; b.R = R;
+    b.best = a.best; b.cell = a.cell; b.walks = walks; b.wout = wout;
+    hipLaunchKernelGGL(batch_walk_setup, dim3(sblocks), dim3(256), 0, ctx->stream, b);
+    const unsigned wblocks = (unsigned)((n + 63) / 64);
+    hipLaunchKernelGGL(sw_wave_walk_kernel<kWalkMeasure>, dim3(wblocks), dim3(64), 0, ctx->stream, (const WaveWalk *)walks, (int)n,
+                       (char *)nullptr, (const int64_t *)nullptr);
+    hipLaunchKernelGGL(batch_walk_sizes, dim3(sblocks), dim3(256), 0, ctx->stream, (const int64_t *)wout, (int)n, offs);
+    HIPCHK(ctx, hipGetLastError());
+    int rc = device_scan(ctx, offs, (int64_t)n, offs + n);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(h_offs, offs, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_wout, wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));              // the one mid-call round trip: how many bytes to expect
+    const size_t ctot = (size_t)h_offs[n];
+    if (ctx->pin_cons.size() <= ctx->cons_used) ctx->pin_cons.resize(ctx->cons_used + 1);
+    PinBuf &cons = ctx->pin_cons[ctx->cons_used];
+    if (ctx->cons.ensure(ctot + 16) || cons.ensure(ctot + 16)) return fail(ctx, MI355_SW_ENOMEM, "consensus buffers: allocation failed");
+    hipLaunchKernelGGL(sw_wave_walk_kernel<kWalkWrite>, dim3(wblocks), dim3(64), 0, ctx->stream, (const WaveWalk *)walks, (int)n,
+                       ctx->cons.as<char>(), (const int64_t *)offs);
+    HIPCHK(ctx, hipGetLastError());
+    if (ctot) HIPCHK(ctx, hipMemcpyAsync(cons.p, ctx->cons.p, ctot, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->cons_used++;
+    cons_base = cons.as<char>();
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  bool bad = false;
+  parallel_for(n, [&](size_t k0, size_t k1) {
+    for (size_t k = k0; k < k1; ++k) {
+      const int id = q.order[first + k];
+      handled[id] = 1;
+      Located &L = loc[id];
+      L.score = h_best[k] > 0 ? h_best[k] : 0;
+      L.ix = h_cell[2 * k]; L.iy = h_cell[2 * k + 1];
+      if (!want_trace || !(L.score > 0)) continue;
+      if (h_wout[3 * k + 2] != 0) { bad = true; continue; }
+      TraceOut &t = tout[id];
+      t.len = (size_t)h_wout[3 * k];
+      t.cx = cons_base + h_offs[k];
+      t.cy = t.cx + t.len;
+      t.pos = (uint32_t)h_wout[3 * k + 1];
+    }
+  });
+  if (bad) return fail(ctx, MI355_SW_ENODEV, "internal: a walk over a whole-problem window failed");
+  return 0;
+}
+
+}  // namespace

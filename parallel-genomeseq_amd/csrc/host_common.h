@@ -64,12 +64,14 @@ struct RefData {
 
 struct QueryBatch {
   DevBuf bytes, lens, offs, sel;  // concatenated bytes (16-byte aligned starts), lengths, offsets, length-sorted ids
+  DevBuf cum;                     // [nq + 1] exclusive prefix of the lengths in sorted order (device-built job lists)
   std::vector<int32_t> len;
   std::vector<int64_t> off;
   std::vector<int32_t> order;     // query ids sorted by length (stable)
+  std::vector<int64_t> cumlen;    // host copy of `cum`
   size_t nq = 0;
   int maxlen = 0;
-  void release() { bytes.release(); lens.release(); offs.release(); sel.release(); }
+  void release() { bytes.release(); lens.release(); offs.release(); sel.release(); cum.release(); }
 };
 
 struct Range { int64_t lo, hi; };
@@ -89,6 +91,14 @@ struct Located {
 
 }  // namespace
 
+// results of mi355_sw_batch_run_view: arrays the context owns until its next call
+struct ViewStore {
+  std::vector<float> score;
+  std::vector<uint32_t> pos, cons_len;
+  std::vector<int64_t> end_x, end_y;
+  std::vector<const char *> cx, cy;
+};
+
 struct mi355_sw_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -101,7 +111,7 @@ struct mi355_sw_ctx {
   bool adhoc_valid = false;
   QueryBatch one;                 // the single query of such a call
   // scratch
-  DevBuf keys, ranges, stab, ftab, ftab_s, htab, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs;
+  DevBuf keys, ranges, stab, ftab, ftab_s, htab, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs, scan;
   // host sides of small per-call uploads: they must outlive the asynchronous copies, and the tables are only
   // sent again when they change
   std::vector<int64_t> h_ranges;
@@ -120,6 +130,7 @@ struct mi355_sw_ctx {
   std::vector<PinBuf> pin_cons;
   size_t cons_used = 0;
   double timings[6] = {0, 0, 0, 0, 0, 0};
+  ViewStore view;
   mi355_sw_kernel_info last_kernel = {};   // score-kernel instance that swept the most cells in the running call
 };
 
@@ -151,6 +162,27 @@ inline int sat8(float a) { return a < 0 ? 0 : (a > 255 ? 255 : (int)(uint8_t)a);
 // positive gap penalty (1e-20) would otherwise overflow it (undefined behaviour; INT64_MIN on x86).
 constexpr int64_t kColsMax = (int64_t)1 << 50;
 inline int64_t clamp_cols(double v) { return v >= (double)kColsMax ? kColsMax : (v <= 0 ? 0 : (int64_t)v); }
+
+// Exactness margins under float32 ROUNDING.  A cell value is the rounded score of a chain of cells
+// (follow the neighbour that achieved the maximum) that ends where a cell is 0.  With integer-valued scores every
+// operation is exact and a chain with positive value over `rows` rows spans fewer than rows + smax*rows/g columns.
+// With fractional scores each of the chain's operations may round by up to u = half an ulp of the largest value
+// (<= smax*(rows+1) * 2^-24; taken as 2^-23 of it), so a chain with k_g gap steps still has
+// smax*rows - g*k_g + (rows + k_g)*u > 0, i.e. k_g < rows*(smax + u)/(g - u): the same formulas with smax + u and g - u.
+// A gap penalty within a factor 64 of u (H - g could stall or shrink by much less than g) has no usable margin.
+struct Margin {
+  double smax = 0, g = 0;
+  bool finite() const { return g > 0 && std::isfinite(smax) && std::isfinite(g); }
+  double slope() const { return finite() ? smax / g : 0.0; }
+  int64_t cols(double rows) const { return finite() ? clamp_cols(rows + std::ceil(rows * smax / g)) : kColsMax; }
+};
+inline Margin make_margin(double smax, double g, bool exact, double rows) {
+  if (!(g > 0) || !std::isfinite(smax) || !std::isfinite(g)) return Margin{smax, 0};
+  if (exact) return Margin{smax, g};
+  const double u = std::ldexp(std::max(smax, 0.0) * (rows + 1.0), -23);
+  if (u * 64 > g) return Margin{smax, 0};
+  return Margin{smax + u, g - u};
+}
 
 struct U8Params { int M, X, G; };
 U8Params u8_params(const mi355_sw_params &p) {
@@ -367,8 +399,13 @@ int upload_queries(mi355_sw_ctx *ctx, QueryBatch &q, size_t n, const char *const
     copy_part(0, n);
   }
   memset(host + tot, 0, 16);
-  if (q.bytes.ensure(tot + 16) || q.lens.ensure(n * 4 + 16) || q.offs.ensure(n * 8 + 16) || q.sel.ensure(n * 4 + 16))
+  q.cumlen.resize(n + 1);
+  q.cumlen[0] = 0;
+  for (size_t k = 0; k < n; ++k) q.cumlen[k + 1] = q.cumlen[k] + q.len[q.order[k]];
+  if (q.bytes.ensure(tot + 16) || q.lens.ensure(n * 4 + 16) || q.offs.ensure(n * 8 + 16) || q.sel.ensure(n * 4 + 16) ||
+      q.cum.ensure((n + 1) * 8 + 16))
     return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(queries) failed");
+  HIPCHK(ctx, hipMemcpyAsync(q.cum.p, q.cumlen.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(q.bytes.p, host, tot + 16, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(q.lens.p, q.len.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(q.offs.p, q.off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));

@@ -25,8 +25,9 @@ int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, co
   // A cell in row i is exact once it lies i + ceil(i * smax / g) columns into a window (the bound of DESIGN.md
   // §3.3 for a path that can only use rows 1..i), so the window needs that margin at the argmax row plus room
   // for the horizontal excursions of the walk; the walk kernel checks every cell it visits against the bound.
-  const float slope = table.gapf > 0 ? table.smaxf / table.gapf : 0.0f;
-  auto row_need = [&](int64_t i) { return clamp_cols((double)i + std::ceil((double)i * (double)slope) + 2.0); };
+  const Margin mg = table.margin(q.maxlen);
+  const float slope = (float)mg.slope();
+  auto row_need = [&](int64_t i) { return mg.finite() ? clamp_cols((double)i + std::ceil((double)i * (double)slope) + 2.0) : kColsMax; };
   std::vector<size_t> todo;
   // short reads with identity scoring: decisions by the register-wavefront kernel (lanes = rows of x);
   // long queries (identity scoring, or any table in the float engine): the pipelined strip kernel
@@ -277,9 +278,10 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
     // only cells equal to the known maximum compete: a path that reaches `score` within |x| diagonal steps can
     // afford fewer gap columns than the general margin allows (DESIGN.md §3.3 with the score subtracted)
     int64_t warm = qwarm[k];
-    if (table.gapf > 0) {
-      const double spare = std::max(0.0, (double)table.smaxf * (double)q.len[k] - (double)score);
-      warm = std::min<int64_t>(warm, clamp_cols((double)q.len[k] + std::ceil(spare / (double)table.gapf) + 2.0));
+    const Margin mg = table.margin(q.len[k]);
+    if (mg.finite()) {
+      const double spare = std::max(0.0, mg.smax * (double)q.len[k] - (double)score);
+      warm = std::min<int64_t>(warm, clamp_cols((double)q.len[k] + std::ceil(spare / mg.g) + 2.0));
     }
     const int64_t first = (int64_t)(0xFFFFFFFFull - (key & 0xFFFFFFFFull));
     loc[k].score = score;
@@ -385,16 +387,17 @@ float elapsed_us(mi355_sw_ctx *ctx, hipEvent_t a, hipEvent_t b) {
   return ms * 1000.0f;
 }
 
-// All queries of `q` against one range of the reference.
-int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
-                const mi355_sw_params &p, int flags, mi355_sw_result *outs) {
+// All queries of `q` against one range of the reference: argmax cells and traceback views (into buffers the context
+// keeps until its next call), indexed by query id.
+int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
+                     const mi355_sw_params &p, int flags, std::vector<Located> &loc, std::vector<TraceOut> &tout) {
   HostTrace trace_("align_range");
   const bool want_trace = !(flags & MI355_SW_SCORE_ONLY);
   const size_t nq = q.nq;
   const int64_t n = rg.hi - rg.lo;
   HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-  std::vector<Located> loc(nq);
-  std::vector<TraceOut> tout(nq);
+  loc.assign(nq, Located());
+  tout.assign(nq, TraceOut());
   // No score can be positive (uint8 engine whose match score saturates to 0; float engine whose best substitution
   // score is <= 0 with a positive gap): every cell of the matrix is 0 and the defined no-match result stands.
   bool all_zero = false;
@@ -446,8 +449,30 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
         for (size_t t = 0; t < fq.size(); ++t) tout[fq[t]] = std::move(ft[t]);
       }
     }
+    // Many small whole problems (short reference or short queries: nothing took the score kernel): float engine with
+    // identity scoring runs them on device-built job lists, one sorted range per orientation (host_batch.h)
+    std::vector<char> handled(nq, 0);
+    if (!any_fast && p.semantics == MI355_SW_F32 && wave_scoring_ok(p) && std::getenv("MI355_SW_NO_WAVE") == nullptr &&
+        std::getenv("MI355_SW_NO_DEVLIST") == nullptr) {
+      auto len_at = [&](size_t pos) { return (int64_t)q.len[q.order[pos]]; };
+      auto first_above = [&](int64_t v) {                          // first sorted position whose length exceeds v
+        size_t lo = 0, hi = nq;
+        while (lo < hi) { const size_t mid = (lo + hi) / 2; if (len_at(mid) <= v) lo = mid + 1; else hi = mid; }
+        return lo;
+      };
+      const size_t z = first_above(0);                             // empty queries: score 0, nothing to run
+      const size_t e0 = first_above(std::min<int64_t>(kWaveMaxLanesSide, n));   // lanes = rows of x (|x| <= 512, |x| <= |y|)
+      const size_t e1 = n <= kWaveMaxLanesSide ? nq : e0;          // lanes = columns of y (|y| <= 512), x streams
+      for (size_t pos = 0; pos < z; ++pos) handled[q.order[pos]] = 1;
+      HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+      int rc = exact_full_device(ctx, ref, q, rg, p, z, e0 - z, 0, want_trace, loc, tout, handled);
+      if (!rc) rc = exact_full_device(ctx, ref, q, rg, p, e0, e1 - e0, 1, want_trace, loc, tout, handled);
+      if (rc) return rc;
+      HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+      ctx->timings[2] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
+    }
     std::vector<int> slow;
-    for (size_t k = 0; k < nq; ++k) if (!qfast[k]) slow.push_back((int)k);
+    for (size_t k = 0; k < nq; ++k) if (!qfast[k] && !handled[k]) slow.push_back((int)k);
     if (!slow.empty()) {
       std::vector<Located> sl;
       std::vector<TraceOut> st;
@@ -464,6 +489,18 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
   ctx->timings[3] += elapsed_us(ctx, ctx->ev[4], ctx->ev[5]);
+  return 0;
+}
+
+// ... as an array of results with library-owned (malloc) strings: the C-ABI's classic form
+int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
+                const mi355_sw_params &p, int flags, mi355_sw_result *outs) {
+  const bool want_trace = !(flags & MI355_SW_SCORE_ONLY);
+  const size_t nq = q.nq;
+  std::vector<Located> loc;
+  std::vector<TraceOut> tout;
+  int rc = align_range_core(ctx, ref, q, rg, p, flags, loc, tout);
+  if (rc) return rc;
   HostTrace trace_results("set_results");
   const float t_iter = (float)(ctx->timings[0] > 0 ? ctx->timings[0] : ctx->timings[3]);
   parallel_for(nq, [&](size_t k0, size_t k1) {
@@ -473,6 +510,41 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
       outs[k].timings_us[1] = 0;
     }
   });
+  return 0;
+}
+
+// ... as a struct of arrays in context-owned memory, strings as views into the D2H buffers: nothing per alignment is
+// allocated (half a million small alignments per call)
+int align_range_view(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
+                     const mi355_sw_params &p, int flags, mi355_sw_batch_view *out) {
+  const bool want_trace = !(flags & MI355_SW_SCORE_ONLY);
+  const size_t nq = q.nq;
+  std::vector<Located> loc;
+  std::vector<TraceOut> tout;
+  int rc = align_range_core(ctx, ref, q, rg, p, flags, loc, tout);
+  if (rc) return rc;
+  HostTrace trace_results("view_results");
+  ViewStore &v = ctx->view;
+  v.score.resize(nq); v.pos.resize(nq); v.cons_len.resize(nq); v.end_x.resize(nq); v.end_y.resize(nq);
+  v.cx.resize(nq); v.cy.resize(nq);
+  parallel_for(nq, [&](size_t k0, size_t k1) {
+    for (size_t k = k0; k < k1; ++k) {
+      const bool hit = loc[k].score > 0;
+      const TraceOut *t = (want_trace && hit) ? &tout[k] : nullptr;
+      v.score[k] = loc[k].score;
+      v.end_x[k] = hit ? loc[k].ix : 0;
+      v.end_y[k] = hit ? loc[k].iy : 0;
+      v.pos[k] = t ? t->pos : 0;
+      v.cons_len[k] = t ? (uint32_t)t->len : 0;
+      v.cx[k] = t && t->len ? t->cx : nullptr;
+      v.cy[k] = t && t->len ? t->cy : nullptr;
+    }
+  });
+  out->n = nq;
+  out->score = v.score.data(); out->pos = v.pos.data(); out->end_x = v.end_x.data(); out->end_y = v.end_y.data();
+  out->cons_x = v.cx.data(); out->cons_y = v.cy.data(); out->cons_len = v.cons_len.data();
+  out->timings_us[0] = (float)(ctx->timings[0] > 0 ? ctx->timings[0] : ctx->timings[3]);
+  out->timings_us[1] = 0;
   return 0;
 }
 

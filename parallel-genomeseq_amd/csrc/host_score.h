@@ -15,6 +15,9 @@ struct ScoreTable {
   std::vector<uint16_t> htab; // [256][ncodes] the same scores as float16 bits (packed float16 instances), empty when
                               // an entry does not fit (|s| <= 2048; padding -16384)
   std::vector<float> ftab;    // [256][ncodes]
+  // margins for queries of up to `rows` rows: exact arithmetic for integer scores (and the uint8 engine), widened by
+  // the float32 rounding slack otherwise
+  Margin margin(double rows) const { return make_margin(smaxf, gapf, integral, rows); }
 };
 
 // A run of length-sorted queries swept by one kernel instance.
@@ -170,11 +173,10 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       if (b.count == 1 && b.sem == kSemI16 && (double)t.smax * b.maxlen < 1.6e7) b.sem = kSemF32;
       else if (b.count == 1 && b.sem == kSemI16 && twin_ok) b.twin = true;
     }
-    const double smax = sem_is_float(b.sem) ? (double)t.smaxf : (double)t.smax;
-    const double gap = sem_is_float(b.sem) ? (double)t.gapf : (double)t.gap;
-    if (smax <= 0 || gap <= 0) b.warm = 0;
-    else b.warm = clamp_cols((double)b.maxlen + std::ceil(smax * b.maxlen / gap));
-    b.warm = (b.warm + 63) / 64 * 64;
+    const Margin mg = t.margin(b.maxlen);
+    if (!(mg.smax > 0)) b.warm = 0;
+    else b.warm = mg.cols(b.maxlen);                                  // DESIGN.md §3.3 (kColsMax: no finite margin)
+    b.warm = std::min(kColsMax, (b.warm + 63) / 64 * 64);
   }
   return out;
 }

@@ -180,6 +180,9 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
       (dirs_total && ctx->dirs.ensure(dirs_total)) || (gtotal && ctx->brow.ensure(gtotal * 4)))
     return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(strip scratch) failed");
   std::vector<StripProblem> pr(n);
+  // test hook: drives the pipeline's bounded-wait expiry (the workgroup raises its status word and drains)
+  const char *inject = std::getenv("MI355_SW_FAULT_INJECT");
+  const int32_t fault = (inject && std::strcmp(inject, "strip_stall") == 0) ? 1 : 0;
   for (size_t k = 0; k < n; ++k) {
     const WaveJob &j = jobs[k];
     StripProblem &s = pr[k];
@@ -198,6 +201,7 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
     s.full_n = rg.hi - rg.lo;
     s.cell = ctx->outs_i.as<int64_t>() + 2 * k;
     s.status = ctx->outs_f.as<int32_t>() + k;
+    s.fault = fault;
   }
   HIPCHK(ctx, hipMemsetAsync(ctx->outs_f.p, 0, n * 4, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ctx->wprobs.p, pr.data(), n * sizeof(StripProblem), hipMemcpyHostToDevice, ctx->stream));
@@ -248,20 +252,25 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
   for (size_t k = 0; k < qidx.size(); ++k) if (loc[k].score > 0) todo.push_back(k);
   // exactness margin along the stream: a positive path ending at a stream index spans fewer than
   // na + smax*na/g stream positions (DESIGN.md §3.3 with the roles of the two sequences as given)
-  double smax, g;
-  if (p.semantics == MI355_SW_U8SAT) { const U8Params u = u8_params(p); smax = u.M; g = u.G; }
-  else if (table != nullptr && table->ok) { smax = table->smaxf; g = table->gapf; }
-  else { smax = p.match; g = p.gap; }
+  int64_t maxna = 1;
+  for (size_t k : todo) maxna = std::max<int64_t>(maxna, orient == 0 ? q.len[qidx[k]] : nref);
+  Margin mg;
+  if (p.semantics == MI355_SW_U8SAT) { const U8Params u = u8_params(p); mg = make_margin(u.M, u.G, true, (double)maxna); }
+  else if (table != nullptr && table->ok) mg = table->margin((double)maxna);
+  else {
+    auto whole = [](float v) { return v == std::floor(v) && std::fabs(v) <= 1048576.0f; };
+    mg = make_margin(p.match, p.gap, whole(p.match) && whole(p.mismatch) && whole(p.gap), (double)maxna);
+  }
   // ... and a cell whose lane-side index is a (its path is confined to a rows / columns) is exact a + ceil(a*smax/g)
   // positions into the window: the window needs that margin at the argmax plus room for the walk's excursions
   // along the stream; the walk kernel checks every cell it visits
-  const float slope = g > 0 ? (float)(smax / g) : 0.0f;
-  auto lane_need = [&](int64_t a) { return clamp_cols((double)a + std::ceil((double)a * (double)slope) + 2.0); };
+  const float slope = (float)mg.slope();
+  auto lane_need = [&](int64_t a) { return mg.finite() ? clamp_cols((double)a + std::ceil((double)a * (double)slope) + 2.0) : kColsMax; };
   std::vector<int64_t> budget(qidx.size()), warm(qidx.size());
   for (size_t k : todo) {
     const int64_t na = orient == 0 ? q.len[qidx[k]] : nref;
     budget[k] = na / 8 + 64;
-    warm[k] = g > 0 ? clamp_cols((double)na + std::ceil(smax * (double)na / g)) : (int64_t)1 << 40;
+    warm[k] = mg.finite() ? mg.cols((double)na) : (int64_t)1 << 40;
   }
   while (!todo.empty()) {
     std::vector<size_t> next;

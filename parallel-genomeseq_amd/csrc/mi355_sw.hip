@@ -30,6 +30,7 @@
 #include "sw_score_kernel.h"
 #include "sw_wave_kernel.h"
 #include "sw_strip_kernel.h"
+#include "sw_batch_kernels.h"
 
 using namespace mi355sw;
 
@@ -37,6 +38,7 @@ using namespace mi355sw;
 #include "host_score.h"
 #include "host_exact.h"
 #include "host_wave.h"
+#include "host_batch.h"
 #include "host_pipeline.h"
 #include "host_multi.h"   // mi355_sw_multi_*: its own extern "C" block
 
@@ -73,7 +75,7 @@ void mi355_sw_destroy(mi355_sw_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   DevBuf *bufs[] = {&c->ref.bytes, &c->ref.codes, &c->batch.bytes, &c->batch.lens, &c->keys, &c->ranges, &c->stab,
-                    &c->batch.offs, &c->batch.sel, &c->ftab, &c->ftab_s, &c->htab, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow, &c->wprobs};
+                    &c->batch.offs, &c->batch.sel, &c->ftab, &c->ftab_s, &c->htab, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow, &c->wprobs, &c->scan, &c->batch.cum};
   for (DevBuf *b : bufs) b->release();
   c->adhoc.release(); c->one.release();
   c->pin_probs.release(); c->pin_walk.release(); c->pin_out.release();
@@ -106,6 +108,17 @@ int mi355_sw_batch_run(mi355_sw_ctx *ctx, const mi355_sw_params *params, int fla
   reset_timings(ctx);
   if (ctx->batch.nq == 0) return 0;
   return align_range(ctx, ctx->ref, ctx->batch, Range{0, (int64_t)ctx->ref.n}, *params, flags, outs);
+}
+
+int mi355_sw_batch_run_view(mi355_sw_ctx *ctx, const mi355_sw_params *params, int flags, mi355_sw_batch_view *out) {
+  int rc = check_params(ctx, params);
+  if (rc) return rc;
+  if (!out) return fail(ctx, MI355_SW_EINVAL, "out is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  reset_timings(ctx);
+  memset(out, 0, sizeof *out);
+  if (ctx->batch.nq == 0) return 0;
+  return align_range_view(ctx, ctx->ref, ctx->batch, Range{0, (int64_t)ctx->ref.n}, *params, flags, out);
 }
 
 int mi355_sw_align_batch(mi355_sw_ctx *ctx, size_t n, const char *const *xs, const size_t *nxs,

@@ -1,0 +1,173 @@
+// sw_batch_kernels.h — device-side job lists for batches of MANY SMALL whole problems (the UniProt shape of
+// src/mpi_sw_solve_uniprot.cpp:95-138: half a million database sequences, each against one short query).
+//
+// The host used to build one descriptor per alignment per pass (problem lists up, results down, walk descriptors up,
+// lengths down, offsets up: ~250 MB of staging and several per-item host loops for 561 k alignments).  Here the
+// descriptors of sw_wave_kernel / sw_wave_walk_kernel are written ON THE DEVICE from what is already resident — the
+// batch's offsets, lengths and length-sorted ids — and the only things that cross PCIe are the results:
+//   batch_wave_setup   WaveProblem[k] for sorted positions [first, first + count): whole problem, TRACK + DIRS
+//   (sw_wave_kernel)   one pass: first maximum in storage order AND the greedy decision of every cell
+//   batch_walk_setup   WaveWalk[k] from the argmax the pass just found
+//   (sw_wave_walk_kernel<kWalkMeasure>)  ->  walk_sizes  ->  exclusive scan  ->  (sw_wave_walk_kernel<kWalkWrite>)
+// plus a three-kernel exclusive scan of int64 (block sums, scan of the sums, add).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sw_wave_kernel.h"
+
+namespace mi355sw {
+
+struct BatchWaveArgs {
+  const uint8_t *qbytes;     // resident queries
+  const int64_t *qoff;
+  const int32_t *qlen;
+  const int32_t *qsel;       // query ids sorted by length
+  const int64_t *qcum;       // [nq + 1] exclusive prefix of the lengths in sorted order
+  const uint8_t *ref;        // first byte of the range of the reference
+  int64_t nref;
+  int first, count;          // sorted positions [first, first + count)
+  int orient;                // as WaveProblem: 0 lanes = rows of x (stream = the range), 1 lanes = columns of y (stream = x)
+  int W;                     // dwords of decisions per lane and stream position
+  uint32_t *dirs;            // decision scratch of this launch
+  WaveProblem *probs;        // [count]
+  float *best;               // [count]
+  int64_t *cell;             // [2 * count]
+};
+
+// decision bytes in front of problem k of the launch (k = 0 .. count): stream positions so far * 16 lanes * W dwords,
+// plus 64 bytes of slack per problem (as wave_dirs_bytes on the host)
+__device__ __host__ inline int64_t batch_dirs_offset(int64_t stream_positions_before, int64_t k, int W) {
+  return stream_positions_before * 16 * (int64_t)W * 4 + 64 * k;
+}
+
+__global__ void batch_wave_setup(const BatchWaveArgs a) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.count) return;
+  const int id = a.qsel[a.first + k];
+  const uint8_t *xq = a.qbytes + a.qoff[id];
+  const int32_t m = a.qlen[id];
+  WaveProblem w;
+  int64_t before;                                                  // stream positions of the problems in front of this one
+  if (a.orient == 0) { w.a = xq; w.na = m; w.b = a.ref; w.nb = (int32_t)a.nref; before = (int64_t)k * a.nref; }
+  else { w.a = a.ref; w.na = (int32_t)a.nref; w.b = xq; w.nb = m; before = a.qcum[a.first + k] - a.qcum[a.first]; }
+  w.b_offset = 0;
+  w.dirs = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(a.dirs) + batch_dirs_offset(before, k, a.W));
+  w.best = a.best + k;
+  w.cell = a.cell + 2 * (size_t)k;
+  w.target = 0.0f; w.own_lo = 0; w.full_n = a.nref;
+  a.probs[k] = w;
+}
+
+struct BatchWalkArgs {
+  const WaveProblem *probs;  // [count] as built by batch_wave_setup
+  const uint8_t *qbytes;
+  const int64_t *qoff;
+  const int32_t *qsel;
+  const uint8_t *ref;
+  int first, count, orient, R;
+  const float *best;
+  const int64_t *cell;
+  WaveWalk *walks;           // [count]
+  int64_t *wout;             // [3 * count]
+};
+
+__global__ void batch_walk_setup(const BatchWalkArgs a) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.count) return;
+  const WaveProblem P = a.probs[k];
+  const int id = a.qsel[a.first + k];
+  WaveWalk w;
+  w.x = a.qbytes + a.qoff[id];
+  w.y = a.ref;
+  w.dirs = P.dirs;
+  w.na = P.na; w.nb = P.nb; w.orient = a.orient;
+  w.R = a.R; w.lanes = 16;
+  w.need_slope = 0.0f;
+  w.b_offset = 0;
+  const bool hit = a.best[k] > 0.0f;
+  w.start_i = hit ? a.cell[2 * (size_t)k] : 0;                     // no positive cell: the walk emits nothing
+  w.start_j = hit ? a.cell[2 * (size_t)k + 1] : 0;
+  w.exact_from = 0;                                                // whole problem: every cell is exact
+  w.cap = P.na + P.nb + 2;
+  w.out = a.wout + 3 * (size_t)k;
+  a.walks[k] = w;
+}
+
+// bytes of consensus the write pass will emit per walk (x and y back to back), 0 for a failed walk
+__global__ void batch_walk_sizes(const int64_t *wout, int n, int64_t *sizes) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  sizes[k] = wout[3 * (size_t)k + 2] == 0 ? 2 * wout[3 * (size_t)k] : 0;
+}
+
+// ---- exclusive scan of int64: v[k] <- sum of v[0..k), total in *total ---------------------------------------------
+constexpr int kScanBlock = 256;
+constexpr int kScanItems = 16;                                     // per thread: 4096 values per workgroup
+
+__device__ inline int64_t scan_block_exclusive(int64_t v, int64_t *shared, int64_t *block_total) {
+  // exclusive prefix of one value per thread over the workgroup (Hillis-Steele over wavefront totals)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int64_t incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int64_t o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) shared[wv] = incl;
+  __syncthreads();
+  int64_t base = 0, tot = 0;
+  for (int k = 0; k < kScanBlock / 64; ++k) { if (k < wv) base += shared[k]; tot += shared[k]; }
+  __syncthreads();
+  *block_total = tot;
+  return base + incl - v;
+}
+
+__global__ __launch_bounds__(kScanBlock) void scan_partials(const int64_t *v, int64_t n, int64_t *partial) {
+  __shared__ int64_t sh[kScanBlock / 64];
+  const int64_t base = ((int64_t)blockIdx.x * kScanBlock + threadIdx.x) * kScanItems;
+  int64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) if (base + k < n) s += v[base + k];
+  int64_t tot;
+  (void)scan_block_exclusive(s, sh, &tot);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// one workgroup: exclusive scan of the partials in place (any count), grand total out
+__global__ __launch_bounds__(kScanBlock) void scan_of_partials(int64_t *partial, int np, int64_t *total) {
+  __shared__ int64_t sh[kScanBlock / 64];
+  __shared__ int64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int b = 0; b < np; b += kScanBlock) {
+    const int k = b + threadIdx.x;
+    const int64_t v = k < np ? partial[k] : 0;
+    int64_t tot;
+    const int64_t ex = scan_block_exclusive(v, sh, &tot);
+    const int64_t c = carry;
+    if (k < np) partial[k] = c + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(kScanBlock) void scan_apply(int64_t *v, int64_t n, const int64_t *partial) {
+  __shared__ int64_t sh[kScanBlock / 64];
+  const int64_t base = ((int64_t)blockIdx.x * kScanBlock + threadIdx.x) * kScanItems;
+  int64_t x[kScanItems];
+  int64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) { x[k] = base + k < n ? v[base + k] : 0; s += x[k]; }
+  int64_t tot;
+  int64_t run = partial[blockIdx.x] + scan_block_exclusive(s, sh, &tot);
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k < n) v[base + k] = run;
+    run += x[k];
+  }
+}
+
+}  // namespace mi355sw

@@ -48,6 +48,8 @@ struct StripProblem {
   int64_t full_n;        // |y| of the full problem (uint8 storage order)
   int64_t *cell;         // [2] row, true column of the first cell equal to target; row 0 when none
   int32_t *status;       // 0 = complete, 1 = a pipeline wait expired (result unusable)
+  int32_t fault;         // test hook (MI355_SW_FAULT_INJECT=strip_stall): wavefront 0 never reports progress, so the
+                         // strip below it runs into the bounded wait and the workgroup takes the expiry path
 };
 
 enum : int { kStripDirs = 0, kStripTrack = 1 };
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
         if (t >= 0 && t < nb) __hip_atomic_store(gout + t, rout[t & (kStripRing - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (l == 0) {
-        if (has_out) __hip_atomic_store(&produced[w], base + seg * 64 + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (has_out && !(P.fault && w == 0)) __hip_atomic_store(&produced[w], base + seg * 64 + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(&consumed[w], base + (seg + 1) * 64, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       const uint8_t hist = buf[64 + l];
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
       buf[64 + l] = (uint8_t)nextc;
       nextc = stage_load(seg + 2);
     }
-    if (l == 0 && ok) {
+    if (l == 0 && ok && !(P.fault && w == 0)) {
       // the whole round of this strip is done: releases every wait of this round on this wavefront
       __hip_atomic_store(&produced[w], base + NBP, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       __hip_atomic_store(&consumed[w], base + NBP, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);

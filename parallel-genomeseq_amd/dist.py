@@ -19,7 +19,10 @@ import torch.distributed as dist
 
 
 def _dev():
-    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    """Where the (tiny) collective payloads live: the rank's GPU under RCCL, the host otherwise (gloo, or no group)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
 
 
 def world():

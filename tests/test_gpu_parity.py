@@ -383,6 +383,65 @@ def test_float32_instance(ctx, oracle, pgs):
     _cmp(ctx.align(q, refb, 0, 20.0, -15.0, 8.0), exp, "f32 score > 2^15")
 
 
+def test_non_dyadic_fractional_scoring(ctx, oracle, pgs):
+    """Scorings whose float32 additions ROUND (0.1, 0.3, 0.7 and a table scaled by 0.37 are not dyadic): the regime where
+    north_star's 1e-5 tolerance, the 2^-k scaling of the float32 score instance and the warm-up margins (proved in real
+    arithmetic, widened by the rounding slack of host_common.h make_margin) could bite.  References long enough for the
+    TILED float32 instance (several tiles per query, warm-up columns in front of each), single calls and batches,
+    one strip-mined query.  Compared bit-exact against the oracle (same operation order as dp_func,
+    similaritymatrix.cpp:49-54); a mismatch reports the largest |delta|."""
+    ref = pgs.synth.dna(83, 300_000)
+    refb = ref.tobytes()
+    reads = [pgs.synth.read_from_ref(ref, 500 + k, m, sub_rate=0.04, indel_rate=0.01)[0].tobytes()
+             for k, m in enumerate((40, 150, 151, 152, 300, 511, 640))]
+    worst = 0.0
+    bad = []
+    for sc in (dict(match=0.7, mismatch=-0.3, gap=0.1), dict(match=0.1, mismatch=-0.3, gap=0.7),
+               dict(match=1.1, mismatch=-0.9, gap=0.37), dict(match=3.3, mismatch=-3.3, gap=2.2)):
+        exp = [oracle.align(q, refb, 0, **sc) for q in reads]
+        got = ctx.align_batch(reads, refb, semantics=0, **sc)
+        assert ctx.last_kernel()["dtype"] == "f32" and ctx.last_kernel()["cells"] > 0        # the tiled float32 instance ran
+        got += [ctx.align(q, refb, 0, **sc) for q in reads[1:4]]
+        exp += exp[1:4]
+        for g, e in zip(got, exp):
+            worst = max(worst, abs(g["score"] - e["score"]))
+            if any(g[k] != e[k] for k in ("score", "pos", "end_x", "end_y", "cons_x", "cons_y")):
+                bad.append((sc, len(e["cons_x"]), g["score"], e["score"], g["pos"], e["pos"]))
+    lut = (pgs.synth.make_lut(4711, 1.0) * np.float32(0.37)).astype(np.float32)
+    exp = [oracle.align(q, refb, 0, gap=0.53, lut=lut) for q in reads]
+    for g, e in zip(ctx.align_batch(reads, refb, semantics=0, gap=0.53, lut=lut), exp):
+        worst = max(worst, abs(g["score"] - e["score"]))
+        if any(g[k] != e[k] for k in ("score", "pos", "end_x", "end_y", "cons_x", "cons_y")):
+            bad.append(("lut x0.37", len(e["cons_x"]), g["score"], e["score"], g["pos"], e["pos"]))
+    # one strip-mined query (2500 rows) on a shorter reference (the oracle holds the whole float matrix)
+    sub = refb[:120_000]
+    q = pgs.synth.read_from_ref(ref[:120_000], 777, 2500, sub_rate=0.03, indel_rate=0.01)[0].tobytes()
+    for sc in (dict(match=0.7, mismatch=-0.3, gap=0.1), dict(match=1.1, mismatch=-0.9, gap=0.37)):
+        g, e = ctx.align(q, sub, 0, **sc), oracle.align(q, sub, 0, **sc)
+        worst = max(worst, abs(g["score"] - e["score"]))
+        if any(g[k] != e[k] for k in ("score", "pos", "end_x", "end_y", "cons_x", "cons_y")):
+            bad.append((sc, "2500 rows", g["score"], e["score"], g["pos"], e["pos"]))
+    assert not bad, "max |delta score| = %g; %r" % (worst, bad[:5])
+
+
+def test_tiny_gap_has_no_rounding_safe_margin(ctx, oracle, pgs):
+    """A gap penalty within a factor 64 of half an ulp of the largest cell value (float32 H - g may stall): the margins
+    of DESIGN.md §3.3 do not exist, so the problem takes the whole-matrix path (small) or fails loudly (large) — never
+    the tiled instance.  Also the overflow of the margin's integer cast (gap = 1e-20)."""
+    ref = pgs.synth.dna(84, 3000).tobytes()
+    q = ref[1000:1100]
+    for gap in (1e-20, 1e-6):
+        g, e = ctx.align(q, ref, 0, 3.25, -3.5, gap), oracle.align(q, ref, 0, 3.25, -3.5, gap)
+        _cmp(g, e, "tiny gap %g" % gap)
+    mid = pgs.synth.dna(85, 300_000).tobytes()                         # whole-matrix path (the LDS anti-diagonal kernel)
+    _cmp(ctx.align(mid[5000:5600], mid, 0, 3.25, -3.5, 1e-6), oracle.align(mid[5000:5600], mid, 0, 3.25, -3.5, 1e-6), "tiny gap, 600 x 300k")
+    assert ctx.last_kernel()["cells"] == 0                             # not the tiled score kernel
+    big = pgs.synth.dna(85, 40_000_000).tobytes()                      # beyond the whole-matrix scratch budget
+    with pytest.raises(pgs.MI355Error) as ei:
+        ctx.align(big[5000:5600], big, 0, 3.25, -3.5, 1e-6)
+    assert ei.value.code == -95                                        # MI355_SW_ENOTSUP, with a message
+
+
 def test_full_size_against_lean_oracle(ctx, oracle, pgs):
     """Config 3 at FULL reference size against the oracle: 150 bp x 50 Mbp does not fit a matrix (30 GB), so the
     oracle's rolling-column locate gives (score, argmax) for the whole reference, and the traceback is checked
@@ -402,10 +461,12 @@ def test_full_size_against_lean_oracle(ctx, oracle, pgs):
     for (q, sem), (mx, ix, iy) in zip(jobs, exp):
         r = got[sem][reads.index(q)]
         assert (r["score"], r["end_x"], r["end_y"]) == (mx, ix, iy), (sem, reads.index(q))
+        # traceback: never conditional — the oracle walks from the FULL-size argmax (the uint8 storage order depends on
+        # the full problem's ncols, so the start cell is not re-derived on the window); the window only supplies H
         lo = max(0, iy - 20_000)
-        w = oracle.align(q, refb[lo:iy], sem)
-        if (w["end_x"], w["end_y"]) == (ix, iy - lo):                  # same start cell => same walk
-            assert (r["cons_x"], r["cons_y"], r["pos"]) == (w["cons_x"], w["cons_y"], w["pos"] + lo)
+        w = oracle.trace_from(q, refb[lo:iy], sem, ix, iy - lo)
+        assert w["score"] == mx                                        # the window is long enough: H(start) is exact
+        assert (r["cons_x"], r["cons_y"], r["pos"]) == (w["cons_x"], w["cons_y"], w["pos"] + lo), (sem, reads.index(q))
 
 
 def test_fuzz_paths_vs_oracle(ctx, oracle, pgs):
@@ -641,3 +702,126 @@ def test_float32_cells_scaling_extremes(ctx, oracle, pgs):
             _cmp(g, oracle.align(q, refb, 0, *sc), "scaling %r |q|=%d" % (sc, len(q)))
         one = ctx.align(reads[0], refb, 0, *sc)
         _cmp(one, oracle.align(reads[0], refb, 0, *sc), "scaling lone %r" % (sc,))
+
+
+def test_strip_pipeline_wait_expiry_is_reported(ctx, oracle, pgs):
+    """sw_strip_kernel's bounded waits: with MI355_SW_FAULT_INJECT=strip_stall wavefront 0 of every workgroup never
+    reports progress, the strip below runs into the spin limit, the workgroup raises its status word and DRAINS (nothing
+    hangs), and the host reports an error instead of a result.  The context stays usable afterwards."""
+    import os
+    ref = pgs.synth.dna(86, 60_000)
+    q = pgs.synth.read_from_ref(ref, 87, 1500, sub_rate=0.02, indel_rate=0.004)[0].tobytes()   # three strips of 640 rows
+    refb = ref.tobytes()
+    os.environ["MI355_SW_FAULT_INJECT"] = "strip_stall"
+    try:
+        with pytest.raises(pgs.MI355Error) as ei:
+            ctx.align(q, refb, 0)
+        assert "wait expired" in str(ei.value)
+    finally:
+        del os.environ["MI355_SW_FAULT_INJECT"]
+    _cmp(ctx.align(q, refb, 0), oracle.align(q, refb, 0), "after the injected stall")
+
+
+def test_config4_uniprot_shape_20k(ctx, oracle, pgs):
+    """configs[3] shape under test at a meaningful size: 20 000 UniProt-shaped protein sequences (log-normal lengths,
+    2 .. 35 000 residues) as FIRST argument against the 144-aa P02232 query as SECOND (src/mpi_sw_solve_uniprot.cpp:120),
+    default scoring, float engine — EVERY (score, pos, end, consensus) against the oracle; the same batch through
+    LPT partitions (dist.shard_lpt, the query-sharding layout of SURVEY.md §8e) fed to real GPU callables, and through
+    two device contexts behind one handle, with the batch best (score, lowest index)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from parallel_genomeseq_amd import dist as pd
+    n = 20_000
+    lens = pgs.synth.lognormal_lengths(5, n)
+    allres = pgs.synth.protein(5, int(lens.sum()))
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    seqs = [allres[offs[k]:offs[k + 1]].tobytes() for k in range(n)]
+    query = pgs.synth.P02232
+    assert len(query) == 144 and lens.min() >= 2
+    with ThreadPoolExecutor(8) as ex:
+        exp = list(ex.map(lambda s: oracle.align(s, query, 0), seqs))
+    got = ctx.align_batch(seqs, query, semantics=0)
+    for k, (g, e) in enumerate(zip(got, exp)):
+        _cmp(g, e, "uniprot[%d] |x|=%d" % (k, lens[k]))
+    scores = np.array([e["score"] for e in exp])
+    # the same call as a struct-of-arrays view (mi355_sw_batch_run_view): arrays + strings read through the view
+    raw = ctx.batch_run(semantics=0, raw=True)
+    assert np.array_equal(raw["score"], scores.astype(np.float32))
+    for key in ("pos", "end_x", "end_y"):
+        assert raw[key].tolist() == [e[key] for e in exp], key
+    assert raw["cons_len"].tolist() == [len(e["cons_x"]) for e in exp]
+    for k in range(0, n, 37):
+        assert ctx.consensus(k) == (exp[k]["cons_x"], exp[k]["cons_y"]), k
+    # the host-built job lists (MI355_SW_NO_DEVLIST=1) must agree with the device-built ones
+    import os
+    os.environ["MI355_SW_NO_DEVLIST"] = "1"
+    try:
+        for g, e in zip(ctx.align_batch(seqs[:3000], query, semantics=0), exp[:3000]):
+            _cmp(g, e, "uniprot, host-built lists")
+    finally:
+        del os.environ["MI355_SW_NO_DEVLIST"]
+    # four LPT partitions by cell count, each aligned on its own (what four ranks would do), scattered back
+    parts = pd.shard_lpt(lens * len(query), 4)
+    loads = [int(lens[p].sum()) for p in parts]
+    assert max(loads) - min(loads) <= int(lens.max())
+    raw = np.zeros(n, dtype=np.float32)
+    pos = np.zeros(n, dtype=np.int64)
+    for p in parts:
+        out = ctx.align_batch([seqs[i] for i in p], query, semantics=0, raw=True)
+        raw[p], pos[p] = out["score"], out["pos"]
+    assert np.array_equal(raw, scores.astype(np.float32)) and pos.tolist() == [e["pos"] for e in exp]
+    idx, res, gathered = pd.align_queries_sharded(lambda qs: ctx.align_batch(qs, query, semantics=0), seqs,
+                                                  weights=lens * len(query))       # world size 1: the whole batch
+    assert np.array_equal(gathered["score"], scores.astype(np.float32))
+    assert pd.allreduce_best(float(scores.max()), int(scores.argmax())) == (float(scores.max()), int(scores.argmax()))
+    m = pgs.MultiContext([0, 0])
+    try:
+        out, best = m.align_batch(seqs, query, semantics=0, raw=True)
+        assert np.array_equal(out["score"], scores.astype(np.float32)) and out["pos"].tolist() == [e["pos"] for e in exp]
+        assert best == int(scores.argmax())
+    finally:
+        m.close()
+
+
+def test_config5_full_size_split_equals_whole(ctx, oracle, pgs):
+    """configs[4] at FULL size (one 10 kbp query against 250 Mbp; the CPU oracle cannot hold 2.5e12 cells): the
+    16-piece OMPParallelLocalAligner split (overlap 2.0, plocalaligner.cpp:44-67,105-143) must give the whole-reference
+    result — on one context and with the pieces dealt to two contexts — the planted position is recovered, and the
+    traceback is checked against the ORACLE on the 26 kbp window that ends at the argmax (long enough for the start
+    cell to be exact: |x| + 3|x|/2 columns)."""
+    n, m, npiece = 250_000_000, 10_000, 16
+    ref = pgs.synth.dna(6, n)
+    q, off = pgs.synth.read_from_ref(ref, 7, m, sub_rate=0.01, indel_rate=0.001)
+    q = q.tobytes()
+    ctx.set_reference(ref)
+    ctx.batch_upload([q])
+    ranges = pgs.capi.make_string_range(npiece, m, n, 2.0)
+    assert ranges[1][0] == ranges[0][1] - 2 * m and ranges[-1][1] == n
+    refb = ref.tobytes()
+    for sem in (0, 1):
+        whole = ctx.batch_run(semantics=sem)[0]
+        if sem == 0:
+            assert abs(whole["pos"] - (off + 1)) < 300 and whole["score"] > 20_000
+        else:
+            # 10 000 rows saturate the uint8 engine everywhere (random 10 kbp x 15 Mbp already scores ~7 700 in float): the
+            # answer is the FIRST 255 in the skewed storage order — in the corner triangle at the end of the reference,
+            # which that order visits early (SURVEY.md §0.4) — not the planted copy
+            assert whole["score"] == 255 and whole["end_x"] + whole["end_y"] > n
+        mx = ctx.score_ranges(ranges, semantics=sem)[:, 0]
+        assert mx.max() == whole["score"]
+        winner = int(np.argmax(mx))                                   # first strictly greatest (plocalaligner.cpp:125)
+        split = ctx.align_split(q, refb, npiece, 2.0, sem, sem)
+        assert split["piece"] == winner
+        if sem == 0:                                                  # (the uint8 storage order is piece-local: SURVEY App. A.6)
+            for k in ("score", "pos", "end_y", "cons_x", "cons_y"):
+                assert split[k] == whole[k], k
+        lo = whole["end_y"] - (26_000 if sem == 0 else 40_000)
+        w = oracle.trace_from(q, refb[lo:whole["end_y"]], sem, whole["end_x"], whole["end_y"] - lo)
+        assert w["score"] == whole["score"]
+        assert (w["cons_x"], w["cons_y"], w["pos"] + lo) == (whole["cons_x"], whole["cons_y"], whole["pos"])
+        mm = pgs.MultiContext([0, 0])
+        try:
+            ms = mm.align_split(q, refb, npiece, 2.0, sem, sem)
+        finally:
+            mm.close()
+        for k in ("score", "pos", "end_x", "end_y", "cons_x", "cons_y", "piece"):
+            assert ms[k] == split[k], (sem, k)

@@ -138,3 +138,18 @@ def test_lean_locate_equals_full_argmax(oracle, golden):
             continue
         got = oracle.locate(c["x"], c["y"], c["sem"], c["match"], c["mismatch"], c["gap"])
         assert got == (c["expect"]["score"], c["expect"]["end_x"], c["expect"]["end_y"]), c
+
+
+def test_trace_from_equals_reference_traceback(oracle, golden):
+    """sw_oracle_trace_from (traceback from a given start cell; the companion of the lean locate for full-size checks)
+    against the real reference's consensus / pos on every golden alignment: started at the reference's argmax it must
+    reproduce the reference's walk."""
+    n = 0
+    for c in golden["align"] + golden["kat"]:
+        e = c["expect"]
+        if e["score"] <= 0:
+            continue
+        w = oracle.trace_from(c["x"], c["y"], c["sem"], e["end_x"], e["end_y"], c["match"], c["mismatch"], c["gap"])
+        assert (w["score"], w["cons_x"], w["cons_y"], w["pos"]) == (e["score"], e["cons_x"], e["cons_y"], e["pos"]), c
+        n += 1
+    assert n > 400
