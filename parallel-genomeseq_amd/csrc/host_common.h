@@ -22,7 +22,10 @@ struct HostTrace {
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  bool view = false;              // aliases memory owned elsewhere: never freed here
+  void alias(void *ptr) { p = ptr; cap = 0; view = true; }
   int ensure(size_t bytes) {
+    if (view) return -1;
     if (bytes <= cap) return 0;
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
@@ -31,7 +34,7 @@ struct DevBuf {
     cap = want;
     return 0;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  void release() { if (p && !view) (void)hipFree(p); p = nullptr; cap = 0; view = false; }
   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
@@ -59,7 +62,8 @@ struct RefData {
   int ncodes = 0;                 // incl. pad
   int code_of[256];
   uint8_t byte_of[256];
-  void release() { bytes.release(); codes.release(); n = 0; }
+  uint64_t version = 0;           // bumped by every upload (caches keyed on the reference's content)
+  void release() { bytes.release(); codes.release(); n = 0; ++version; }
 };
 
 struct QueryBatch {
@@ -75,6 +79,65 @@ struct QueryBatch {
 };
 
 struct Range { int64_t lo, hi; };
+
+// A few persistent helper threads per context (re-hashing the caller's reference while the call already runs on the
+// resident copy): creating threads per call cost more than a short alignment.
+class Helpers {
+ public:
+  static constexpr int kThreads = 4;
+  ~Helpers() { stop(); }
+  void submit(int w, std::function<void()> job) {
+    Slot &s = slot[w];
+    start(w);
+    {
+      std::lock_guard<std::mutex> g(s.m);
+      s.job = std::move(job);
+      s.busy = true;
+    }
+    s.cv.notify_all();
+  }
+  void wait(int w) {
+    Slot &s = slot[w];
+    if (!s.th.joinable()) return;
+    std::unique_lock<std::mutex> g(s.m);
+    s.cv.wait(g, [&] { return !s.busy; });
+  }
+  void stop() {
+    for (Slot &s : slot) {
+      if (!s.th.joinable()) continue;
+      { std::lock_guard<std::mutex> g(s.m); s.quit = true; }
+      s.cv.notify_all();
+      s.th.join();
+    }
+  }
+
+ private:
+  struct Slot {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool busy = false, quit = false;
+  };
+  Slot slot[kThreads];
+  void start(int w) {
+    Slot &s = slot[w];
+    if (s.th.joinable()) return;
+    s.th = std::thread([&s] {
+      std::unique_lock<std::mutex> g(s.m);
+      for (;;) {
+        s.cv.wait(g, [&] { return s.busy || s.quit; });
+        if (s.quit) return;
+        std::function<void()> job = std::move(s.job);
+        g.unlock();
+        job();
+        g.lock();
+        s.busy = false;
+        s.cv.notify_all();
+      }
+    });
+  }
+};
 
 struct Hash128 {
   uint64_t a = 0, b = 0;
@@ -111,14 +174,14 @@ struct mi355_sw_ctx {
   bool adhoc_valid = false;
   QueryBatch one;                 // the single query of such a call
   // scratch
-  DevBuf keys, ranges, stab, ftab, ftab_s, htab, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs, scan;
+  DevBuf keys, ranges, stab, ftab, ftab_s, htab, htab8, soloblk, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs, scan;
   // host sides of small per-call uploads: they must outlive the asynchronous copies, and the tables are only
   // sent again when they change
   std::vector<int64_t> h_ranges;
   std::vector<int16_t> h_stab;
   std::vector<float> h_ftab, h_ftab_s;
   int fshift = 0;                 // float32 score instance: cells hold H * 2^-fshift in this call
-  std::vector<uint16_t> h_htab;
+  std::vector<uint16_t> h_htab, h_htab8;
   // event pairs around the score launches of a call, read back after the call's first synchronisation
   std::vector<hipEvent_t> score_ev;
   size_t score_ev_used = 0;
@@ -126,11 +189,12 @@ struct mi355_sw_ctx {
   std::vector<std::vector<char>> arenas;
   // pinned staging: problem / walk descriptors (up), small results (down), and a pool of consensus buffers that
   // live until the next call (cons_used of them are taken)
-  PinBuf pin_probs, pin_walk, pin_out;
+  PinBuf pin_probs, pin_walk, pin_out, pin_solo_up, pin_solo_down;
   std::vector<PinBuf> pin_cons;
   size_t cons_used = 0;
   double timings[6] = {0, 0, 0, 0, 0, 0};
   ViewStore view;
+  Helpers helpers;
   mi355_sw_kernel_info last_kernel = {};   // score-kernel instance that swept the most cells in the running call
 };
 
@@ -246,6 +310,7 @@ int upload_reference(mi355_sw_ctx *ctx, RefData &r, const char *y, size_t ny) {
   }
   r.ncodes = nc + 1;   // + pad
   r.n = ny;
+  ++r.version;
   if (r.bytes.ensure(ny + 64) || r.codes.ensure(ny + 64)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(reference) failed");
   std::vector<uint8_t> codes(ny);
   for (size_t k = 0; k < ny; ++k) codes[k] = (uint8_t)r.code_of[u[k]];
@@ -296,6 +361,12 @@ void parallel_for(size_t n, F fn) {
   for (auto &f : parts) f.get();
 }
 
+inline Hash128 combine_hash(Hash128 r, const Hash128 &o) {
+  r.a = (r.a ^ o.a) * 0xBF58476D1CE4E5B9ull + (r.a >> 29);
+  r.b = (r.b + o.b) * 0x94D049BB133111EBull; r.b ^= r.b >> 31;
+  return r;
+}
+
 // Hash of a whole buffer: four independent quarters (hashed on helper threads when the buffer is large), combined.
 Hash128 content_hash(const char *p, size_t n) {
   if (n < ((size_t)4 << 20)) return content_hash_part(p, n);
@@ -303,11 +374,7 @@ Hash128 content_hash(const char *p, size_t n) {
   std::future<Hash128> f[3];
   for (int k = 0; k < 3; ++k) f[k] = std::async(std::launch::async, content_hash_part, p + (size_t)(k + 1) * q, k == 2 ? n - 3 * q : q);
   Hash128 r = content_hash_part(p, q);
-  for (int k = 0; k < 3; ++k) {
-    const Hash128 o = f[k].get();
-    r.a = (r.a ^ o.a) * 0xBF58476D1CE4E5B9ull + (r.a >> 29);
-    r.b = (r.b + o.b) * 0x94D049BB133111EBull; r.b ^= r.b >> 31;
-  }
+  for (int k = 0; k < 3; ++k) r = combine_hash(r, f[k].get());
   return r;
 }
 
@@ -332,16 +399,30 @@ int adhoc_reference(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData *
   return 0;
 }
 
-// One-by-one loops against a large reference (src/sw_solve_big.cpp:78-92: a new aligner per read, same reference):
-// hashing 50 MB costs as much as aligning against it, so the call starts on the resident copy while a helper
-// thread re-hashes the caller's buffer, and is repeated on a fresh upload in the rare case the content changed.
+// One-by-one loops against one reference (src/sw_solve_big.cpp:78-92: a new aligner per read, same reference):
+// hashing the reference costs as much as aligning against it, so the call starts on the resident copy while the
+// context's helper threads re-hash the caller's buffer (four independent quarters when it is large), and is repeated
+// on a fresh upload in the rare case the content changed.
 struct AdhocSpeculation {
-  std::future<Hash128> hash;
+  Hash128 part[Helpers::kThreads];
+  int nparts = 0;
   bool active = false;
 };
 int adhoc_begin(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData **out, AdhocSpeculation &sp) {
-  if (adhoc_cache_enabled() && ctx->adhoc_valid && ctx->adhoc.n == ny && ny >= ((size_t)1 << 20)) {
-    sp.hash = std::async(std::launch::async, content_hash, y, ny);
+  if (adhoc_cache_enabled() && ctx->adhoc_valid && ctx->adhoc.n == ny && ny >= ((size_t)64 << 10)) {
+    // the same split as content_hash(): one part below 4 MB, else four quarters
+    if (ny < ((size_t)4 << 20)) {
+      sp.nparts = 1;
+      ctx->helpers.submit(0, [&sp, y, ny] { sp.part[0] = content_hash_part(y, ny); });
+    } else {
+      const size_t q = (ny / 4) & ~(size_t)31;
+      sp.nparts = 4;
+      for (int k = 0; k < 4; ++k) {
+        const char *p0 = y + (size_t)k * q;
+        const size_t len = k == 3 ? ny - 3 * q : q;
+        ctx->helpers.submit(k, [&sp, k, p0, len] { sp.part[k] = content_hash_part(p0, len); });
+      }
+    }
     sp.active = true;
     *out = &ctx->adhoc;
     return 0;
@@ -353,7 +434,9 @@ int adhoc_begin(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData **out
 bool adhoc_confirm(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData **out, AdhocSpeculation &sp, int &rc) {
   if (!sp.active) return true;
   sp.active = false;
-  const Hash128 h = sp.hash.get();
+  for (int k = 0; k < sp.nparts; ++k) ctx->helpers.wait(k);
+  Hash128 h = sp.part[0];
+  for (int k = 1; k < sp.nparts; ++k) h = combine_hash(h, sp.part[k]);
   if (h == ctx->adhoc_hash) return true;
   ctx->adhoc_valid = false;
   rc = adhoc_reference(ctx, y, ny, out, &h);

@@ -12,8 +12,9 @@ struct ScoreTable {
   int gap = 0, smax = 0;      // packed instances
   float gapf = 0, smaxf = 0;  // float32 instance
   std::vector<int16_t> stab;  // [256][ncodes]
-  std::vector<uint16_t> htab; // [256][ncodes] the same scores as float16 bits (packed float16 instances), empty when
+  std::vector<uint16_t> htab; // [256][ncodes] the same scores as float16 bits scaled by 1/2048 (kSemF16), empty when
                               // an entry does not fit (|s| <= 2048; padding -16384)
+  std::vector<uint16_t> htab8; // uint8 engine: the scores as float16 bits scaled by 1/256 (kSemU8H)
   std::vector<float> ftab;    // [256][ncodes]
   // margins for queries of up to `rows` rows: exact arithmetic for integer scores (and the uint8 engine), widened by
   // the float32 rounding slack otherwise
@@ -29,6 +30,7 @@ struct Bucket {
   int sem = kSemI16;          // kernel instance: kSemI16 / kSemU8 packed pairs, kSemF32 one query per slot
   bool strips = false;        // queries longer than one 512-row strip
   bool twin = false;          // lone long query: two tiles of it per packed register (sw_score_kernel TWIN)
+  bool unsat = false;         // uint8 engine swept by a float-engine instance WITHOUT saturation, maxima clamped at 255
   int64_t warm = 0;           // exactness margin in columns
   bool fast = false;          // swept by the score kernel (else whole-matrix exact path)
   int64_t chunk_len = 0;      // own columns per tile
@@ -92,8 +94,11 @@ ScoreTable plan_table(const RefData &ref, const mi355_sw_params &p) {
     f.gapf = (float)u.G; f.smaxf = (float)u.M;
     f.integral = true;
     // packed float16 instance (kSemU8H): cells hold (H + 1) / 256, scores are s / 256, padding -64
+    f.htab8.resize(f.stab.size());
+    for (size_t k = 0; k < f.stab.size(); ++k) f.htab8[k] = half_bits((float)f.stab[k] / 256.0f);
+    // unsaturated sweep (kSemF16 with clamped publishing, make_buckets): cells hold H / 2048
     f.htab.resize(f.stab.size());
-    for (size_t k = 0; k < f.stab.size(); ++k) f.htab[k] = half_bits((float)f.stab[k] / 256.0f);
+    for (size_t k = 0; k < f.stab.size(); ++k) f.htab[k] = half_bits((float)f.stab[k] / kF16Scale);
   } else {
     const float g = p.gap;
     if (!(g > 0.0f) || !std::isfinite(g)) { f.why = "gap penalty is not positive: no finite warm-up margin"; return f; }
@@ -159,6 +164,20 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       // the same rule in packed float16 cells scaled by 1/256 (4.25 instead of 5.5 ops per cell); values never leave
       // 0..255, so this holds for every query length
       if (b.sem == kSemU8 && std::getenv("MI355_SW_NO_F16") == nullptr) b.sem = kSemU8H;
+      // The score pass only has to deliver, per query, the maximum and the FIRST sub-chunk that reaches it.  Sweep
+      // WITHOUT saturation (the float engine's recurrence on the integer scores M, -X, G: max(0, NW + s, W - G, N - G),
+      // which is the uint8 rule while nothing exceeds 255) and clamp what is published at 255: left of the first cell
+      // that reaches 255 no saturation has happened, so both recurrences agree there and that cell holds 255 in both;
+      // the maximum is min(255, unsaturated maximum) and its first sub-chunk is the same.  Later sub-chunks may differ,
+      // but cannot change (maximum, first sub-chunk).  The cell is then the float engine's: 3.5 ops instead of 4.25
+      // (pairs, float16) or 6 (lone query, float32).  Needs the unsaturated values to stay exact: |x| * M + M <= 2040
+      // for float16 cells, < 2^24 for float32 cells.  locate and traceback keep the saturating rule.
+      if (std::getenv("MI355_SW_NO_UNSAT") == nullptr) {
+        const int64_t bound = (int64_t)t.smax * b.maxlen + t.smax;
+        if (b.sem == kSemU8H && !b.strips && b.SL != 64 && !t.htab.empty() && bound <= 2040 && t.gap <= 2040 &&
+            std::getenv("MI355_SW_NO_F16") == nullptr) { b.sem = kSemF16; b.unsat = true; }
+        else if ((b.sem == kSemF32U8 || (b.twin && b.count == 1)) && (double)t.smax * b.maxlen < 1.6e7) { b.sem = kSemF32; b.twin = false; b.unsat = true; }
+      }
     } else {
       // packed 16-bit cells when scores are small integers and the score bound fits; float32 cells otherwise
       const bool fits = t.integral && (int64_t)t.smax * std::min<int64_t>(b.maxlen, std::max<int64_t>(n, 1)) + t.smax <= 32000;
@@ -325,19 +344,11 @@ int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int S
   return cl;
 }
 
-// Uploads what every score launch of a call shares and clears the keys.
-int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range> &ranges, const ScoreTable &t) {
-  const size_t nq = q.nq, nr = ranges.size();
-  if (nr > 32768) return fail(ctx, MI355_SW_ENOTSUP, "more than 32768 ranges per launch");
-  // the previous call's copies out of these host vectors have completed: every call ends synchronised
-  std::vector<int64_t> &rl = ctx->h_ranges;
-  rl.resize(2 * nr);
-  for (size_t k = 0; k < nr; ++k) { rl[k] = ranges[k].lo; rl[nr + k] = ranges[k].hi; }
+// The score tables of a call on the device (sent again only when they change), and the scale of the float32 instance.
+int score_tables(mi355_sw_ctx *ctx, int maxlen, int64_t maxrange, const ScoreTable &t) {
   const void *stab_was = ctx->stab.p, *ftab_was = ctx->ftab.p;
-  if (ctx->ranges.ensure(rl.size() * 8) || ctx->keys.ensure(nq * nr * 8) || ctx->stab.ensure(t.stab.size() * 2) ||
-      ctx->ftab.ensure(t.ftab.size() * 4 + 16))
+  if (ctx->stab.ensure(t.stab.size() * 2) || ctx->ftab.ensure(t.ftab.size() * 4 + 16))
     return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
-  HIPCHK(ctx, hipMemcpyAsync(ctx->ranges.p, rl.data(), rl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   if (ctx->stab.p != stab_was || ctx->h_stab != t.stab) {
     ctx->h_stab = t.stab;
     HIPCHK(ctx, hipMemcpyAsync(ctx->stab.p, ctx->h_stab.data(), ctx->h_stab.size() * 2, hipMemcpyHostToDevice, ctx->stream));
@@ -348,9 +359,7 @@ int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range>
   }
   // float32 instance: table and gap scaled by 2^-k, 2^k above every value a cell of this call can take
   if (!t.ftab.empty()) {
-    int64_t maxrange = 1;
-    for (auto &r : ranges) maxrange = std::max(maxrange, r.hi - r.lo);
-    const double bound = (double)t.smaxf * (double)std::min<int64_t>(std::max(1, q.maxlen), maxrange) + (double)t.smaxf + 1.0;
+    const double bound = (double)t.smaxf * (double)std::min<int64_t>(std::max(1, maxlen), std::max<int64_t>(1, maxrange)) + (double)t.smaxf + 1.0;
     ctx->fshift = std::max(1, std::min(100, std::ilogb(bound) + 2));
     std::vector<float> scaled(t.ftab.size());
     for (size_t k = 0; k < scaled.size(); ++k) scaled[k] = std::ldexp(t.ftab[k], -ctx->fshift);
@@ -361,6 +370,14 @@ int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range>
       HIPCHK(ctx, hipMemcpyAsync(ctx->ftab_s.p, ctx->h_ftab_s.data(), ctx->h_ftab_s.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     }
   }
+  if (!t.htab8.empty()) {
+    const void *was = ctx->htab8.p;
+    if (ctx->htab8.ensure(t.htab8.size() * 2 + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
+    if (ctx->htab8.p != was || ctx->h_htab8 != t.htab8) {
+      ctx->h_htab8 = t.htab8;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->htab8.p, ctx->h_htab8.data(), ctx->h_htab8.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+    }
+  }
   if (!t.htab.empty()) {
     const void *htab_was = ctx->htab.p;
     if (ctx->htab.ensure(t.htab.size() * 2 + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
@@ -369,13 +386,36 @@ int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range>
       HIPCHK(ctx, hipMemcpyAsync(ctx->htab.p, ctx->h_htab.data(), ctx->h_htab.size() * 2, hipMemcpyHostToDevice, ctx->stream));
     }
   }
+  return 0;
+}
+
+// Uploads what every score launch of a call shares and clears the keys.
+int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range> &ranges, const ScoreTable &t) {
+  const size_t nq = q.nq, nr = ranges.size();
+  if (nr > 32768) return fail(ctx, MI355_SW_ENOTSUP, "more than 32768 ranges per launch");
+  // the previous call's copies out of these host vectors have completed: every call ends synchronised
+  std::vector<int64_t> &rl = ctx->h_ranges;
+  rl.resize(2 * nr);
+  int64_t maxrange = 1;
+  for (size_t k = 0; k < nr; ++k) { rl[k] = ranges[k].lo; rl[nr + k] = ranges[k].hi; maxrange = std::max(maxrange, ranges[k].hi - ranges[k].lo); }
+  if (ctx->ranges.ensure(rl.size() * 8) || ctx->keys.ensure(nq * nr * 8))
+    return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
+  HIPCHK(ctx, hipMemcpyAsync(ctx->ranges.p, rl.data(), rl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  int rc = score_tables(ctx, q.maxlen, maxrange, t);
+  if (rc) return rc;
   HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, nq * nr * 8, ctx->stream));
   return 0;
 }
 
+// Where a score launch finds its ranges and leaves its keys when not in the context's own buffers (host_solo.h).
+struct ScoreIO {
+  const int64_t *range_lo = nullptr, *range_hi = nullptr;
+  unsigned long long *keys = nullptr;
+};
+
 // One score-kernel launch: bucket b over all ranges.  Device time is added to ctx->timings[0].
 int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const std::vector<Range> &ranges,
-                 const mi355_sw_params &p, const ScoreTable &t, Bucket &b) {
+                 const mi355_sw_params &p, const ScoreTable &t, Bucket &b, const ScoreIO *io = nullptr) {
   HostTrace trace_("score_launch");
   const size_t nr = ranges.size();
   int64_t maxlen = 0;
@@ -396,8 +436,8 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   ScoreArgs a;
   a.refcodes = ref.codes.as<uint8_t>();
   a.ref_len = (int64_t)ref.n;
-  a.range_lo = ctx->ranges.as<int64_t>();
-  a.range_hi = ctx->ranges.as<int64_t>() + nr;
+  a.range_lo = io ? io->range_lo : ctx->ranges.as<int64_t>();
+  a.range_hi = io ? io->range_hi : ctx->ranges.as<int64_t>() + nr;
   a.chunk_len = b.chunk_len;
   a.sub_len = b.sub_len;
   a.warm = (cpr == 1) ? 0 : b.warm;              // a single tile per range starts at the range's own border
@@ -410,7 +450,7 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   a.qcount = b.count;
   a.nq = (int)q.nq;
   a.stab = b.sem == kSemF32 ? ctx->ftab_s.p
-           : (sem_is_float(b.sem) ? ctx->ftab.p : ((b.sem == kSemF16 || b.sem == kSemU8H) ? ctx->htab.p : ctx->stab.p));
+           : (sem_is_float(b.sem) ? ctx->ftab.p : (b.sem == kSemF16 ? ctx->htab.p : (b.sem == kSemU8H ? ctx->htab8.p : ctx->stab.p)));
   a.ncodes = ref.ncodes;
   if (b.sem == kSemF32) { const float gs = std::ldexp(t.gapf, -ctx->fshift); memcpy(&a.gap2, &gs, 4); }
   else if (sem_is_float(b.sem)) memcpy(&a.gap2, &t.gapf, 4);
@@ -418,7 +458,12 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   else if (b.sem == kSemU8H) a.gap2 = (uint32_t)half_bits(-(float)t.gap / 256.0f) * 0x00010001u;
   else a.gap2 = (uint32_t)t.gap * 0x00010001u;
   a.clamp2 = 255u * 0x00010001u;
-  a.keys = ctx->keys.as<unsigned long long>();
+  a.pubmax = 0u;
+  if (b.unsat) {                                  // uint8 engine swept without saturation: clamp what is published
+    if (b.sem == kSemF32) { const float v = std::ldexp(255.0f, -ctx->fshift); memcpy(&a.pubmax, &v, 4); }
+    else a.pubmax = (uint32_t)half_bits(255.0f / kF16Scale);
+  }
+  a.keys = io ? io->keys : ctx->keys.as<unsigned long long>();
 
   const int nqw = (sem_is_float(b.sem) || b.twin) ? 1 : 2;          // queries per workgroup
   // keep single launches to a few seconds: split the bucket's pairs over several launches
@@ -476,8 +521,8 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     ki.chunk_len = b.chunk_len; ki.sub_len = b.sub_len; ki.warm = a.warm; ki.cells = cells;
     ki.valu_ops_per_cell = valu_ops_per_cell(b);
     static const char *cellname[] = {"i16x2", "u8 as i16x2", "f32", "u8 as f32", "f16x2", "u8 as f16x2"};
-    std::snprintf(ki.name, sizeof ki.name, "sw_score_kernel<R=%d, %s, SL=%d%s%s>", b.R, cellname[b.sem], b.SL,
-                  b.strips ? ", strips" : "", b.twin ? ", twin" : "");
+    std::snprintf(ki.name, sizeof ki.name, "sw_score_kernel<R=%d, %s, SL=%d%s%s>%s", b.R, cellname[b.sem], b.SL,
+                  b.strips ? ", strips" : "", b.twin ? ", twin" : "", b.unsat ? " uint8 engine swept unsaturated, maxima clamped at 255" : "");
   }
   return 0;
 }

@@ -16,7 +16,11 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <future>
+#include <mutex>
+#include <thread>
 #include <memory>
 #include <cmath>
 #include <cstdio>
@@ -31,6 +35,7 @@
 #include "sw_wave_kernel.h"
 #include "sw_strip_kernel.h"
 #include "sw_batch_kernels.h"
+#include "sw_solo_kernel.h"
 
 using namespace mi355sw;
 
@@ -40,6 +45,7 @@ using namespace mi355sw;
 #include "host_wave.h"
 #include "host_batch.h"
 #include "host_pipeline.h"
+#include "host_solo.h"
 #include "host_multi.h"   // mi355_sw_multi_*: its own extern "C" block
 
 // ================================= C-ABI ======================================================
@@ -75,10 +81,10 @@ void mi355_sw_destroy(mi355_sw_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   DevBuf *bufs[] = {&c->ref.bytes, &c->ref.codes, &c->batch.bytes, &c->batch.lens, &c->keys, &c->ranges, &c->stab,
-                    &c->batch.offs, &c->batch.sel, &c->ftab, &c->ftab_s, &c->htab, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow, &c->wprobs, &c->scan, &c->batch.cum};
+                    &c->batch.offs, &c->batch.sel, &c->ftab, &c->ftab_s, &c->htab, &c->htab8, &c->soloblk, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow, &c->wprobs, &c->scan, &c->batch.cum};
   for (DevBuf *b : bufs) b->release();
   c->adhoc.release(); c->one.release();
-  c->pin_probs.release(); c->pin_walk.release(); c->pin_out.release();
+  c->pin_probs.release(); c->pin_walk.release(); c->pin_out.release(); c->pin_solo_up.release(); c->pin_solo_down.release();
   for (PinBuf &b : c->pin_cons) b.release();
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto &e : c->score_ev) (void)hipEventDestroy(e);
@@ -141,13 +147,23 @@ int mi355_sw_align(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, s
   AdhocSpeculation sp;
   memset(out, 0, sizeof *out);
   rc = adhoc_begin(ctx, y, ny, &ref, sp);
-  if (!rc) rc = upload_queries(ctx, ctx->one, 1, &x, &nx);
-  if (!rc) rc = align_range(ctx, *ref, ctx->one, Range{0, (int64_t)ny}, *params, 0, out);
+  // one short read against a long reference: the single-alignment chain (host_solo.h); everything else, or whatever
+  // that chain declines, takes the general pipeline
+  auto work = [&]() -> int {
+    int r = solo_align(ctx, *ref, x, nx, Range{0, (int64_t)ny}, *params, true, out);
+    if (r <= 0) return r;
+    reset_timings(ctx);
+    r = upload_queries(ctx, ctx->one, 1, &x, &nx);
+    if (!r) r = align_range(ctx, *ref, ctx->one, Range{0, (int64_t)ny}, *params, 0, out);
+    return r;
+  };
+  if (!rc) rc = work();
   int rc2 = 0;
   if (!adhoc_confirm(ctx, y, ny, &ref, sp, rc2)) {             // the caller's buffer changed since the last call
     mi355_sw_free_result(out);
+    reset_timings(ctx);
     rc = rc2;
-    if (!rc) rc = align_range(ctx, *ref, ctx->one, Range{0, (int64_t)ny}, *params, 0, out);
+    if (!rc) rc = work();
   }
   return rc;
 }
@@ -163,13 +179,21 @@ int mi355_sw_argmax(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, 
   const RefData *ref = nullptr;
   AdhocSpeculation sp;
   rc = adhoc_begin(ctx, y, ny, &ref, sp);
-  if (!rc) rc = upload_queries(ctx, ctx->one, 1, &x, &nx);
-  if (!rc) rc = align_range(ctx, *ref, ctx->one, Range{0, (int64_t)ny}, *params, MI355_SW_SCORE_ONLY, &r);
+  auto work = [&]() -> int {
+    int r2 = solo_align(ctx, *ref, x, nx, Range{0, (int64_t)ny}, *params, false, &r);
+    if (r2 <= 0) return r2;
+    reset_timings(ctx);
+    r2 = upload_queries(ctx, ctx->one, 1, &x, &nx);
+    if (!r2) r2 = align_range(ctx, *ref, ctx->one, Range{0, (int64_t)ny}, *params, MI355_SW_SCORE_ONLY, &r);
+    return r2;
+  };
+  if (!rc) rc = work();
   int rc2 = 0;
   if (!adhoc_confirm(ctx, y, ny, &ref, sp, rc2)) {
     mi355_sw_free_result(&r);
+    reset_timings(ctx);
     rc = rc2;
-    if (!rc) rc = align_range(ctx, *ref, ctx->one, Range{0, (int64_t)ny}, *params, MI355_SW_SCORE_ONLY, &r);
+    if (!rc) rc = work();
   }
   if (rc) return rc;
   if (index_x) *index_x = r.end_x;

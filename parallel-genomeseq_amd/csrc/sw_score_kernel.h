@@ -87,6 +87,9 @@ struct ScoreArgs {
   int ncodes;
   uint32_t gap2;             // gap penalty in both halves (packed) / float bits (kSemF32)
   uint32_t clamp2;           // 255 in both halves (U8SAT)
+  uint32_t pubmax;           // != 0: published maxima are clamped to this cell value (bit pattern of the instance's cell
+                             // type: float16 in the low half, or float32) — the uint8 engine swept WITHOUT saturation,
+                             // see host_score.h make_buckets
   unsigned long long *keys;  // [nranges][nq]  (max << 32) | (0xFFFFFFFF - sub-chunk index in the range)
   // strip-mined variant only (queries longer than 16*R rows): boundary rows between strips,
   // two ping-pong buffers of brow_stride dwords per tile, 16 dwords of front padding each
@@ -378,12 +381,14 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
       const unsigned long long tag = 0xFFFFFFFFull - (unsigned long long)(chunk * subs_per_tile + sub);
       unsigned long long *k = a.keys + (size_t)range * a.nq;
       if (sem_is_float(SEM)) {
-        if (m32 > best_a) {                                         // non-negative floats order like their bits
+        if (a.pubmax != 0u && m32 > a.pubmax) m32 = a.pubmax;       // non-negative floats order like their bits
+        if (m32 > best_a) {
           best_a = m32;
           atomicMax(k + qA, ((unsigned long long)m32 << 32) | tag);
         }
       } else {
-        const uint32_t va = m32 & 0xFFFFu, vb = m32 >> 16;
+        uint32_t va = m32 & 0xFFFFu, vb = m32 >> 16;
+        if (a.pubmax != 0u) { va = va > a.pubmax ? a.pubmax : va; vb = vb > a.pubmax ? a.pubmax : vb; }
         if (va > best_a) { best_a = va; atomicMax(k + qA, ((unsigned long long)va << 32) | tag); }
         if (hasB && vb > best_b) { best_b = vb; atomicMax(k + qB, ((unsigned long long)vb << 32) | tag); }
         if (TWIN && active2 && vb > best_b) {                        // the second tile of the same query

@@ -825,3 +825,34 @@ def test_config5_full_size_split_equals_whole(ctx, oracle, pgs):
             mm.close()
         for k in ("score", "pos", "end_x", "end_y", "cons_x", "cons_y", "piece"):
             assert ms[k] == split[k], (sem, k)
+
+
+def test_u8_unsaturated_sweep_edges(ctx, oracle, pgs):
+    """The uint8 engine's score pass runs WITHOUT saturation and clamps the published maxima at 255 (host_score.h
+    make_buckets).  Edges of that argument: maxima of exactly 252 / 255 / 258 before clamping (84, 85, 86 matches), a read
+    that saturates, decays and hits again further right (later sub-chunks differ between the two recurrences; the first
+    one decides), non-default uint8 scorings incl. mismatch penalty 0 and match 255, batches (packed float16 cells) and
+    lone calls (float32 cells), against the oracle's saturating rule."""
+    rng = np.random.default_rng(77)
+    ref = pgs.synth.dna(91, 400_000)
+    refb = bytearray(ref.tobytes())
+    reads = []
+    for k, m in enumerate((84, 85, 86, 150, 150, 300, 511)):
+        at = 10_000 + 50_000 * k
+        reads.append(bytes(refb[at:at + m]))
+    long_read = bytes(refb[200_000:200_400])                         # 400 matches: saturates early
+    refb[330_000:330_400] = long_read                                # ... and occurs again much further right
+    degraded = bytearray(long_read)
+    for i in range(90, 400, 7):                                      # saturate, decay, saturate again inside one hit
+        degraded[i] = ord("ACGT"[("ACGT".index(chr(degraded[i])) + 1) % 4])
+    reads += [long_read, bytes(degraded), pgs.synth.dna(92, 150).tobytes()]
+    refb = bytes(refb)
+    for sc in (dict(), dict(match=5.0, mismatch=-4.0, gap=3.0), dict(match=2.0, mismatch=0.0, gap=1.0),
+               dict(match=255.0, mismatch=-255.0, gap=200.0), dict(match=7.9, mismatch=-1.2, gap=1.99)):
+        exp = [oracle.align(q, refb, 1, **sc) for q in reads]
+        got = ctx.align_batch(reads, refb, semantics=1, **sc)
+        for k, (g, e) in enumerate(zip(got, exp)):
+            _cmp(g, e, ("u8 batch", sc, k))
+        for k in (0, 1, 2, 7, 8):
+            _cmp(ctx.align(reads[k], refb, 1, **sc), exp[k], ("u8 lone", sc, k))
+    assert "unsaturated" in ctx.last_kernel()["name"]
