@@ -157,6 +157,7 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
   }
   for (Bucket &b : out) {
     const bool twin_ok = b.count == 1 && b.SL == 64 && std::getenv("MI355_SW_NO_TWIN") == nullptr;
+    const bool twin16_ok = b.count == 1 && b.maxlen >= 1 && b.maxlen <= kMaxRowsFast && std::getenv("MI355_SW_NO_TWIN") == nullptr;
     if (p.semantics == MI355_SW_U8SAT) {
       // lone query: two of its tiles per packed register on whole-wavefront tiles, else one query per register
       b.twin = twin_ok;
@@ -174,8 +175,10 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       // for float16 cells, < 2^24 for float32 cells.  locate and traceback keep the saturating rule.
       if (std::getenv("MI355_SW_NO_UNSAT") == nullptr) {
         const int64_t bound = (int64_t)t.smax * b.maxlen + t.smax;
-        if (b.sem == kSemU8H && !b.strips && b.SL != 64 && !t.htab.empty() && bound <= 2040 && t.gap <= 2040 &&
-            std::getenv("MI355_SW_NO_F16") == nullptr) { b.sem = kSemF16; b.unsat = true; }
+        const bool f16_ok = !b.strips && b.SL != 64 && !t.htab.empty() && bound <= 2040 && t.gap <= 2040 &&
+                            std::getenv("MI355_SW_NO_F16") == nullptr;
+        if (b.sem == kSemU8H && f16_ok) { b.sem = kSemF16; b.unsat = true; }
+        else if (b.sem == kSemF32U8 && f16_ok && twin16_ok) { b.sem = kSemF16; b.unsat = true; b.twin = true; b.SL = 16; b.R = pick_R(b.maxlen); }
         else if ((b.sem == kSemF32U8 || (b.twin && b.count == 1)) && (double)t.smax * b.maxlen < 1.6e7) { b.sem = kSemF32; b.twin = false; b.unsat = true; }
       }
     } else {
@@ -189,7 +192,12 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       // a lone query would fill both halves of every packed register with itself: the float32 instance (one query per
       // slot, exact for integer scores below 2^24) sweeps it faster — also than two of its tiles per packed integer
       // register (config 5: 282 ms against 338 ms), which remains the uint8 engine's way (its cells are float16)
-      if (b.count == 1 && b.sem == kSemI16 && (double)t.smax * b.maxlen < 1.6e7) b.sem = kSemF32;
+      // ... except a short one with small scores: two of its TILES per packed float16 register on 16-lane tiles
+      if (b.count == 1 && b.sem == kSemI16 && twin16_ok && !t.htab.empty() && !b.strips && b.SL != 64 &&
+          (int64_t)t.smax * b.maxlen + t.smax <= 2040 && std::getenv("MI355_SW_NO_F16") == nullptr) {
+        b.sem = kSemF16; b.twin = true; b.SL = 16; b.R = pick_R(b.maxlen);
+      }
+      else if (b.count == 1 && b.sem == kSemI16 && (double)t.smax * b.maxlen < 1.6e7) b.sem = kSemF32;
       else if (b.count == 1 && b.sem == kSemI16 && twin_ok) b.twin = true;
     }
     const Margin mg = t.margin(b.maxlen);
@@ -263,6 +271,16 @@ int launch_score_twin(int R, bool strips, dim3 grid, size_t shmem, hipStream_t s
 #define CASE_T(r) case r: launch_score(sw_score_kernel<r, SEM, false, 64, true>, grid, shmem, st, a); return 0;
     CASE_T(10) CASE_T(12) CASE_T(16) CASE_T(20) CASE_T(24) CASE_T(32)
 #undef CASE_T
+  }
+  return -1;
+}
+
+// a lone short query on 16-lane tiles, two TILES of it per packed float16 register
+int launch_score_twin16(int R, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
+  switch (R) {
+#define CASE_T16(r) case r: launch_score(sw_score_kernel<r, kSemF16, false, 16, true>, grid, shmem, st, a); return 0;
+    CASE_T16(2) CASE_T16(4) CASE_T16(6) CASE_T16(8) CASE_T16(10) CASE_T16(12) CASE_T16(16) CASE_T16(20) CASE_T16(24) CASE_T16(32)
+#undef CASE_T16
   }
   return -1;
 }
@@ -496,7 +514,8 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     for (int e = 0; e < 2; ++e) { hipEvent_t ev; HIPCHK(ctx, hipEventCreate(&ev)); ctx->score_ev.push_back(ev); }
   }
   HIPCHK(ctx, hipEventRecord(ctx->score_ev[ctx->score_ev_used], ctx->stream));
-  int rc = b.twin ? (b.sem == kSemU8H ? launch_score_twin<kSemU8H>(b.R, b.strips, grid, shmem, ctx->stream, a)
+  int rc = b.twin ? (b.sem == kSemF16 ? launch_score_twin16(b.R, grid, shmem, ctx->stream, a)
+                     : b.sem == kSemU8H ? launch_score_twin<kSemU8H>(b.R, b.strips, grid, shmem, ctx->stream, a)
                      : b.sem == kSemU8 ? launch_score_twin<kSemU8>(b.R, b.strips, grid, shmem, ctx->stream, a)
                                        : launch_score_twin<kSemI16>(b.R, b.strips, grid, shmem, ctx->stream, a))
            : b.sem == kSemF16 ? launch_score_f16<kSemF16>(b.R, b.SL, grid, shmem, ctx->stream, a)

@@ -52,7 +52,7 @@ int solo_align(mi355_sw_ctx *ctx, const RefData &ref, const char *x, size_t nx, 
   const int64_t warm1 = std::min(b.warm, clamp_cols((double)nx + std::ceil(mg.smax * (double)nx / mg.g) + 3.0));
   const int64_t nbmax = sub_len + 63 + std::max(need_t, warm1);
   const int64_t cap = (int64_t)nx + nbmax + 2;
-  const size_t lds = (size_t)nbmax * 64 * DB + (((size_t)nbmax + 15) & ~(size_t)15) + 64 * (size_t)R + 2 * (size_t)cap + 64;
+  const size_t lds = ((size_t)nbmax + 1) * 64 * DB + (((size_t)nbmax + 136 + 15) & ~(size_t)15) + 64 * (size_t)R + 2 * (size_t)cap + 64;
   if (lds > kSoloLdsMax) return 1;
 
   // ---- the call block ----

@@ -204,7 +204,7 @@ template <int R, int SEM, bool STRIPS = false, int SL = 16, bool TWIN = false>
 __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   static_assert(SL == 64 || SL == 16 || SL == 8, "a slot is a whole wavefront, a DPP row or half a DPP row");
   static_assert(!(STRIPS && SL == 8), "the strip-mined instances use whole DPP rows or whole wavefronts");
-  static_assert(!TWIN || (SL == 64 && !sem_is_float(SEM) && R % 2 == 0), "twin tiles: packed cells on whole-wavefront tiles");
+  static_assert(!TWIN || ((SL == 64 || SL == 16) && !sem_is_float(SEM) && R % 2 == 0), "twin tiles: packed cells on whole-wavefront or 16-lane tiles");
   constexpr int LS = TWIN ? lane_stride(R / 2) : lane_stride(R);    // dwords between the profile rows of adjacent lanes
   constexpr int NQ4 = TWIN ? (R / 2 + 3) / 4 : (R + 3) / 4;
   constexpr int NSLOT = 256 / SL;                                  // tiles per workgroup
@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
       if (TWIN) {
         const int16_t *st = static_cast<const int16_t *>(a.stab);
         const int sa = (i < mA) ? st[(int)xA[i] * a.ncodes + c]
-                                : (SEM == kSemU8H ? (int)(int16_t)0xD400 /* float16 -64 */ : kPadScore);
+                                : (SEM == kSemU8H ? (int)(int16_t)0xD400 /* float16 -64 */
+                                   : (SEM == kSemF16 ? (int)(int16_t)0xC800 /* float16 -8 */ : kPadScore));
         reinterpret_cast<uint16_t *>(prof)[((c * PL + ll) * LS) * 2 + r] = (uint16_t)sa;
         continue;
       }
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   uint8_t *buf2 = codebuf + (NSLOT + slot) * CB;                   // TWIN: window of the second tile
   const uint8_t *buf2_lane = buf2 + HIST - ls;
   const uint32_t *prof_lane = prof + (tid & (PL - 1)) * LS;
+  uint32_t *buf2_32 = reinterpret_cast<uint32_t *>(buf2);
   auto window_put = [&](const Codes &c) {
     if (CPL >= 4) {
 #pragma unroll
@@ -327,17 +329,28 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
       buf[HIST + ls] = (uint8_t)c.w[0];
     }
   };
+  auto window_put2 = [&](const Codes &c) {                          // TWIN: the second tile's window
+    if (CPL >= 4) {
+#pragma unroll
+      for (int d = 0; d < CPL / 4; ++d) buf2_32[HIST / 4 + (CPL / 4) * ls + d] = c.w[d];
+    } else {
+      buf2[HIST + ls] = (uint8_t)c.w[0];
+    }
+  };
   // first fill: history = padding; later: the last HIST bytes of the window move to its front
   auto window_init = [&]() {
     if (SL == 64) { buf[ls] = (uint8_t)pad; if (TWIN) buf2[ls] = (uint8_t)pad; }
-    else if (ls < HIST / 4) buf32[ls] = pad4;
+    else if (ls < HIST / 4) { buf32[ls] = pad4; if (TWIN) buf2_32[ls] = pad4; }
   };
   auto window_slide = [&]() {
     if (SL == 64) {
       const uint8_t h = buf[kSeg + ls]; buf[ls] = h;
       if (TWIN) { const uint8_t h2 = buf2[kSeg + ls]; buf2[ls] = h2; }
     }
-    else { const uint32_t h = buf32[kSeg / 4 + (ls & 3)]; if (ls < HIST / 4) buf32[ls] = h; }
+    else {
+      const uint32_t h = buf32[kSeg / 4 + (ls & 3)]; if (ls < HIST / 4) buf32[ls] = h;
+      if (TWIN) { const uint32_t h2 = buf2_32[kSeg / 4 + (ls & 3)]; if (ls < HIST / 4) buf2_32[ls] = h2; }
+    }
   };
   // value of the lane above: DPP inside the row (16/8 lanes) or across the wavefront (64 lanes)
   auto shift_in = [&](uint32_t v, uint32_t border) -> uint32_t {
@@ -445,7 +458,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
     window_put(nextcodes);
     nextcodes = stage_load(1);
     if (TWIN) {
-      buf2[HIST + ls] = (uint8_t)stage_load(0, true).w[0];
+      window_put2(stage_load(0, true));
       nextcodes2 = stage_load(1, true);
     }
     uint4 nextb = make_uint4(zero_bits<SEM>(), zero_bits<SEM>(), zero_bits<SEM>(), zero_bits<SEM>());
@@ -556,7 +569,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
       window_put(nextcodes);
       nextcodes = stage_load(seg + 2);
       if (TWIN) {
-        buf2[HIST + ls] = (uint8_t)nextcodes2.w[0];
+        window_put2(nextcodes2);
         nextcodes2 = stage_load(seg + 2, true);
       }
       {

@@ -120,12 +120,15 @@ __global__ __launch_bounds__(64) void sw_solo_kernel(const SoloArgs a) {
     arrive();
     return;
   }
-  dir_t *D = reinterpret_cast<dir_t *>(lds);                          // [lds_steps][64]
-  uint8_t *win = lds + (size_t)a.lds_steps * 64 * DB;                  // [lds_steps] window bytes
-  uint8_t *xs = win + ((a.lds_steps + 15) & ~15);                      // [64 * R]
+  // LDS: decisions [lds_steps + 1][64] (the last row takes the stores of positions outside the window), the window's
+  // bytes with 64 bytes of padding in front (lane l is l positions behind lane 0) and behind, the query, the strings
+  dir_t *D = reinterpret_cast<dir_t *>(lds);
+  uint8_t *winp = lds + ((size_t)a.lds_steps + 1) * 64 * DB;           // [64 + lds_steps + 64 + 8]
+  uint8_t *win = winp + 64;
+  uint8_t *xs = winp + (((size_t)a.lds_steps + 136 + 15) & ~(size_t)15); // [64 * R]
   char *cx = reinterpret_cast<char *>(xs + 64 * R);                    // [cap], then cy [cap]
   char *cy = cx + a.cap;
-  for (int t = l; t < nb; t += 64) win[t] = a.y[wl + t];
+  for (int t = l - 64; t < nb + 72; t += 64) win[t] = (t >= 0 && t < nb) ? a.y[wl + t] : 0;
   for (int e = l; e < 64 * R; e += 64) xs[e] = e < m ? a.x[e] : 0;
   __syncthreads();
 
@@ -139,49 +142,66 @@ __global__ __launch_bounds__(64) void sw_solo_kernel(const SoloArgs a) {
   const float gpen = U8 ? a.sc.u8G : a.sc.gap;
   unsigned long long bkey = ~0ull;
   long long bi = 0, bj = 0;
+  // per-row decision codes, already shifted to the row's two bits: no shifts in the loop
+  uint32_t dNW[R], dW[R], dN[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { dNW[r] = (uint32_t)kDirNW << (2 * r); dW[r] = (uint32_t)kDirW << (2 * r); dN[r] = (uint32_t)kDirN << (2 * r); }
 
   const int steps = nb + 63;                                           // lane 63 reaches stream position nb - 1
-  for (int s = 0; s < steps; ++s) {
-    const int t = s - l;
-    const bool in = (uint32_t)t < (uint32_t)nb;
-    const uint32_t cb = in ? (uint32_t)win[t] : 0x100u;                // outside the window nothing matches
-    const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(H[R - 1]), 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
-    float diag = __uint_as_float(up_prev);
-    float north = __uint_as_float(up);
-    up_prev = up;
-    uint32_t dpack = 0;
-    bool hit = false;
+  const int groups = (steps + 3) / 4;
+  const uint8_t *wlane = win - l;                                      // + s = byte of this lane's position at step s
+  uint32_t w4;
+  __builtin_memcpy(&w4, wlane, 4);                                     // the bytes of steps 0..3 (unaligned LDS read)
+  for (int g4 = 0; g4 < groups; ++g4) {
+    uint32_t w4next;
+    __builtin_memcpy(&w4next, wlane + 4 * (g4 + 1), 4);                // one group ahead: the read's latency is hidden
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float wv = H[r];
-      const bool eq = ca[r] == cb;
-      float xv;
-      if (U8) xv = eq ? fminf(diag + a.sc.u8M, 255.0f) : fmaxf(diag - a.sc.u8X, 0.0f);
-      else xv = diag + (eq ? a.sc.match : a.sc.mismatch);
-      const float tmx = fmaxf(wv, north);
-      const float h = fmaxf(fmaxf(xv, tmx - gpen), 0.0f);
-      // smithwaterman.cpp:51,59,66,72 at this cell (n1 = NW = diag, n2 = W = wv, n3 = N = north)
-      const float lowest = fminf(fminf(diag, wv), north);
-      const uint32_t c_go = lowest != 0.0f ? 1u : 0u, c_nw = diag >= tmx ? 1u : 0u, c_w = wv >= north ? 1u : 0u;
-      const uint32_t dir = c_go * (3u - c_w - c_nw * (2u - c_w));        // 0 stop, 1 NW, 2 W, 3 N
-      dpack |= dir << (2 * r);
-      hit |= h == score;
-      diag = wv;
-      H[r] = h;
-      north = h;
-    }
-    if (in) D[(size_t)t * 64 + l] = (dir_t)dpack;
-    if (hit && in && t >= own_lo) {                                    // rare: which rows, where in the storage order
-      const long long j = wl + t + 1;
+    for (int k = 0; k < 4; ++k) {
+      const int s = 4 * g4 + k;
+      const int t = s - l;
+      const bool in = (uint32_t)t < (uint32_t)nb;
+      const uint32_t cb = in ? ((w4 >> (8 * k)) & 0xFFu) : 0x100u;     // outside the window nothing matches
+      const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(H[R - 1]), 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+      float diag = __uint_as_float(up_prev);
+      float north = __uint_as_float(up);
+      up_prev = up;
+      uint32_t dpack = 0;
+      bool hit = false;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const long long i = (long long)l * R + r + 1;
-        if (H[r] == score && i <= m) {
-          const unsigned long long k2 = U8 ? order_key<1>(i, j, m, a.n) : order_key<0>(i, j, m, a.n);
-          if (k2 < bkey) { bkey = k2; bi = i; bj = j; }
+        const float wv = H[r];
+        const bool eq = ca[r] == cb;
+        float xv;
+        if (U8) xv = eq ? fminf(diag + a.sc.u8M, 255.0f) : fmaxf(diag - a.sc.u8X, 0.0f);
+        else xv = diag + (eq ? a.sc.match : a.sc.mismatch);
+        const float tmx = fmaxf(wv, north);
+        const float h = fmaxf(fmaxf(xv, tmx - gpen), 0.0f);
+        // smithwaterman.cpp:51,59,66,72 at this cell (n1 = NW = diag, n2 = W = wv, n3 = N = north): stop when a neighbour
+        // is 0, else NW if it is >= both others, else W if it is >= N, else N
+        const float lowest = fminf(fminf(diag, wv), north);
+        uint32_t d = wv >= north ? dW[r] : dN[r];
+        d = diag >= tmx ? dNW[r] : d;
+        d = lowest != 0.0f ? d : 0u;
+        dpack |= d;
+        hit |= h == score;
+        diag = wv;
+        H[r] = h;
+        north = h;
+      }
+      D[(size_t)(in ? t : a.lds_steps) * 64 + l] = (dir_t)dpack;       // outside the window: the spare row
+      if (hit && in && t >= own_lo) {                                  // rare: which rows, where in the storage order
+        const long long j = wl + t + 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const long long i = (long long)l * R + r + 1;
+          if (H[r] == score && i <= m) {
+            const unsigned long long k2 = U8 ? order_key<1>(i, j, m, a.n) : order_key<0>(i, j, m, a.n);
+            if (k2 < bkey) { bkey = k2; bi = i; bj = j; }
+          }
         }
       }
     }
+    w4 = w4next;
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
