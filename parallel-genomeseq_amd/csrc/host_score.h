@@ -341,6 +341,17 @@ int launch_score_R(int R, int SL, bool strips, dim3 grid, size_t shmem, hipStrea
   return -1;
 }
 
+// Granularity at which a tile reports its maxima = what the locate step re-runs.  uint8 engine: >= the query length
+// (a power of two >= 256), so that the skewed storage order stays within two neighbouring sub-chunks.  Float engine,
+// lone query (the latency path): one 64-column segment — the first sub-chunk that reaches the maximum holds the first
+// maximum whatever the granularity, and a shorter sub-chunk is a shorter window to re-run.
+int64_t score_sub_len(int semantics, const Bucket &b) {
+  if (semantics == MI355_SW_F32 && b.count == 1 && !b.strips && b.SL != 64) return kSeg;
+  int64_t s = 256;
+  while (s < b.maxlen) s *= 2;
+  return s;
+}
+
 int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int SL = 16, bool twin = false, int maxlen = 0) {
   int64_t cl = 65536;
   while (cl < 8 * warm) cl *= 2;                 // long queries: keep the warm-up redundancy bounded
@@ -442,8 +453,7 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm, b.SL, b.twin, b.maxlen);
   // report maxima per sub-chunk of >= 256 columns (>= query length, so that the uint8 storage order stays
   // within two neighbouring sub-chunks): that is what locate re-runs; the strip-mined instance reports per tile
-  b.sub_len = 256;
-  while (b.sub_len < b.maxlen) b.sub_len *= 2;
+  b.sub_len = score_sub_len(p.semantics, b);
   if (b.strips) while (b.chunk_len / b.sub_len > 64) b.sub_len *= 2;      // the strip-mined instances keep <= 64 sub-chunk maxima in LDS
   if (b.sub_len > b.chunk_len || b.chunk_len % b.sub_len != 0) b.sub_len = b.chunk_len;
   const int64_t cpr = (maxlen + b.chunk_len - 1) / b.chunk_len;

@@ -44,8 +44,7 @@ int solo_align(mi355_sw_ctx *ctx, const RefData &ref, const char *x, size_t nx, 
   // the largest window any candidate can need, and what it takes in LDS
   const int R = nx <= 192 ? 3 : 5;
   const int DB = R <= 4 ? 1 : 2;
-  int64_t sub_len = 256;
-  while (sub_len < (int64_t)nx) sub_len *= 2;
+  const int64_t sub_len = score_sub_len(p.semantics, b);
   const int64_t budget = (int64_t)nx / 8 + 64;
   const int64_t lane_need = clamp_cols((double)nx + std::ceil((double)nx * mg.slope()) + 3.0);
   const int64_t need_t = want_trace ? budget + std::min(b.warm, lane_need) : 0;

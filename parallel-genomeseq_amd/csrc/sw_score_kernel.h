@@ -387,6 +387,11 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
     }
     return m32;
   };
+  // atomicMax on the query's key, skipped when the key already holds something at least as large: a lone query's
+  // tiles (tens of thousands) all aim at ONE address, and the serialised atomics cost more than the sweep's last 15 %
+  auto key_max = [&](unsigned long long *addr, unsigned long long v) {
+    if (v > __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(addr, v);
+  };
   auto publish_value = [&](int64_t sub, uint32_t m32) {
     // Only a sub-chunk that strictly beats the tile's earlier ones can become the query's (max, first
     // sub-chunk) key, so all others skip the atomic (a tile publishes O(log) times, not once per sub-chunk).
@@ -397,16 +402,16 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
         if (a.pubmax != 0u && m32 > a.pubmax) m32 = a.pubmax;       // non-negative floats order like their bits
         if (m32 > best_a) {
           best_a = m32;
-          atomicMax(k + qA, ((unsigned long long)m32 << 32) | tag);
+          key_max(k + qA, ((unsigned long long)m32 << 32) | tag);
         }
       } else {
         uint32_t va = m32 & 0xFFFFu, vb = m32 >> 16;
         if (a.pubmax != 0u) { va = va > a.pubmax ? a.pubmax : va; vb = vb > a.pubmax ? a.pubmax : vb; }
-        if (va > best_a) { best_a = va; atomicMax(k + qA, ((unsigned long long)va << 32) | tag); }
-        if (hasB && vb > best_b) { best_b = vb; atomicMax(k + qB, ((unsigned long long)vb << 32) | tag); }
+        if (va > best_a) { best_a = va; key_max(k + qA, ((unsigned long long)va << 32) | tag); }
+        if (hasB && vb > best_b) { best_b = vb; key_max(k + qB, ((unsigned long long)vb << 32) | tag); }
         if (TWIN && active2 && vb > best_b) {                        // the second tile of the same query
           best_b = vb;
-          atomicMax(k + qA, ((unsigned long long)vb << 32) | (tag - (unsigned long long)subs_per_tile));
+          key_max(k + qA, ((unsigned long long)vb << 32) | (tag - (unsigned long long)subs_per_tile));
         }
       }
     }

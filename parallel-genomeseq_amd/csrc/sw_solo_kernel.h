@@ -62,6 +62,11 @@ struct SoloArgs {
 
 constexpr int kSoloSpinLimit = 1 << 22;
 
+// max / min without the compiler's NaN canonicalisation moves (no value here is ever a NaN): one instruction each
+__device__ __forceinline__ float solo_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float solo_max3_0(float a, float b) { float r; asm("v_max3_f32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float solo_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 template <int R, bool U8>
 __global__ __launch_bounds__(64) void sw_solo_kernel(const SoloArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -172,13 +177,13 @@ __global__ __launch_bounds__(64) void sw_solo_kernel(const SoloArgs a) {
         const float wv = H[r];
         const bool eq = ca[r] == cb;
         float xv;
-        if (U8) xv = eq ? fminf(diag + a.sc.u8M, 255.0f) : fmaxf(diag - a.sc.u8X, 0.0f);
+        if (U8) xv = eq ? fminf(diag + a.sc.u8M, 255.0f) : diag - a.sc.u8X;      // (the floor at 0 is the max3 below)
         else xv = diag + (eq ? a.sc.match : a.sc.mismatch);
-        const float tmx = fmaxf(wv, north);
-        const float h = fmaxf(fmaxf(xv, tmx - gpen), 0.0f);
+        const float tmx = solo_max(wv, north);
+        const float h = solo_max3_0(xv, tmx - gpen);
         // smithwaterman.cpp:51,59,66,72 at this cell (n1 = NW = diag, n2 = W = wv, n3 = N = north): stop when a neighbour
         // is 0, else NW if it is >= both others, else W if it is >= N, else N
-        const float lowest = fminf(fminf(diag, wv), north);
+        const float lowest = solo_min3(diag, wv, north);
         uint32_t d = wv >= north ? dW[r] : dN[r];
         d = diag >= tmx ? dNW[r] : d;
         d = lowest != 0.0f ? d : 0u;
