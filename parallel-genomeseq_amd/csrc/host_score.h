@@ -165,28 +165,26 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       // the same rule in packed float16 cells scaled by 1/256 (4.25 instead of 5.5 ops per cell); values never leave
       // 0..255, so this holds for every query length
       if (b.sem == kSemU8 && std::getenv("MI355_SW_NO_F16") == nullptr) b.sem = kSemU8H;
-      // The score pass only has to deliver, per query, the maximum and the FIRST sub-chunk that reaches it.  Sweep
-      // WITHOUT saturation (the float engine's recurrence on the integer scores M, -X, G: max(0, NW + s, W - G, N - G),
-      // which is the uint8 rule while nothing exceeds 255) and clamp what is published at 255: left of the first cell
-      // that reaches 255 no saturation has happened, so both recurrences agree there and that cell holds 255 in both;
-      // the maximum is min(255, unsaturated maximum) and its first sub-chunk is the same.  Later sub-chunks may differ,
-      // but cannot change (maximum, first sub-chunk).  The cell is then the float engine's: 3.5 ops instead of 4.25
-      // (pairs, float16) or 6 (lone query, float32).  Needs the unsaturated values to stay exact: |x| * M + M <= 2040
-      // for float16 cells, < 2^24 for float32 cells.  locate and traceback keep the saturating rule.
-      if (std::getenv("MI355_SW_NO_UNSAT") == nullptr) {
-        const int64_t bound = (int64_t)t.smax * b.maxlen + t.smax;
-        const bool f16_ok = !b.strips && b.SL != 64 && !t.htab.empty() && bound <= 2040 && t.gap <= 2040 &&
-                            std::getenv("MI355_SW_NO_F16") == nullptr;
-        if (b.sem == kSemU8H && f16_ok) { b.sem = kSemF16; b.unsat = true; }
-        else if (b.sem == kSemF32U8 && f16_ok && twin16_ok) { b.sem = kSemF16; b.unsat = true; b.twin = true; b.SL = 16; b.R = pick_R(b.maxlen); }
-        else if ((b.sem == kSemF32U8 || (b.twin && b.count == 1)) && (double)t.smax * b.maxlen < 1.6e7) { b.sem = kSemF32; b.twin = false; b.unsat = true; }
+      // The score pass only has to deliver, per query, the maximum and the FIRST sub-chunk that reaches it.  Sweep with
+      // the FLOAT engine's packed float16 cell (kSemF16: max(0, NW + s, W - G, N - G) on the integer scores M, -X, G,
+      // whose clamped add saturates the diagonal term at 2048 instead of 255) and clamp what is published at 255: left of
+      // the first cell that reaches 255 neither rule has saturated, so both recurrences agree there and that cell holds
+      // >= 255 in both; the maximum is min(255, swept maximum) and its first sub-chunk is the same.  Later sub-chunks may
+      // differ, but cannot change (maximum, first sub-chunk).  Every value stays an integer <= 2048, exact in float16
+      // for ANY query length.  3.5 ops per cell pair instead of 4.25 (kSemU8H) or 6 per cell (lone query, float32).
+      // locate and traceback keep the saturating rule.
+      if (std::getenv("MI355_SW_NO_UNSAT") == nullptr && std::getenv("MI355_SW_NO_F16") == nullptr && !t.htab.empty() && t.gap <= 2040) {
+        if (b.count >= 2) { b.sem = kSemF16; b.unsat = true; b.twin = false; }
+        else if (twin16_ok && !b.strips && b.SL != 64) { b.sem = kSemF16; b.unsat = true; b.twin = true; b.SL = 16; b.R = pick_R(b.maxlen); }
+        else if (twin_ok) { b.sem = kSemF16; b.unsat = true; b.twin = true; }
       }
     } else {
       // packed 16-bit cells when scores are small integers and the score bound fits; float32 cells otherwise
       const bool fits = t.integral && (int64_t)t.smax * std::min<int64_t>(b.maxlen, std::max<int64_t>(n, 1)) + t.smax <= 32000;
       b.sem = fits ? kSemI16 : kSemF32;
       // small scores on short reads: packed float16 cells (clamped add + three-input maximum: 3.5 instead of 4.5 ops per cell)
-      if (fits && !t.htab.empty() && !b.strips && b.SL != 64 && b.count >= 2 &&   // (on 64-lane tiles it measured no faster)
+      static const bool f16_wide = std::getenv("MI355_SW_NO_F16_WIDE") == nullptr;               // A/B switch
+      if (fits && !t.htab.empty() && !b.strips && (b.SL != 64 || f16_wide) && b.count >= 2 &&
           (int64_t)t.smax * b.maxlen + t.smax <= 2040 && std::getenv("MI355_SW_NO_F16") == nullptr)
         b.sem = kSemF16;
       // a lone query would fill both halves of every packed register with itself: the float32 instance (one query per
@@ -287,12 +285,30 @@ int launch_score_twin16(int R, dim3 grid, size_t shmem, hipStream_t st, const Sc
 
 // packed float16 cells: reads whose scores stay within +-2048, 8- and 16-lane tiles
 template <int SEM>
-int launch_score_f16(int R, int SL, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
+int launch_score_f16(int R, int SL, bool strips, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
+  if (strips) {
+    if (SL == 16) { if (R != 32) return -1; launch_score(sw_score_kernel<32, SEM, true, 16>, grid, shmem, st, a); return 0; }
+    if (SL != 64) return -1;
+    switch (R) {
+#define CASE_HS(r) case r: launch_score(sw_score_kernel<r, SEM, true, 64>, grid, shmem, st, a); return 0;
+      CASE_HS(20) CASE_HS(24) CASE_HS(32)
+#undef CASE_HS
+    }
+    return -1;
+  }
   if (SL == 8) {
     switch (R) {
 #define CASE_H8(r) case r: launch_score(sw_score_kernel<r, SEM, false, 8>, grid, shmem, st, a); return 0;
       CASE_H8(7) CASE_H8(10) CASE_H8(13) CASE_H8(16) CASE_H8(19) CASE_H8(26) CASE_H8(32)
 #undef CASE_H8
+    }
+    return -1;
+  }
+  if (SL == 64) {
+    switch (R) {
+#define CASE_H64(r) case r: launch_score(sw_score_kernel<r, SEM, false, 64>, grid, shmem, st, a); return 0;
+      CASE_H64(10) CASE_H64(12) CASE_H64(16) CASE_H64(20) CASE_H64(24) CASE_H64(32)
+#undef CASE_H64
     }
     return -1;
   }
@@ -524,11 +540,12 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     for (int e = 0; e < 2; ++e) { hipEvent_t ev; HIPCHK(ctx, hipEventCreate(&ev)); ctx->score_ev.push_back(ev); }
   }
   HIPCHK(ctx, hipEventRecord(ctx->score_ev[ctx->score_ev_used], ctx->stream));
-  int rc = b.twin ? (b.sem == kSemF16 ? launch_score_twin16(b.R, grid, shmem, ctx->stream, a)
+  int rc = b.twin ? (b.sem == kSemF16 ? (b.SL == 64 ? launch_score_twin<kSemF16>(b.R, b.strips, grid, shmem, ctx->stream, a)
+                                                    : launch_score_twin16(b.R, grid, shmem, ctx->stream, a))
                      : b.sem == kSemU8H ? launch_score_twin<kSemU8H>(b.R, b.strips, grid, shmem, ctx->stream, a)
                      : b.sem == kSemU8 ? launch_score_twin<kSemU8>(b.R, b.strips, grid, shmem, ctx->stream, a)
                                        : launch_score_twin<kSemI16>(b.R, b.strips, grid, shmem, ctx->stream, a))
-           : b.sem == kSemF16 ? launch_score_f16<kSemF16>(b.R, b.SL, grid, shmem, ctx->stream, a)
+           : b.sem == kSemF16 ? launch_score_f16<kSemF16>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
            : b.sem == kSemU8H ? launch_score_R<kSemU8H>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
            : b.sem == kSemU8 ? launch_score_R<kSemU8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)
            : b.sem == kSemF32U8 ? launch_score_R<kSemF32U8>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a)

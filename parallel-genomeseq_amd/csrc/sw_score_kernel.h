@@ -32,6 +32,10 @@
 namespace mi355sw {
 
 typedef short i16x2 __attribute__((ext_vector_type(2)));
+// one 16-byte LDS read (ds_read_b128): a single vector load the compiler cannot split into ds_read2_b64 pairs — the
+// profile's lane stride is laid out for b128 lane groups, and the split form ran into bank conflicts on 56 % of its LDS
+// cycles (profiles/r02_pmc_wide_tiles.json)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kSlotLanes = 16;         // lanes of a DPP row; a tile ("slot") takes 16 or 8 of them
@@ -486,15 +490,15 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
 #pragma unroll 4
       for (int k = 0; k < kSeg; ++k) {
         const uint32_t c = buf_lane[k];
-        const uint4 *pp = reinterpret_cast<const uint4 *>(prof_lane + c * code_stride);
+        const u32x4 *pp = static_cast<const u32x4 *>(__builtin_assume_aligned(prof_lane + c * code_stride, 16));
         uint32_t p[TWIN ? R : NQ4 * 4];
         if (TWIN) {
           // 16-bit scores of this lane's rows for the two tiles' codes, merged row by row: low half = first tile
-          const uint4 *pp2 = reinterpret_cast<const uint4 *>(prof_lane + (uint32_t)buf2_lane[k] * code_stride);
+          const u32x4 *pp2 = static_cast<const u32x4 *>(__builtin_assume_aligned(prof_lane + (uint32_t)buf2_lane[k] * code_stride, 16));
           uint32_t d1[NQ4 * 4], d2[NQ4 * 4];
 #pragma unroll
           for (int q = 0; q < NQ4; ++q) {
-            const uint4 v = pp[q], u = pp2[q];
+            const u32x4 v = pp[q], u = pp2[q];
             d1[4 * q + 0] = v.x; d1[4 * q + 1] = v.y; d1[4 * q + 2] = v.z; d1[4 * q + 3] = v.w;
             d2[4 * q + 0] = u.x; d2[4 * q + 1] = u.y; d2[4 * q + 2] = u.z; d2[4 * q + 3] = u.w;
           }
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
         } else {
 #pragma unroll
           for (int q = 0; q < NQ4; ++q) {
-            const uint4 v = pp[q];
+            const u32x4 v = pp[q];
             p[4 * q + 0] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
           }
         }
