@@ -251,6 +251,30 @@ def engine_rate(pgs, ctx, D, nreads, read_len, ref_len, steps, **kw):
             "valu_ops_per_cell": ki["valu_ops_per_cell"], "steps": steps}
 
 
+def extra_read_lengths(pgs, device, ref_len):
+    """Whole-job rate at other read lengths (other tile shapes / kernel instances), both engines: 512 reads each
+    (256 at 2048 bp), 1 warm-up + 1 timed pass."""
+    ref = pgs.synth.dna(3, ref_len)
+    ctx = pgs.Context(device)
+    out = {}
+    try:
+        ctx.set_reference(ref)
+        for read_len, nreads in ((300, 512), (600, 512), (1000, 512), (2048, 256)):
+            reads, _ = pgs.synth.fast_reads_from_ref(ref, 4, nreads, read_len)
+            ctx.batch_upload([r.tobytes() for r in reads])
+            for sem, name in ((pgs.F32, "f32"), (pgs.U8SAT, "u8")):
+                ctx.batch_run(semantics=sem, raw=True)
+                t0 = time.perf_counter()
+                ctx.batch_run(semantics=sem, raw=True)
+                dt = time.perf_counter() - t0
+                ki = ctx.last_kernel()
+                out["%s_%dbp" % (name, read_len)] = {"gcups": float(nreads) * read_len * ref_len / dt * 1e-9, "reads": nreads,
+                                                     "kernel": ki["name"], "valu_ops_per_cell": ki["valu_ops_per_cell"]}
+        return out
+    finally:
+        ctx.close()
+
+
 def extra_config4(pgs, device, nseq):
     """configs[3] shape on one GPU: nseq UniProt-shaped protein sequences (first argument) against the 144-aa P02232
     query (second), identity scoring 3/-3, gap 2, float engine (src/mpi_sw_solve_uniprot.cpp:120)."""
@@ -469,6 +493,7 @@ def worker(args):
     if strong is not None and not args.no_config5:
         strong["config5"] = strong_config5(pgs, D, args, local_rank)
     if extras is not None:
+        extras["read_lengths"] = extra_read_lengths(pgs, local_rank, args.ref_len)
         extras["one_by_one_calls"] = extra_latency(pgs, local_rank)
         extras["config4_uniprot_shape"] = extra_config4(pgs, local_rank, args.c4_sequences)
         if not args.no_config5:

@@ -349,8 +349,12 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         for (size_t t = 0; t < n; ++t) { offs[t] = (int64_t)at; at += 2 * (size_t)wp[t].cap; }
         if (ctx->cons.ensure(captot + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(consensus) failed");
         HIPCHK(ctx, hipMemcpyAsync(woffs, offs, n * 8, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(sw_wave_walk_kernel<kWalkBoth>, dim3(wblocks), dim3(64), 0, ctx->stream, ctx->walkp.as<WaveWalk>(), (int)n,
-                           ctx->cons.as<char>(), (const int64_t *)woffs);
+        if (strips && orient == 0)     // a few long walks: one wavefront each, looking ahead along the diagonal
+          hipLaunchKernelGGL(sw_wave_walk_long_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const WaveWalk *)ctx->walkp.as<WaveWalk>(), (int)n,
+                             ctx->cons.as<char>(), (const int64_t *)woffs);
+        else
+          hipLaunchKernelGGL(sw_wave_walk_kernel<kWalkBoth>, dim3(wblocks), dim3(64), 0, ctx->stream, ctx->walkp.as<WaveWalk>(), (int)n,
+                             ctx->cons.as<char>(), (const int64_t *)woffs);
         HIPCHK(ctx, hipGetLastError());
         if (cons.ensure(captot + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipHostMalloc(consensus) failed");
         HIPCHK(ctx, hipMemcpyAsync(wo, wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));

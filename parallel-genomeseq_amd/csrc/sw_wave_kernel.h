@@ -310,4 +310,67 @@ __global__ void sw_wave_walk_kernel(const WaveWalk *probs, int n, char *cons, co
   W.out[0] = len; W.out[1] = pos; W.out[2] = status;
 }
 
+// The same walk for a FEW LONG alignments (one 10 kbp query: ~10 000 dependent decision reads, each a cache miss, at
+// ~1.3 us per step on one thread): one wavefront per walk.  Lane p reads the decision p steps ahead ALONG THE NW
+// DIAGONAL (where a walk spends ~99 % of its steps); the leading run of NW decisions is consumed at once, the first other
+// decision (W, N, stop, or a cell outside the exact zone) is applied, and the lanes look ahead again from there.
+// Results as sw_wave_walk_kernel<kWalkBoth>.  ORIENT 0 only (lanes of the decision kernel = rows of x).
+__global__ __launch_bounds__(64) void sw_wave_walk_long_kernel(const WaveWalk *probs, int n, char *cons, const int64_t *offs) {
+  const int w = blockIdx.x;
+  if (w >= n) return;
+  const WaveWalk W = probs[w];
+  const int p = threadIdx.x;
+  char *cons_x = cons + offs[w];
+  char *cons_y = cons_x + W.cap;
+  long long ix = W.start_i, iy = W.start_j;
+  long long len = 0, pos = 0, status = 0;
+  if (ix <= 0 || iy <= 0) { if (p == 0) { W.out[0] = 0; W.out[1] = 0; W.out[2] = 0; } return; }
+  const int wd = (W.R + 15) / 16;
+  for (;;) {
+    const long long cx = ix - p, cy = iy - p;                        // this lane's cell, p NW steps ahead
+    int code;                                                          // 0 stop, 1 NW, 2 W, 3 N, 4 window, 5 capacity, 6 beyond the border
+    if (cx < 1 || cy < 1) code = 6;
+    else {
+      const long long t = cy - W.b_offset - 1;
+      bool inwin = !(t < 0 || t >= W.nb || cx > W.na);
+      if (inwin && W.exact_from > 0) {
+        long long need = W.exact_from;
+        if (W.need_slope > 0.0f) {
+          const long long rn = W.b_offset + cx + (long long)ceilf((float)cx * W.need_slope) + 2;
+          need = rn < need ? rn : need;
+        }
+        if (cy - 1 < need) inwin = false;
+      }
+      if (!inwin) code = 4;
+      else if (len + p >= W.cap) code = 5;
+      else {
+        const int lane = (int)((cx - 1) / W.R), r = (int)((cx - 1) % W.R);
+        code = (int)((W.dirs[((size_t)t * (size_t)W.lanes + (size_t)lane) * wd + (r >> 4)] >> (2 * (r & 15))) & 3u);
+      }
+    }
+    const unsigned long long other = __ballot(code != kDirNW);
+    const int run = other ? __builtin_ctzll(other) : 64;
+    if (p < run) { cons_x[len + p] = (char)W.x[cx - 1]; cons_y[len + p] = (char)W.y[cy - 1]; }
+    if (run == 64) { ix -= 64; iy -= 64; len += 64; continue; }
+    const int ev = __shfl(code, run);
+    const long long ex = ix - run, ey = iy - run, elen = len + run;
+    if (ev == kDirStop) {
+      if (p == 0) { cons_x[elen] = (char)W.x[ex - 1]; cons_y[elen] = (char)W.y[ey - 1]; }
+      len = elen + 1; pos = ey;
+      break;
+    } else if (ev == kDirW) {
+      if (p == 0) { cons_x[elen] = '-'; cons_y[elen] = (char)W.y[ey - 1]; }
+      len = elen + 1; ix = ex; iy = ey - 1;
+    } else if (ev == kDirN) {
+      if (p == 0) { cons_x[elen] = (char)W.x[ex - 1]; cons_y[elen] = '-'; }
+      len = elen + 1; ix = ex - 1; iy = ey;
+    } else {
+      len = elen;
+      status = ev == 5 ? 2 : 1;
+      break;
+    }
+  }
+  if (p == 0) { W.out[0] = len; W.out[1] = pos; W.out[2] = status; }
+}
+
 }  // namespace mi355sw
