@@ -185,7 +185,7 @@ typedef struct {
   int64_t warm;             /* warm-up columns in front of a tile */
   double cells;             /* cells this instance swept in the call */
   double valu_ops_per_cell; /* VALU instructions per cell and lane of the inner loop (cost model) */
-  char name[96];            /* e.g. "sw_score_kernel<R=19, f16x2, SL=8>" */
+  char name[160];           /* e.g. "sw_score_kernel<R=19, f16x2, SL=8>" */
 } mi355_sw_kernel_info;
 int mi355_sw_last_kernel(const mi355_sw_ctx *ctx, mi355_sw_kernel_info *out);
 

@@ -44,7 +44,7 @@ class BatchView(C.Structure):
 class KernelInfo(C.Structure):
     _fields_ = [("cell", C.c_int), ("lanes", C.c_int), ("rows_per_lane", C.c_int), ("strips", C.c_int), ("twin", C.c_int),
                 ("chunk_len", C.c_int64), ("sub_len", C.c_int64), ("warm", C.c_int64), ("cells", C.c_double),
-                ("valu_ops_per_cell", C.c_double), ("name", C.c_char * 96)]
+                ("valu_ops_per_cell", C.c_double), ("name", C.c_char * 160)]
 
 
 CELL_NAMES = {0: "i16", 1: "u8", 2: "f32", 3: "u8", 4: "f16", 5: "u8"}      # arithmetic type of the cells ("dtype" of bench.py)
