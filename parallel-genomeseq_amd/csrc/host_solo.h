@@ -10,23 +10,32 @@ namespace {
 
 constexpr int kSoloMaxRows = 320;                 // 64 lanes x R in {3, 5}
 constexpr size_t kSoloLdsMax = 150 * 1024;
-constexpr size_t kSoloQueryOff = 64, kSoloResultOff = 448, kSoloConsOff = 512;
+constexpr int kSoloMaxRanges = 64;                // pieces of one call (OMPParallelLocalAligner: sw_solve_small uses 17, sw_solve_big 2 x cores)
+// the call block: header, query, range starts / ends, keys, result header, consensus strings
+constexpr size_t kSoloQueryOff = 64, kSoloLoOff = 448, kSoloHiOff = kSoloLoOff + 8 * kSoloMaxRanges,
+                 kSoloKeyOff = kSoloHiOff + 8 * kSoloMaxRanges, kSoloResultOff = kSoloKeyOff + 8 * kSoloMaxRanges,
+                 kSoloConsOff = kSoloResultOff + 64;
 
 struct SoloBlock {                                // first 64 bytes of the call block
   int64_t qoff;
   int32_t qlen, qsel;
-  int64_t range_lo, range_hi;
-  unsigned long long key, gmin;
-  uint32_t done, pad[3];
+  unsigned long long gmin;
+  uint32_t done, pad[9];
 };
 static_assert(sizeof(SoloBlock) == 64, "layout of the call block");
 
+// The query against every range of `ranges` (one range: SWAligner; the pieces of _make_string_range:
+// OMPParallelLocalAligner with default scoring, where the per-piece maxima of plocalaligner.cpp:110-129 and the winner's
+// re-alignment :132-141 are the same sweep): the FIRST range with the strictly greatest maximum is located and traced;
+// pos / end_y are relative to that range, *piece says which.
 // returns 1: not applicable / the kernel declined (continue on the general path); 0: *out filled; < 0: error
-int solo_align(mi355_sw_ctx *ctx, const RefData &ref, const char *x, size_t nx, const Range &rg, const mi355_sw_params &p,
-               bool want_trace, mi355_sw_result *out) {
+int solo_align(mi355_sw_ctx *ctx, const RefData &ref, const char *x, size_t nx, const std::vector<Range> &ranges,
+               const mi355_sw_params &p, bool want_trace, mi355_sw_result *out, int *piece = nullptr) {
   static const bool off = std::getenv("MI355_SW_NO_SOLO") != nullptr;
-  const int64_t n = rg.hi - rg.lo;
-  if (off || nx < 1 || nx > (size_t)kSoloMaxRows || n < 1024 || !wave_scoring_ok(p)) return 1;
+  if (off || nx < 1 || nx > (size_t)kSoloMaxRows || ranges.empty() || ranges.size() > (size_t)kSoloMaxRanges || !wave_scoring_ok(p)) return 1;
+  int64_t n = 0, nmin = INT64_MAX;                 // longest / shortest range
+  for (const Range &r : ranges) { n = std::max(n, r.hi - r.lo); nmin = std::min(nmin, r.hi - r.lo); }
+  if (nmin < 1024) return 1;
   HostTrace trace_("solo_align");
   const bool u8 = p.semantics == MI355_SW_U8SAT;
   const ScoreTable table = plan_table(ref, p);
@@ -36,7 +45,7 @@ int solo_align(mi355_sw_ctx *ctx, const RefData &ref, const char *x, size_t nx, 
   std::vector<Bucket> buckets = make_buckets(ref, qv, table, p, n);
   if (buckets.size() != 1) return 1;
   Bucket &b = buckets[0];
-  if (!bucket_fast_ok(ref, table, b, n, p)) return 1;
+  for (const Range &r : ranges) if (!bucket_fast_ok(ref, table, b, r.hi - r.lo, p)) return 1;
   const int keykind = b.sem == kSemF16 ? 2 : (b.sem == kSemF32 ? 4 : 0);
   if (keykind == 0) return 1;
   const Margin mg = table.margin((double)nx);
@@ -55,6 +64,7 @@ int solo_align(mi355_sw_ctx *ctx, const RefData &ref, const char *x, size_t nx, 
   if (lds > kSoloLdsMax) return 1;
 
   // ---- the call block ----
+  static_assert(kSoloMaxRows + kSoloQueryOff <= kSoloLoOff, "layout of the call block");
   const size_t down_bytes = (kSoloConsOff - kSoloResultOff) + 2 * (size_t)cap;
   if (ctx->soloblk.ensure(kSoloConsOff + 2 * (size_t)cap + 64) || ctx->pin_solo_up.ensure(kSoloConsOff) ||
       ctx->pin_solo_down.ensure(down_bytes + 64))
@@ -63,8 +73,12 @@ int solo_align(mi355_sw_ctx *ctx, const RefData &ref, const char *x, size_t nx, 
   memset(up, 0, kSoloConsOff);
   SoloBlock *blk = reinterpret_cast<SoloBlock *>(up);
   blk->qoff = 0; blk->qlen = (int32_t)nx; blk->qsel = 0;
-  blk->range_lo = rg.lo; blk->range_hi = rg.hi;
-  blk->key = 0; blk->gmin = ~0ull; blk->done = 0;
+  blk->gmin = ~0ull; blk->done = 0;
+  const size_t nr = ranges.size();
+  for (size_t k = 0; k < nr; ++k) {
+    reinterpret_cast<int64_t *>(up + kSoloLoOff)[k] = ranges[k].lo;
+    reinterpret_cast<int64_t *>(up + kSoloHiOff)[k] = ranges[k].hi;
+  }
   memcpy(up + kSoloQueryOff, x, nx);
   uint8_t *dev = ctx->soloblk.as<uint8_t>();
   HIPCHK(ctx, hipMemcpyAsync(dev, up, kSoloConsOff, hipMemcpyHostToDevice, ctx->stream));
@@ -75,21 +89,21 @@ int solo_align(mi355_sw_ctx *ctx, const RefData &ref, const char *x, size_t nx, 
   qv.lens.alias(dev + offsetof(SoloBlock, qlen));
   qv.sel.alias(dev + offsetof(SoloBlock, qsel));
   ScoreIO io;
-  io.range_lo = reinterpret_cast<const int64_t *>(dev + offsetof(SoloBlock, range_lo));
-  io.range_hi = reinterpret_cast<const int64_t *>(dev + offsetof(SoloBlock, range_hi));
-  io.keys = reinterpret_cast<unsigned long long *>(dev + offsetof(SoloBlock, key));
+  io.range_lo = reinterpret_cast<const int64_t *>(dev + kSoloLoOff);
+  io.range_hi = reinterpret_cast<const int64_t *>(dev + kSoloHiOff);
+  io.keys = reinterpret_cast<unsigned long long *>(dev + kSoloKeyOff);
   HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-  const std::vector<Range> ranges{rg};
   rc = score_launch(ctx, ref, qv, ranges, p, table, b, &io);
   if (rc) return rc;
   if (b.sub_len != sub_len) return fail(ctx, MI355_SW_ENODEV, "internal: sub-chunk granularity of the single-alignment path");
 
   SoloArgs a;
   a.key = io.keys;
+  a.range_lo = io.range_lo; a.range_hi = io.range_hi; a.nranges = (int32_t)nr;
   a.gmin = reinterpret_cast<unsigned long long *>(dev + offsetof(SoloBlock, gmin));
   a.done = reinterpret_cast<unsigned int *>(dev + offsetof(SoloBlock, done));
   a.x = dev + kSoloQueryOff; a.m = (int32_t)nx;
-  a.y = ref.bytes.as<uint8_t>() + rg.lo; a.n = n;
+  a.yref = ref.bytes.as<uint8_t>();
   a.sub_len = sub_len;
   a.keykind = keykind; a.fshift = ctx->fshift;
   a.mg_smax = (float)mg.smax; a.mg_g = (float)mg.g;
@@ -136,6 +150,7 @@ int solo_align(mi355_sw_ctx *ctx, const RefData &ref, const char *x, size_t nx, 
   t.cy = t.cx + cap;
   t.pos = (uint32_t)r->pos;
   set_result(*out, r->score, r->ix, r->iy, (want_trace && r->score > 0) ? &t : nullptr);
+  if (piece) *piece = r->piece;
   out->timings_us[0] = (float)(ctx->timings[0] > 0 ? ctx->timings[0] : ctx->timings[3]);
   out->timings_us[1] = 0;
   return 0;

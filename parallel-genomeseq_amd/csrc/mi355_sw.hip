@@ -150,7 +150,7 @@ int mi355_sw_align(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, s
   // one short read against a long reference: the single-alignment chain (host_solo.h); everything else, or whatever
   // that chain declines, takes the general pipeline
   auto work = [&]() -> int {
-    int r = solo_align(ctx, *ref, x, nx, Range{0, (int64_t)ny}, *params, true, out);
+    int r = solo_align(ctx, *ref, x, nx, std::vector<Range>{Range{0, (int64_t)ny}}, *params, true, out);
     if (r <= 0) return r;
     reset_timings(ctx);
     r = upload_queries(ctx, ctx->one, 1, &x, &nx);
@@ -180,7 +180,7 @@ int mi355_sw_argmax(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, 
   AdhocSpeculation sp;
   rc = adhoc_begin(ctx, y, ny, &ref, sp);
   auto work = [&]() -> int {
-    int r2 = solo_align(ctx, *ref, x, nx, Range{0, (int64_t)ny}, *params, false, &r);
+    int r2 = solo_align(ctx, *ref, x, nx, std::vector<Range>{Range{0, (int64_t)ny}}, *params, false, &r);
     if (r2 <= 0) return r2;
     reset_timings(ctx);
     r2 = upload_queries(ctx, ctx->one, 1, &x, &nx);
@@ -240,15 +240,31 @@ int mi355_sw_align_split(mi355_sw_ctx *ctx, const char *x, size_t nx, const char
   memset(out, 0, sizeof *out);
   rc = adhoc_begin(ctx, y, ny, &refp, sp);
   QueryBatch &q = ctx->one;
-  if (!rc) rc = upload_queries(ctx, q, 1, &x, &nx);
   int bp = 0;
+  // default scoring in both roles (what sw_solve_small.cpp:82 / sw_solve_big.cpp:78 construct): the per-piece maxima and
+  // the winner's re-alignment are the same sweep -> the single-alignment chain over all pieces (host_solo.h)
+  const bool same_sweep = params->lut == nullptr && params->match == 3.0f && params->mismatch == -3.0f && params->gap == 2.0f &&
+                          sm_semantics == la_semantics;
   auto work = [&]() -> int {
     mi355_sw_params ps = *params;
     ps.semantics = sm_semantics;
     std::vector<Range> ranges(npiece);
     for (int k = 0; k < npiece; ++k) ranges[k] = Range{lefts[k], rights[k]};
+    if (same_sweep) {
+      int r = solo_align(ctx, *refp, x, nx, ranges, ps, true, out, &bp);
+      if (r < 0) return r;
+      if (r == 0) {
+        if (out->score > 0) { out->pos += (uint32_t)lefts[bp]; out->end_y += lefts[bp]; }
+        else out->pos = (uint32_t)lefts[bp];
+        out->timings_us[1] = out->timings_us[0];
+        return 0;
+      }
+      reset_timings(ctx);
+    }
+    int r = upload_queries(ctx, q, 1, &x, &nx);
+    if (r) return r;
     std::vector<float> pmax(npiece, 0.0f);
-    int r = range_maxima(ctx, *refp, q, ranges, ps, pmax.data());
+    r = range_maxima(ctx, *refp, q, ranges, ps, pmax.data());
     if (r) return r;
     float best = -1.0f;                                  // plocalaligner.cpp:106,122-129
     bp = 0;

@@ -34,18 +34,21 @@ struct SoloResult {            // header of the result block (device; zeroed by 
   int64_t ix, iy;              // argmax row, argmax column (1-based, relative to the range)
   int64_t len, pos;            // consensus length, position where the walk stopped (relative to the range)
   int32_t written;             // 1 when the block was filled by this launch
-  int32_t pad[5];
+  int32_t piece;               // which range held the maximum (0 for a single range)
+  int32_t pad[4];
 };
 static_assert(sizeof(SoloResult) == 64, "the strings start at +64");
 
 struct SoloArgs {
-  const unsigned long long *key;   // the query's key of this call's score pass
+  const unsigned long long *key;   // [nranges] the query's keys of this call's score pass, one per range
+  const int64_t *range_lo;         // [nranges] the ranges (pieces of the reference, plocalaligner.cpp:44-67) the score pass swept;
+  const int64_t *range_hi;         //           the FIRST one with the strictly greatest maximum is located and traced (:122-129)
+  int32_t nranges;
   unsigned long long *gmin;        // smallest storage-order key over the workgroups (~0 at launch)
   unsigned int *done;              // workgroups that have finished their sweep (0 at launch)
   const uint8_t *x;                // query bytes (device)
   int32_t m;
-  const uint8_t *y;                // first byte of the range
-  int64_t n;                       // columns of the range
+  const uint8_t *yref;             // first byte of the resident reference (ranges index it)
   int64_t sub_len;                 // granularity of the key's tag
   int32_t keykind;                 // 2: float16 bits of H / 2048; 4: float32 bits of H * 2^-fshift
   int32_t fshift;
@@ -76,8 +79,15 @@ __global__ __launch_bounds__(64) void sw_solo_kernel(const SoloArgs a) {
   const int c = blockIdx.x;
   char *cons_out = reinterpret_cast<char *>(a.out) + sizeof(SoloResult);
 
-  // ---- the key of the score pass ----------------------------------------------------------------------------------
-  const unsigned long long key = __hip_atomic_load(a.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- the key(s) of the score pass: first range with the strictly greatest maximum -----------------------------------
+  int piece = 0;
+  unsigned long long key = __hip_atomic_load(a.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int pc = 1; pc < a.nranges; ++pc) {
+    const unsigned long long k2 = __hip_atomic_load(a.key + pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((k2 >> 32) > (key >> 32)) { key = k2; piece = pc; }        // non-negative scores order like their bits
+  }
+  const uint8_t *ybase = a.yref + a.range_lo[piece];
+  const int64_t n = a.range_hi[piece] - a.range_lo[piece];
   float score;
   {
     const uint32_t hi = (uint32_t)(key >> 32);
@@ -87,11 +97,12 @@ __global__ __launch_bounds__(64) void sw_solo_kernel(const SoloArgs a) {
   if (!(score > 0.0f)) {                                // all-zero matrix: the defined no-match result
     if (c == 0 && l == 0) {
       a.out->score = 0.0f; a.out->status = kSoloOk; a.out->ix = 0; a.out->iy = 0; a.out->len = 0; a.out->pos = 0;
+      a.out->piece = piece;
       a.out->written = 1;
     }
     return;
   }
-  const int64_t nsub = (a.n + a.sub_len - 1) / a.sub_len;
+  const int64_t nsub = (n + a.sub_len - 1) / a.sub_len;
   const int64_t first = (int64_t)(0xFFFFFFFFull - (key & 0xFFFFFFFFull));
   // candidate sub-chunks, in the order of host_pipeline.h locate_fast; duplicates and out-of-range ones drop out
   int64_t mine = -1;
@@ -112,7 +123,7 @@ __global__ __launch_bounds__(64) void sw_solo_kernel(const SoloArgs a) {
   const int m = a.m;
   const float slope = a.mg_smax / a.mg_g;
   const int64_t sub_lo = max((int64_t)0, mine * a.sub_len - 63);
-  const int64_t sub_hi = min((mine + 1) * a.sub_len, a.n);
+  const int64_t sub_hi = min((mine + 1) * a.sub_len, n);
   const float spare = fmaxf(0.0f, a.mg_smax * (float)m - score);
   // (one column more than the host's double-precision forms of the same margins: these are evaluated in float)
   const int64_t warm1 = min(a.warm, (int64_t)m + (int64_t)ceilf(spare / a.mg_g) + 3);
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(64) void sw_solo_kernel(const SoloArgs a) {
   uint8_t *xs = winp + (((size_t)a.lds_steps + 136 + 15) & ~(size_t)15); // [64 * R]
   char *cx = reinterpret_cast<char *>(xs + 64 * R);                    // [cap], then cy [cap]
   char *cy = cx + a.cap;
-  for (int t = l - 64; t < nb + 72; t += 64) win[t] = (t >= 0 && t < nb) ? a.y[wl + t] : 0;
+  for (int t = l - 64; t < nb + 72; t += 64) win[t] = (t >= 0 && t < nb) ? ybase[wl + t] : 0;
   for (int e = l; e < 64 * R; e += 64) xs[e] = e < m ? a.x[e] : 0;
   __syncthreads();
 
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(64) void sw_solo_kernel(const SoloArgs a) {
         for (int r = 0; r < R; ++r) {
           const long long i = (long long)l * R + r + 1;
           if (H[r] == score && i <= m) {
-            const unsigned long long k2 = U8 ? order_key<1>(i, j, m, a.n) : order_key<0>(i, j, m, a.n);
+            const unsigned long long k2 = U8 ? order_key<1>(i, j, m, n) : order_key<0>(i, j, m, n);
             if (k2 < bkey) { bkey = k2; bi = i; bj = j; }
           }
         }
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(64) void sw_solo_kernel(const SoloArgs a) {
   }
   const unsigned long long g = __hip_atomic_load(a.gmin, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
   if (g == ~0ull) {                                                    // nobody found the maximum again
-    if (c == 0) { a.out->status = kSoloLost; a.out->written = 1; }
+    if (c == 0) { a.out->status = kSoloLost; a.out->piece = piece; a.out->written = 1; }
     return;
   }
   if (bkey != g) return;
@@ -267,6 +278,7 @@ __global__ __launch_bounds__(64) void sw_solo_kernel(const SoloArgs a) {
     }
   }
   a.out->score = score;
+  a.out->piece = piece;
   a.out->ix = bi; a.out->iy = bj;
   a.out->len = len; a.out->pos = pos;
   atomicMax(reinterpret_cast<unsigned int *>(&a.out->status), (unsigned int)status);

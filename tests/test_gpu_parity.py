@@ -856,3 +856,27 @@ def test_u8_unsaturated_sweep_edges(ctx, oracle, pgs):
         for k in (0, 1, 2, 7, 8):
             _cmp(ctx.align(reads[k], refb, 1, **sc), exp[k], ("u8 lone", sc, k))
     assert "unsaturated" in ctx.last_kernel()["name"]
+
+
+def test_split_calls_on_the_single_alignment_chain(ctx, oracle, pgs):
+    """OMPParallelLocalAligner with default scoring (what src/sw_solve_small.cpp:82 / sw_solve_big.cpp:78 construct) runs
+    score kernel + solo kernel over ALL pieces in one chain (host_solo.h): the first piece with the strictly greatest
+    maximum wins (plocalaligner.cpp:122-129) — equal hits in different pieces, 2 .. 64 pieces, both engines, reads that
+    straddle a cut, a read with no good hit — against the oracle's serial split aligner."""
+    ref = bytearray(pgs.synth.dna(95, 300_000).tobytes())
+    q = bytes(ref[40_000:40_150])
+    ref[220_000:220_150] = q                                         # the same hit again in a later piece
+    refb = bytes(ref)
+    refa = np.frombuffer(refb, dtype=np.uint8)
+    reads = [q, pgs.synth.read_from_ref(refa, 96, 150)[0].tobytes(), pgs.synth.read_from_ref(refa, 97, 300)[0].tobytes(),
+             pgs.synth.dna(98, 120).tobytes()]
+    for npiece in (2, 7, 16, 64):
+        ranges = oracle.make_string_range(npiece, 150, len(refb), 2.0)
+        reads.append(refb[ranges[1][0] - 60:ranges[1][0] + 90])      # straddles the left edge of piece 1 (inside the overlap)
+        for sem in (0, 1):
+            for x in reads:
+                got = ctx.align_split(x, refb, npiece, 2.0, sem, sem)
+                exp = oracle.align_split(x, refb, npiece, 2.0, sem, sem)
+                _cmp(got, exp, ("split", npiece, sem, len(x)))
+                assert got["piece"] == exp["piece"]
+        reads.pop()
