@@ -124,15 +124,37 @@ def align_split_sharded(ranges, piece_maxima_fn, final_align_fn):
         key = int(t.item())
     _, piece = unpack_key(key)
     owner = piece % size
-    obj = [None]
+    res = None
     if rank == owner:
-        r = dict(final_align_fn(piece))
+        res = dict(final_align_fn(piece))
         left = ranges[piece][0]
-        r["pos"] = r["pos"] + left
-        if r.get("end_y", 0) > 0:
-            r["end_y"] = r["end_y"] + left
-        r["piece"] = piece
-        obj[0] = r
+        res["pos"] = res["pos"] + left
+        if res.get("end_y", 0) > 0:
+            res["end_y"] = res["end_y"] + left
+        res["piece"] = piece
     if size > 1:
-        dist.broadcast_object_list(obj, src=owner)
-    return obj[0], piece
+        res = _broadcast_result(res, owner)
+    return res, piece
+
+
+def _broadcast_result(res, src):
+    """The owner's result to every rank as two tensor broadcasts (a fixed 6-word header, then the consensus bytes) —
+    no pickling, and on RCCL the payload goes GPU to GPU."""
+    dev = _dev()
+    head = torch.zeros(6, dtype=torch.int64, device=dev)
+    if res is not None:
+        cx, cy = res["cons_x"].encode("latin-1"), res["cons_y"].encode("latin-1")
+        head = torch.tensor([int(np.float32(res["score"]).view(np.uint32)), res["pos"], res.get("end_x", 0), res.get("end_y", 0),
+                             len(cx), res["piece"]], dtype=torch.int64, device=dev)
+    dist.broadcast(head, src=src)
+    h = head.cpu().tolist()
+    n = int(h[4])
+    body = torch.zeros(max(1, 2 * n), dtype=torch.uint8, device=dev)
+    if res is not None and n:
+        body = torch.frombuffer(bytearray(cx + cy), dtype=torch.uint8).to(dev)
+    dist.broadcast(body, src=src)
+    if res is not None:
+        return res
+    b = bytes(body.cpu().numpy().tobytes())
+    return dict(score=float(np.uint32(h[0]).view(np.float32)), pos=int(h[1]), end_x=int(h[2]), end_y=int(h[3]),
+                cons_x=b[:n].decode("latin-1"), cons_y=b[n:2 * n].decode("latin-1"), piece=int(h[5]))
