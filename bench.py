@@ -362,6 +362,12 @@ def extra_latency(pgs, device):
                 tm = ctx.last_timings()
                 out["%s_150bp_x_%dMbp" % (name, n // 1_000_000)] = {"ms_per_align": dt * 1e3, "score_kernel_ms": tm["score_us"] * 1e-3,
                                                                    "gcups": 150.0 * n / dt * 1e-9}
+                # the same read through OMPParallelLocalAligner as the reference's drivers construct it (sw_solve_big.cpp:78)
+                ctx.align_split(reads[0], ref, 16, 2.0, sem, sem)
+                t0 = time.perf_counter()
+                for k in range(32):
+                    ctx.align_split(reads[k % 8], ref, 16, 2.0, sem, sem)
+                out["%s_150bp_x_%dMbp_split16" % (name, n // 1_000_000)] = {"ms_per_align": (time.perf_counter() - t0) / 32 * 1e3}
         return out
     finally:
         ctx.close()

@@ -264,6 +264,7 @@ int mi355_sw_multi_align_batch(mi355_sw_multi *m, size_t n, const char *const *x
   if ((n && (!xs || !nxs || !outs))) return mfail(m, MI355_SW_EINVAL, "null argument");
   if (n >= 0xFFFFFFFFull) return mfail(m, MI355_SW_EINVAL, "more than 2^32 - 2 alignments per call");
   const int ndev = (int)m->ctx.size();
+  if (n) memset(outs, 0, n * sizeof *outs);                      // so that a failed call can release what was filled
   // deal by length: snake order over the length-sorted batch (device loads differ by at most one item per round)
   std::vector<uint32_t> order(n);
   {
@@ -309,10 +310,12 @@ int mi355_sw_multi_align_batch(mi355_sw_multi *m, size_t n, const char *const *x
     gkey[d] = key;
     return 0;
   });
-  if (rc) return rc;
-  if (m->flags & MI355_SW_MULTI_RCCL) {                            // second phase: every device finished its share
+  if (!rc && (m->flags & MI355_SW_MULTI_RCCL))                     // second phase: every device finished its share
     rc = on_devices(m, [&](int d) -> int { return merge_key_rccl(m, d, gkey[d], &gkey[d]); });
-    if (rc) return rc;
+  if (rc) {                                                        // nothing half-filled leaves the call
+    mi355_sw_free_results(outs, n);
+    memset(outs, 0, n * sizeof *outs);
+    return rc;
   }
   unsigned long long best = 0;
   for (int d = 0; d < ndev; ++d) best = std::max(best, gkey[d]);

@@ -61,6 +61,7 @@ void pick_shape64(int len, int &R, bool &strips) {
     for (int r : one) if (64 * r >= len) { R = r; return; }
   }
   static const int many[] = {20, 24, 32};
+  if (const char *e = std::getenv("MI355_SW_STRIP_R")) { const int v = std::atoi(e); if (v == 20 || v == 24 || v == 32) { R = v; return; } }   // tuning aid
   int64_t best = -1;
   for (int r : many) {
     const int64_t rows = (int64_t)((len + 64 * r - 1) / (64 * r)) * 64 * r;
@@ -195,6 +196,7 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
           (int64_t)t.smax * b.maxlen + t.smax <= 2040 && std::getenv("MI355_SW_NO_F16") == nullptr) {
         b.sem = kSemF16; b.twin = true; b.SL = 16; b.R = pick_R(b.maxlen);
       }
+      else if (b.count == 1 && b.sem == kSemI16 && twin_ok && std::getenv("MI355_SW_LONG_TWIN") != nullptr) b.twin = true;   // A/B switch
       else if (b.count == 1 && b.sem == kSemI16 && (double)t.smax * b.maxlen < 1.6e7) b.sem = kSemF32;
       else if (b.count == 1 && b.sem == kSemI16 && twin_ok) b.twin = true;
     }

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Latency of OMPParallelLocalAligner-style calls (mi355_sw_align_split), the loop of src/sw_solve_big.cpp:78-92:
 one 150 bp read, npiece pieces, overlap 2.0, same reference every call."""
-import sys, time
-sys.path.insert(0, '/root/repo')
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pgs = g._load_package()
 ctx = pgs.Context(0)
