@@ -131,19 +131,19 @@ size_t strip_dirs_bytes(int64_t nb, int nstrips, int R) { return (size_t)nb * 64
 
 template <int R>
 void launch_strip(bool u8, bool track, dim3 grid, dim3 block, hipStream_t st, const StripProblem *dp, const WaveScoring &sc,
-                  const float *gtab, int ncodes) {
+                  const float *gtab, int ncodes, int groups = 1) {
   if (gtab) {                                   // table scoring (float engine): tab[257][ncodes] in dynamic LDS
     const size_t lds = (size_t)257 * ncodes * 4;
-    if (track) hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripTrack, true>), grid, block, lds, st, dp, sc, gtab, ncodes);
-    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripDirs, true>), grid, block, lds, st, dp, sc, gtab, ncodes);
+    if (track) hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripTrack, true>), grid, block, lds, st, dp, sc, gtab, ncodes, 1);
+    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripDirs, true>), grid, block, lds, st, dp, sc, gtab, ncodes, groups);
     return;
   }
   if (track) {
-    if (u8) hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripTrack>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0);
-    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripTrack>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0);
+    if (u8) hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripTrack>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0, 1);
+    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripTrack>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0, 1);
   } else {
-    if (u8) hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripDirs>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0);
-    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripDirs>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0);
+    if (u8) hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripDirs>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0, groups);
+    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripDirs>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0, groups);
   }
 }
 
@@ -167,14 +167,21 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   if (n == 0) return 0;
   const bool track = jobs[0].track;
   size_t dirs_total = 0, gtotal = 0;
-  int nwmax = 1;
+  int nwmax = 1, nsmax = 1;
   std::vector<size_t> goff(n, 0);
+  for (size_t k = 0; k < n; ++k) nsmax = std::max(nsmax, strip_count(q.len[jobs[k].q], R));
+  // the decisions of a FEW long alignments: the strips of each dealt to several workgroups, four wavefronts (one per
+  // SIMD) each, instead of sixteen wavefronts on one CU (config 5: the sweep of the 26 k-column window)
+  static const bool no_groups = std::getenv("MI355_SW_NO_STRIP_GROUPS") != nullptr;
+  const int spg = 4;
+  const int groups = (!track && !no_groups && n <= 8 && nsmax > spg) ? (nsmax + spg - 1) / spg : 1;
   for (size_t k = 0; k < n; ++k) {
     WaveJob &j = jobs[k];
     const int ns = strip_count(q.len[j.q], R);
     nwmax = std::max(nwmax, std::min(ns, kStripMaxWaves));
     if (!track) { j.dirs_off = dirs_total; dirs_total += strip_dirs_bytes(j.nb, ns, R); }
-    if (ns > kStripMaxWaves) { goff[k] = gtotal; gtotal += 2 * ((size_t)j.nb + 192); }
+    if (groups > 1) { goff[k] = gtotal; gtotal += (((size_t)groups * ((size_t)j.nb + 192) + 1) & ~(size_t)1) + 2 * (size_t)groups; }   // rows (even count) + 64-bit counters
+    else if (ns > kStripMaxWaves) { goff[k] = gtotal; gtotal += 2 * ((size_t)j.nb + 192); }
   }
   if (ctx->wprobs.ensure(n * sizeof(StripProblem)) || ctx->outs_i.ensure(n * 16) || ctx->outs_f.ensure(n * 4) ||
       (dirs_total && ctx->dirs.ensure(dirs_total)) || (gtotal && ctx->brow.ensure(gtotal * 4)))
@@ -192,8 +199,11 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
     s.nb = j.nb;
     s.nstrips = strip_count(q.len[j.q], R);
     s.nw = std::min(s.nstrips, kStripMaxWaves);
-    s.gbound = s.nstrips > kStripMaxWaves ? ctx->brow.as<float>() + goff[k] : nullptr;
+    s.gbound = (groups > 1 || s.nstrips > kStripMaxWaves) ? ctx->brow.as<float>() + goff[k] : nullptr;
     s.gstride = (int64_t)j.nb + 192;
+    s.spg = groups > 1 ? spg : 0;
+    s.gcount = groups > 1 ? reinterpret_cast<long long *>(ctx->brow.as<float>() + goff[k] + (((size_t)groups * ((size_t)j.nb + 192) + 1) & ~(size_t)1))
+                          : nullptr;                            // 8-byte aligned: every offset is an even number of floats
     s.dirs = track ? nullptr : reinterpret_cast<uint32_t *>(ctx->dirs.as<uint8_t>() + j.dirs_off);
     s.target = j.target;
     s.own_lo = j.own_lo;
@@ -204,6 +214,7 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
     s.fault = fault;
   }
   HIPCHK(ctx, hipMemsetAsync(ctx->outs_f.p, 0, n * 4, ctx->stream));
+  if (groups > 1) HIPCHK(ctx, hipMemsetAsync(ctx->brow.p, 0, gtotal * 4, ctx->stream));      // the progress counters start at 0
   HIPCHK(ctx, hipMemcpyAsync(ctx->wprobs.p, pr.data(), n * sizeof(StripProblem), hipMemcpyHostToDevice, ctx->stream));
   WaveScoring sc;
   sc.match = p.match; sc.mismatch = p.mismatch; sc.gap = p.gap;
@@ -211,7 +222,7 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   sc.u8M = (float)u.M; sc.u8X = (float)u.X; sc.u8G = (float)u.G;
   const bool u8 = p.semantics == MI355_SW_U8SAT;
   const StripProblem *dp = ctx->wprobs.as<StripProblem>();
-  const dim3 grid((unsigned)n), block((unsigned)(64 * nwmax));
+  const dim3 grid((unsigned)(n * groups)), block((unsigned)(64 * (groups > 1 ? spg : nwmax)));
   const float *gtab = use_table ? ctx->ftab.as<float>() : nullptr;
   if (use_table && (size_t)257 * ref.ncodes * 4 > 48 * 1024) {
     const int lds = 257 * ref.ncodes * 4;
@@ -221,11 +232,11 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
     STRIP_LDS_ATTR(3) STRIP_LDS_ATTR(5) STRIP_LDS_ATTR(8) STRIP_LDS_ATTR(10) STRIP_LDS_ATTR(16)
 #undef STRIP_LDS_ATTR
   }
-  if (R == 3) launch_strip<3>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes);
-  else if (R == 5) launch_strip<5>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes);
-  else if (R == 8) launch_strip<8>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes);
-  else if (R == 10) launch_strip<10>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes);
-  else launch_strip<16>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes);
+  if (R == 3) launch_strip<3>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups);
+  else if (R == 5) launch_strip<5>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups);
+  else if (R == 8) launch_strip<8>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups);
+  else if (R == 10) launch_strip<10>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups);
+  else launch_strip<16>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups);
   HIPCHK(ctx, hipGetLastError());
   std::vector<int32_t> st(n);
   std::vector<int64_t> ci(2 * n);
@@ -287,7 +298,7 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         const int64_t a_end = orient == 0 ? loc[k].ix : loc[k].iy;   // lane-side index of the argmax
         const int64_t wl = std::max<int64_t>(0, s_end - (budget[k] + std::min(warm[k], lane_need(a_end))));
         const int64_t nb = s_end - wl;
-        const size_t need = strips ? strip_dirs_bytes(nb, strip_count((int)na, 10), 10)
+        const size_t need = strips ? strip_dirs_bytes(nb, strip_count((int)na, 5), 5)
                                    : wave_dirs_bytes(nb, 32);      // upper bound whatever instance the group gets
         if (need > kDirsBudget) return fail(ctx, MI355_SW_ENOTSUP, "traceback window exceeds the device scratch budget");
         if (!jobs.empty() && bytes + need > kDirsBudget) break;
@@ -299,7 +310,10 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
       }
       int gmax = 0;
       for (const WaveJob &j : jobs) gmax = std::max(gmax, orient == 0 ? q.len[j.q] : (int)nref);
-      const int groupR = strips ? strip_R(gmax) : wave_R(gmax);     // the instance this group runs on
+      int groupR = strips ? strip_R(gmax) : wave_R(gmax);           // the instance this group runs on
+      // a few long alignments whose strips are dealt to several workgroups (run_strip): five rows per lane make twice
+      // the strips, i.e. twice the workgroups, of ten (config 5: 32 strips on 8 CUs)
+      if (strips && groupR == 10 && jobs.size() <= 8 && gmax > 2560 && std::getenv("MI355_SW_NO_STRIP_GROUPS") == nullptr) groupR = 5;
       int rc = strips ? run_strip(ctx, ref, q, rg, p, jobs, groupR) : run_wave(ctx, ref, q, rg, p, jobs);
       if (rc) return rc;
       // walk: measure, lay out, write (only the bytes that exist are copied back)

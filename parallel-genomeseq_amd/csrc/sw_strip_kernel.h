@@ -48,6 +48,10 @@ struct StripProblem {
   int64_t full_n;        // |y| of the full problem (uint8 storage order)
   int64_t *cell;         // [2] row, true column of the first cell equal to target; row 0 when none
   int32_t *status;       // 0 = complete, 1 = a pipeline wait expired (result unusable)
+  int32_t spg;           // > 0: the strips are dealt to several WORKGROUPS, spg consecutive strips each (one wavefront per
+                         // strip, one round); the bottom row of a workgroup's last strip reaches the next workgroup
+                         // through gbound + g * gstride, progress through gcount[g] (global, zero at launch)
+  long long *gcount;
   int32_t fault;         // test hook (MI355_SW_FAULT_INJECT=strip_stall): wavefront 0 never reports progress, so the
                          // strip below it runs into the bounded wait and the workgroup takes the expiry path
 };
@@ -60,9 +64,13 @@ constexpr int kStripSpinLimit = 1 << 22; // polls (with s_sleep) before a wait i
 // LUT = true (float engine): scores come from a table tab[257][ncodes] in dynamic LDS (row = query byte, row 256 =
 // padding row; column = reference code, column ncodes-1 = padding) and the stream is the window of reference
 // CODES; LUT = false: identity scoring on raw bytes, no table.
+// groups > 1 (kStripDirs only): the grid holds `groups` workgroups per problem — the traceback decisions of ONE long
+// alignment on several CUs (a workgroup of sixteen wavefronts is bound by its CU's issue rate: 31 ms for config 5's
+// 26 k-column window); all workgroups of a launch are resident at once (the host keeps the grid far below the CU count),
+// the chain of waits is acyclic (strip s only waits for strip s - 1) and every wait is bounded as before.
 template <int R, bool U8, int MODE, bool LUT = false>
 __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const StripProblem *probs, const WaveScoring sc,
-                                                                       const float *gtab = nullptr, int ncodes = 0) {
+                                                                       const float *gtab = nullptr, int ncodes = 0, int groups = 1) {
   extern __shared__ float tab[];
   __shared__ float ring[kStripMaxWaves + 1][kStripRing];            // [w] = output of wavefront w; [kStripMaxWaves] = round input of wavefront 0
   __shared__ long long produced[kStripMaxWaves], consumed[kStripMaxWaves + 1];
@@ -70,7 +78,9 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
   __shared__ __attribute__((aligned(16))) uint8_t win[kStripMaxWaves][128];
   __shared__ unsigned long long wkey[kStripMaxWaves];
   __shared__ long long wi[kStripMaxWaves], wj[kStripMaxWaves];
-  const StripProblem P = probs[blockIdx.x];
+  const bool multi = groups > 1;
+  const StripProblem P = probs[multi ? blockIdx.x / groups : blockIdx.x];
+  const int grp = multi ? blockIdx.x % groups : 0;
   const int tid = threadIdx.x;
   const int w = tid >> 6, l = tid & 63;
   if (tid < kStripMaxWaves) produced[tid] = 0;
@@ -80,14 +90,16 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
     for (int e = tid; e < 257 * ncodes; e += blockDim.x) tab[e] = e < 256 * ncodes ? gtab[e] : -1.0e30f;
   }
   __syncthreads();
-  const int nw = P.nw;
   const int na = P.na, nb = P.nb;
   const int nstrips = P.nstrips;
+  const int s_first = multi ? grp * P.spg : 0;                       // this workgroup's first strip
+  const int nw = multi ? min(P.spg, nstrips - s_first) : P.nw;       // wavefronts that take part (multi: one per strip)
+  if (nw <= 0) return;
   const int LT = 64 * nstrips;
   constexpr int W = (R + 15) / 16;
   const int nseg = (nb + 64 + 63) / 64;                  // lane 63 reaches stream position nb - 1
   const long long NBP = (long long)nseg * 64;            // counter units per round
-  const int rounds = (nstrips + nw - 1) / nw;
+  const int rounds = multi ? 1 : (nstrips + nw - 1) / nw;
   const float gpen = U8 ? sc.u8G : sc.gap;
   bool ok = true;
 
@@ -106,6 +118,18 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
     }
   };
 
+  auto wait_global = [&](long long *counter, long long need) {        // progress of the workgroup above (device scope)
+    int spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      if (__hip_atomic_load(&dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 || ++spins > kStripSpinLimit) {
+        __hip_atomic_store(&dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ok = false;
+        return;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  };
+
   uint8_t *buf = win[w < kStripMaxWaves ? w : 0];
   const uint8_t *buf_lane = buf + 64 - l;                // + k = byte of stream position seg*64 + k - l
   auto stage_load = [&](int seg) -> uint32_t {
@@ -114,7 +138,7 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
   };
 
   for (int round = 0; round < rounds && ok && w < nw; ++round) {
-    const int s = round * nw + w;                        // this wavefront's strip in this round
+    const int s = s_first + round * nw + w;              // this wavefront's strip in this round
     if (s >= nstrips) break;
     const long long base = (long long)round * NBP;
     const bool has_in = s > 0, has_out = s + 1 < nstrips;
@@ -123,8 +147,8 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
     const float *rin = ring[in_global ? kStripMaxWaves : (w > 0 ? w - 1 : 0)];
     float *rstage = ring[kStripMaxWaves];
     float *rout = ring[w];
-    const float *gin = in_global ? P.gbound + (size_t)((round + 1) & 1) * (size_t)P.gstride : nullptr;
-    float *gout = out_global ? P.gbound + (size_t)(round & 1) * (size_t)P.gstride : nullptr;
+    const float *gin = in_global ? P.gbound + (size_t)(multi ? grp - 1 : ((round + 1) & 1)) * (size_t)P.gstride : nullptr;
+    float *gout = out_global ? P.gbound + (size_t)(multi ? grp : (round & 1)) * (size_t)P.gstride : nullptr;
 
     uint32_t ca[R];
 #pragma unroll
@@ -149,7 +173,8 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
       if (has_in) {
         const long long need = (seg + 1) * 64 < nb ? (seg + 1) * 64 : nb;
         if (in_global) {
-          wait_for(&produced[nw - 1], base - NBP + need);
+          if (multi) wait_global(P.gcount + (grp - 1), need);
+          else wait_for(&produced[nw - 1], base - NBP + need);
           if (ok) { const int t = seg * 64 + l; rstage[t & (kStripRing - 1)] = t < nb ? __hip_atomic_load(gin + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f; }
         } else {
           wait_for(&produced[w - 1], base + need);
@@ -231,6 +256,8 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
         const int t = seg * 64 - 63 + l;
         if (t >= 0 && t < nb) __hip_atomic_store(gout + t, rout[t & (kStripRing - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      if (multi && out_global && l == 0)                               // (the release covers this wavefront's stores above)
+        __hip_atomic_store(P.gcount + grp, (long long)seg * 64 + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       if (l == 0) {
         if (has_out && !(P.fault && w == 0)) __hip_atomic_store(&produced[w], base + seg * 64 + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(&consumed[w], base + (seg + 1) * 64, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -240,6 +267,7 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
       buf[64 + l] = (uint8_t)nextc;
       nextc = stage_load(seg + 2);
     }
+    if (multi && out_global && l == 0 && ok) __hip_atomic_store(P.gcount + grp, NBP, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     if (l == 0 && ok && !(P.fault && w == 0)) {
       // the whole round of this strip is done: releases every wait of this round on this wavefront
       __hip_atomic_store(&produced[w], base + NBP, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -251,6 +279,7 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
     __hip_atomic_store(&produced[w], 0x7FFFFFFFFFFFFFFFll, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_store(&consumed[w], 0x7FFFFFFFFFFFFFFFll, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (!ok) *P.status = 1;
+    if (multi && w == nw - 1) __hip_atomic_store(P.gcount + grp, 0x7FFFFFFFFFFFFFFFll, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (MODE == kStripTrack) {
 #pragma unroll
