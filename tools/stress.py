@@ -22,7 +22,8 @@ ctx = pgs.Context(0)
 KEYS = ("score", "pos", "end_x", "end_y", "cons_x", "cons_y")
 ALPH = [b"ACGT", b"ACGT", b"ACGT", b"AC", b"ACGTN", b"ACDEFGHIKLMNPQRSTVWY", bytes(range(65, 65 + 26))]
 SC = [(3.0, -3.0, 2.0)] * 5 + [(2.0, -1.0, 1.0), (5.0, -4.0, 3.0), (1.0, -1.0, 1.0), (10.0, -2.0, 4.0), (3.5, -2.25, 1.5),
-                               (4.0, -6.0, 3.0), (1.0, -3.0, 5.0), (7.0, -7.0, 1.0), (255.0, -200.0, 100.0), (0.5, -0.25, 0.25)]
+                               (4.0, -6.0, 3.0), (1.0, -3.0, 5.0), (7.0, -7.0, 1.0), (255.0, -200.0, 100.0), (0.5, -0.25, 0.25),
+                               (0.7, -0.3, 0.1), (1.1, -0.9, 0.37), (0.1, -0.3, 0.7)]       # non-dyadic: float32 adds round
 
 
 def rseq(n, alpha):
@@ -60,7 +61,7 @@ while time.time() - t0 < budget:
         tick = time.time()
         print("... %d cases, %d mismatches, %.0f s" % (ncase, nbad, tick - t0), flush=True)
     alpha = ALPH[int(rng.integers(0, len(ALPH)))]
-    kind = int(rng.integers(0, 10))
+    kind = int(rng.integers(0, 12))
     ma, mi, gp = SC[int(rng.integers(0, len(SC)))]
     sem = int(rng.integers(0, 2))
     if kind <= 5:       # single alignment, oracle cost bounded to ~3e8 cells
@@ -98,6 +99,24 @@ while time.time() - t0 < budget:
             if bad:
                 nbad += 1
                 print("MISMATCH batch |q|=%d n=%d sem=%d sc=%s keys=%s" % (len(q), n, sem, (ma, mi, gp), bad), flush=True)
+            ncase += 1
+    elif kind >= 10:    # many small whole problems against a short reference (device-built job lists, struct-of-arrays view)
+        n = int(rng.choice([1, 40, 144, 300, 700, 1023]))
+        ref = rseq(n, alpha)
+        qs = [plant(ref, int(rng.choice([0, 1, 2, 17, 60, 144, 145, 300, 511, 512, 513, 900, 3000])), alpha) for _ in range(int(rng.integers(20, 400)))]
+        ctx.set_reference(ref)
+        ctx.batch_upload(qs)
+        raw = ctx.batch_run(semantics=sem, match=ma, mismatch=mi, gap=gp, raw=True)
+        for k, q in enumerate(qs):
+            exp = ob.align(q, ref, sem, ma, mi, gp)
+            cx, cy = ctx.consensus(k)
+            got = dict(score=float(raw["score"][k]), pos=int(raw["pos"][k]), end_x=int(raw["end_x"][k]), end_y=int(raw["end_y"][k]),
+                       cons_x=cx, cons_y=cy)
+            bad = [key for key in KEYS if got[key] != exp[key]]
+            if bad:
+                nbad += 1
+                print("MISMATCH small |q|=%d n=%d sem=%d sc=%s keys=%s got=%s exp=%s" % (len(q), n, sem, (ma, mi, gp), bad,
+                                                                                        {key: got[key] for key in bad[:2]}, {key: exp[key] for key in bad[:2]}), flush=True)
             ncase += 1
     else:               # split aligner
         n = int(rng.choice([3000, 30000, 120000]))
