@@ -370,7 +370,8 @@ int64_t score_sub_len(int semantics, const Bucket &b) {
   return s;
 }
 
-int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int SL = 16, bool twin = false, int maxlen = 0) {
+int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int SL = 16, bool twin = false, int maxlen = 0,
+                       int64_t sub_len = 0) {
   int64_t cl = 65536;
   while (cl < 8 * warm) cl *= 2;                 // long queries: keep the warm-up redundancy bounded
   // fill the chip: 256 CUs x 32 waves x 4 slots; shrink tiles while they stay >> warm-up
@@ -385,9 +386,11 @@ int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int S
   // mostly idle, so tiles shrink until every CU has a workgroup (down to one sub-chunk: >= 256 columns, >= |x|)
   int64_t floor_cl = 256;
   while (floor_cl < maxlen) floor_cl *= 2;
+  if (sub_len > 0 && sub_len < floor_cl) floor_cl = std::max<int64_t>(128, sub_len);   // finer sub-chunks allow shorter tiles (measured:
+                                                                                       // 0.30 ms per 150 bp x 1 Mbp call at 128 columns, 0.33 at 256)
   const double per_wg = 256.0 / SL * (twin ? 2.0 : 1.0);
   while (cl / 2 >= floor_cl && (double)npairs * (double)((max_range_len + cl - 1) / cl) / per_wg < 256.0) cl /= 2;
-  if (const char *e = std::getenv("MI355_SW_CHUNK")) { const long v = std::atol(e); if (v >= 256) cl = v / 64 * 64; }   // tuning aid
+  if (const char *e = std::getenv("MI355_SW_CHUNK")) { const long v = std::atol(e); if (v >= 64) cl = v / 64 * 64; }   // tuning aid
   return cl;
 }
 
@@ -468,10 +471,10 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   int64_t maxlen = 0;
   for (auto &r : ranges) maxlen = std::max(maxlen, r.hi - r.lo);
   const size_t npairs = (sem_is_float(b.sem) || b.twin) ? (size_t)b.count : ((size_t)b.count + 1) / 2;   // queries per workgroup: 1 or 2
-  b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm, b.SL, b.twin, b.maxlen);
   // report maxima per sub-chunk of >= 256 columns (>= query length, so that the uint8 storage order stays
   // within two neighbouring sub-chunks): that is what locate re-runs; the strip-mined instance reports per tile
   b.sub_len = score_sub_len(p.semantics, b);
+  b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm, b.SL, b.twin, b.maxlen, b.sub_len);
   if (b.strips) while (b.chunk_len / b.sub_len > 64) b.sub_len *= 2;      // the strip-mined instances keep <= 64 sub-chunk maxima in LDS
   if (b.sub_len > b.chunk_len || b.chunk_len % b.sub_len != 0) b.sub_len = b.chunk_len;
   const int64_t cpr = (maxlen + b.chunk_len - 1) / b.chunk_len;
