@@ -119,7 +119,7 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     cons_base = cons.as<char>();
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  bool bad = false;
+  std::atomic<bool> bad{false};
   parallel_for(n, [&](size_t k0, size_t k1) {
     for (size_t k = k0; k < k1; ++k) {
       const int id = q.order[first + k];
@@ -128,7 +128,7 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
       L.score = h_best[k] > 0 ? h_best[k] : 0;
       L.ix = h_cell[2 * k]; L.iy = h_cell[2 * k + 1];
       if (!want_trace || !(L.score > 0)) continue;
-      if (h_wout[3 * k + 2] != 0) { bad = true; continue; }
+      if (h_wout[3 * k + 2] != 0) { bad.store(true, std::memory_order_relaxed); continue; }
       TraceOut &t = tout[id];
       t.len = (size_t)h_wout[3 * k];
       t.cx = cons_base + h_offs[k];
@@ -136,7 +136,7 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
       t.pos = (uint32_t)h_wout[3 * k + 1];
     }
   });
-  if (bad) return fail(ctx, MI355_SW_ENODEV, "internal: a walk over a whole-problem window failed");
+  if (bad.load()) return fail(ctx, MI355_SW_ENODEV, "internal: a walk over a whole-problem window failed");
   return 0;
 }
 
