@@ -239,11 +239,13 @@ int exact_full(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
 // Argmax cells for the score-kernel queries (qfast[q] != 0) over one range, from the score pass' keys.
 // qchunk / qwarm: tile geometry of each query's bucket.
 int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
-                const mi355_sw_params &p, const std::vector<char> &qfast, const std::vector<int64_t> &qchunk,
+                const mi355_sw_params &p, const std::vector<char> &qfast_in, const std::vector<int64_t> &qchunk,
                 const std::vector<int64_t> &qwarm, const std::vector<char> &qfloat, const unsigned long long *keys,
-                const ScoreTable &table, std::vector<Located> &loc) {
+                const ScoreTable &table, std::vector<Located> &loc, const std::vector<char> *skip = nullptr) {
   HostTrace trace_("locate_fast");
   const size_t nq = q.nq;
+  std::vector<char> qfast = qfast_in;                    // (queries already located elsewhere are not ours)
+  if (skip) for (size_t k = 0; k < nq; ++k) if ((*skip)[k]) qfast[k] = 0;
   const int64_t n = rg.hi - rg.lo;
   std::vector<ExactJob> jobs;
   std::vector<WaveJob> sjobs;                  // long queries with identity scoring: pipelined strip kernel
@@ -380,6 +382,48 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
   return 0;
 }
 
+// Queries whose saturating float16 sweep reached the cap (host_score.h make_buckets): exact maximum and first maximum
+// cell from the sub-chunks the sweep flagged — each re-evaluated on the pipelined strip kernel (kStripMax) over a window
+// with the general warm-up margin in front.  `flagged` = {query id, sub-chunk}; done[k] is set for every query resolved.
+int locate_saturated(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg, const mi355_sw_params &p,
+                     const std::vector<int64_t> &qchunk, const std::vector<int64_t> &qwarm,
+                     const std::vector<std::pair<uint32_t, uint32_t>> &flagged, std::vector<Located> &loc, std::vector<char> &done) {
+  HostTrace trace_("locate_saturated");
+  const int64_t n = rg.hi - rg.lo;
+  std::vector<WaveJob> jobs;
+  jobs.reserve(flagged.size());
+  for (const auto &f : flagged) {
+    const int k = (int)f.first;
+    const int64_t sub_len = qchunk[k];
+    const int64_t sub_lo = std::max<int64_t>(0, (int64_t)f.second * sub_len - 63);   // the lane lag of the sweep
+    const int64_t sub_hi = std::min(((int64_t)f.second + 1) * sub_len, n);
+    if (sub_lo >= sub_hi) continue;
+    const int64_t wl = std::max<int64_t>(0, sub_lo - qwarm[k]);
+    WaveJob j;
+    j.q = k; j.orient = 0; j.s_lo = wl; j.nb = (int32_t)(sub_hi - wl); j.track = true; j.dirs = false; j.maxmode = true;
+    j.target = -1.0f; j.own_lo = (int32_t)(sub_lo - wl);
+    jobs.push_back(j);
+  }
+  std::vector<unsigned long long> bestkey(q.nq, ~0ull);
+  for (int R : {3, 5, 8, 10, 16}) {
+    std::vector<WaveJob> group;
+    for (const WaveJob &j : jobs) if (strip_R(q.len[j.q]) == R) group.push_back(j);
+    for (size_t lo = 0; lo < group.size(); lo += 4096) {
+      std::vector<WaveJob> part(group.begin() + lo, group.begin() + std::min(group.size(), lo + 4096));
+      int rc = run_strip(ctx, ref, q, rg, p, part, R);
+      if (rc) return rc;
+      for (const WaveJob &j : part) {
+        if (!(j.best > 0) || j.ci <= 0) continue;
+        const unsigned long long kk = host_order_key(MI355_SW_F32, j.ci, j.cj, q.len[j.q], n);
+        Located &L = loc[j.q];
+        if (j.best > L.score || (j.best == L.score && kk < bestkey[j.q])) { L.score = j.best; L.ix = j.ci; L.iy = j.cj; bestkey[j.q] = kk; }
+        done[j.q] = 1;
+      }
+    }
+  }
+  return 0;
+}
+
 float elapsed_us(mi355_sw_ctx *ctx, hipEvent_t a, hipEvent_t b) {
   float ms = 0;
   if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0;
@@ -410,29 +454,68 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
     const ScoreTable table = plan_table(ref, p);
     // references shorter than 1024 columns never take the score kernel (bucket_fast_ok): skip the length classes
     std::vector<Bucket> buckets;
-    if (n >= 1024) buckets = make_buckets(ref, q, table, p, n);
-    std::vector<char> qfast(nq, 0), qfloat(nq, 0);
+    // the float engine's saturating float16 sweep (make_buckets) needs the strip kernel for its flagged sub-chunks
+    bool allow_sat = p.semantics == MI355_SW_F32 && strip_scoring_ok(ref, p);
+    std::vector<char> qfast(nq, 0), qfloat(nq, 0), qsat(nq, 0), qdone(nq, 0);
     std::vector<int64_t> qchunk(nq, 0), qwarm(nq, 0);
+    std::vector<unsigned long long> keys;
     bool any_fast = false;
-    for (Bucket &b : buckets) { b.fast = bucket_fast_ok(ref, table, b, n, p); any_fast |= b.fast; }
-    if (any_fast) {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      buckets.clear();
+      if (n >= 1024) buckets = make_buckets(ref, q, table, p, n, allow_sat);
+      any_fast = false;
+      bool any_sat = false;
+      for (Bucket &b : buckets) { b.fast = bucket_fast_ok(ref, table, b, n, p); any_fast |= b.fast; any_sat |= b.fast && b.satflag; }
+      if (!any_fast) break;
       const std::vector<Range> ranges{rg};
       int rc = score_begin(ctx, q, ranges, table);
       if (rc) return rc;
+      std::fill(qsat.begin(), qsat.end(), 0);
       for (Bucket &b : buckets) {
         if (!b.fast) continue;
         rc = score_launch(ctx, ref, q, ranges, p, table, b);
         if (rc) return rc;
         for (int k = 0; k < b.count; ++k) {
           const int id = q.order[b.first + k];
-          qfast[id] = 1; qchunk[id] = b.sub_len; qwarm[id] = b.warm; qfloat[id] = b.sem == kSemF16 ? 2 : (b.sem == kSemU8H ? 3 : (b.sem == kSemF32 ? 4 : (sem_is_float(b.sem) ? 1 : 0)));
+          qfast[id] = 1; qchunk[id] = b.sub_len; qwarm[id] = b.warm; qsat[id] = b.satflag ? 1 : 0;
+          qfloat[id] = b.sem == kSemF16 ? 2 : (b.sem == kSemU8H ? 3 : (b.sem == kSemF32 ? 4 : (sem_is_float(b.sem) ? 1 : 0)));
         }
       }
-      std::vector<unsigned long long> keys;
       rc = score_fetch(ctx, nq, keys);
       if (rc) return rc;
+      if (!any_sat) break;
+      // the flagged (query, sub-chunk) pairs of the saturating sweep
+      unsigned int nflag = 0;
+      HIPCHK(ctx, hipMemcpy(&nflag, ctx->flags.p, 4, hipMemcpyDeviceToHost));
+      size_t nsatq = 0;
+      for (size_t k = 0; k < nq; ++k) nsatq += qsat[k] ? 1 : 0;
+      if (nflag > kFlagCap || (double)nflag > 64.0 * (double)nsatq + 1024.0) {
+        // saturated nearly everywhere (a background that reaches the cap): the exact packed int16 sweep instead
+        allow_sat = false;
+        ctx->last_kernel.cells = 0;                                  // the sweep that counts is the one that follows
+        continue;
+      }
+      std::vector<uint32_t> raw(2 * (size_t)nflag);
+      if (nflag) HIPCHK(ctx, hipMemcpy(raw.data(), ctx->flags.as<unsigned int>() + 2, (size_t)nflag * 8, hipMemcpyDeviceToHost));
+      std::vector<std::pair<uint32_t, uint32_t>> flagged(nflag);
+      for (size_t f = 0; f < nflag; ++f) flagged[f] = {raw[2 * f], raw[2 * f + 1]};
+      std::sort(flagged.begin(), flagged.end());
+      flagged.erase(std::unique(flagged.begin(), flagged.end()), flagged.end());
       HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-      rc = locate_fast(ctx, ref, q, rg, p, qfast, qchunk, qwarm, qfloat, keys.data(), table, loc);
+      rc = locate_saturated(ctx, ref, q, rg, p, qchunk, qwarm, flagged, loc, qdone);
+      if (rc) return rc;
+      HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+      ctx->timings[1] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
+      // every query whose key sits at the cap must have been resolved by a flagged sub-chunk
+      for (size_t k = 0; k < nq; ++k)
+        if (qsat[k] && !qdone[k] && half_value((uint16_t)(keys[k] >> 32)) * kF16Scale >= kF16Scale)
+          return fail(ctx, MI355_SW_ENODEV, "internal: a saturated query without a flagged sub-chunk");
+      break;
+    }
+    if (any_fast) {
+      int rc = 0;
+      HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+      rc = locate_fast(ctx, ref, q, rg, p, qfast, qchunk, qwarm, qfloat, keys.data(), table, loc, &qdone);
       if (rc) return rc;
       HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
       ctx->timings[1] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);

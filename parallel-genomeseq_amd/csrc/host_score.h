@@ -31,6 +31,8 @@ struct Bucket {
   bool strips = false;        // queries longer than one 512-row strip
   bool twin = false;          // lone long query: two tiles of it per packed register (sw_score_kernel TWIN)
   bool unsat = false;         // uint8 engine swept by a float-engine instance WITHOUT saturation, maxima clamped at 255
+  bool satflag = false;       // float engine swept on float16 cells BEYOND their exact range (the sweep saturates at 2048):
+                              // sub-chunks that reach the cap are flagged and re-evaluated exactly (locate_saturated)
   int64_t warm = 0;           // exactness margin in columns
   bool fast = false;          // swept by the score kernel (else whole-matrix exact path)
   int64_t chunk_len = 0;      // own columns per tile
@@ -136,7 +138,8 @@ size_t profile_lds_bytes(int ncodes, int R, int SL = 16, bool twin = false) {
 }
 
 // Length classes of the batch: one bucket per kernel instance (R), plus one strip-mined bucket.
-std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const ScoreTable &t, const mi355_sw_params &p, int64_t n) {
+std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const ScoreTable &t, const mi355_sw_params &p, int64_t n,
+                                 bool allow_sat = false) {
   std::vector<Bucket> out;
   // queries beyond 512 rows: whole-wavefront tiles (64 lanes x R rows: one strip up to 2048 rows, 2048-row
   // strips beyond) when the 64-position profile fits LDS, else 16-lane tiles in 512-row strips
@@ -188,6 +191,17 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       if (fits && !t.htab.empty() && !b.strips && (b.SL != 64 || f16_wide) && b.count >= 2 &&
           (int64_t)t.smax * b.maxlen + t.smax <= 2040 && std::getenv("MI355_SW_NO_F16") == nullptr)
         b.sem = kSemF16;
+      // Beyond float16's exact range (reads above 680 bp at match 3) the packed int16 cell costs 4.5 ops.  The float16
+      // cell still sweeps them when its clamp is allowed to SATURATE the values at 2048: if the true maximum M is below
+      // 2048 nothing saturated and the sweep is exact; if not, the first cell holding M has 2048 in the sweep (every
+      // suffix of its best path has a positive sum — else an earlier cell would hold M too — so a walk capped at 2048
+      // that has reached the cap is back at it there), so its sub-chunk is among the FLAGGED ones (sub-chunk maximum at
+      // the cap), which locate_saturated re-evaluates exactly: few windows per read instead of the whole reference.
+      // Only where a random background stays well below the cap (<= 2048 rows) and the exact kernel takes the scoring.
+      else if (allow_sat && fits && !t.htab.empty() && !b.strips && b.count >= 2 && b.maxlen <= 2048 &&
+               std::getenv("MI355_SW_NO_F16") == nullptr && std::getenv("MI355_SW_NO_SATFLAG") == nullptr) {
+        b.sem = kSemF16; b.satflag = true;
+      }
       // a lone query would fill both halves of every packed register with itself: the float32 instance (one query per
       // slot, exact for integer scores below 2^24) sweeps it faster — also than two of its tiles per packed integer
       // register (config 5: 282 ms against 338 ms), which remains the uint8 engine's way (its cells are float16)
@@ -439,6 +453,8 @@ int score_tables(mi355_sw_ctx *ctx, int maxlen, int64_t maxrange, const ScoreTab
   return 0;
 }
 
+constexpr uint32_t kFlagCap = 1u << 20;   // (query, sub-chunk) pairs a saturating float16 sweep may flag before it is abandoned
+
 // Uploads what every score launch of a call shares and clears the keys.
 int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range> &ranges, const ScoreTable &t) {
   const size_t nq = q.nq, nr = ranges.size();
@@ -454,6 +470,8 @@ int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range>
   int rc = score_tables(ctx, q.maxlen, maxrange, t);
   if (rc) return rc;
   HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, nq * nr * 8, ctx->stream));
+  if (ctx->flags.ensure(8 + (size_t)kFlagCap * 8)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
+  HIPCHK(ctx, hipMemsetAsync(ctx->flags.p, 0, 8, ctx->stream));
   return 0;
 }
 
@@ -513,6 +531,13 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     else a.pubmax = (uint32_t)half_bits(255.0f / kF16Scale);
   }
   a.keys = io ? io->keys : ctx->keys.as<unsigned long long>();
+  a.flag_count = nullptr; a.flag_list = nullptr; a.flag_cap = 0; a.flag_value = 0;
+  if (b.satflag) {
+    a.flag_count = ctx->flags.as<unsigned int>();
+    a.flag_list = reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2);
+    a.flag_cap = kFlagCap;
+    a.flag_value = (uint32_t)half_bits(1.0f);                       // cells hold H / 2048: the clamp's upper end
+  }
 
   const int nqw = (sem_is_float(b.sem) || b.twin) ? 1 : 2;          // queries per workgroup
   // keep single launches to a few seconds: split the bucket's pairs over several launches
@@ -573,7 +598,9 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     ki.valu_ops_per_cell = valu_ops_per_cell(b);
     static const char *cellname[] = {"i16x2", "u8 as i16x2", "f32", "u8 as f32", "f16x2", "u8 as f16x2"};
     std::snprintf(ki.name, sizeof ki.name, "sw_score_kernel<R=%d, %s, SL=%d%s%s>%s", b.R, cellname[b.sem], b.SL,
-                  b.strips ? ", strips" : "", b.twin ? ", twin" : "", b.unsat ? " uint8 engine swept unsaturated, maxima clamped at 255" : "");
+                  b.strips ? ", strips" : "", b.twin ? ", twin" : "",
+                  b.unsat ? " uint8 engine swept unsaturated, maxima clamped at 255"
+                          : b.satflag ? " float engine swept saturating at 2048, saturated sub-chunks re-evaluated exactly" : "");
   }
   return 0;
 }

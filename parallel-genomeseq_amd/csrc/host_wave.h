@@ -24,6 +24,7 @@ struct WaveJob {
   int32_t nb;
   bool track, dirs;
   bool keyed = false;     // wave kernel, track: first cell equal to target in storage order (else: first maximum)
+  bool maxmode = false;   // strip kernel, track: the maximum over the own positions and its first cell (kStripMax)
   float target = 0;       // strip kernel / keyed: only cells equal to target compete ...
   int32_t own_lo = 0;     // ... at stream positions >= own_lo (0-based)
   // results
@@ -131,7 +132,12 @@ size_t strip_dirs_bytes(int64_t nb, int nstrips, int R) { return (size_t)nb * 64
 
 template <int R>
 void launch_strip(bool u8, bool track, dim3 grid, dim3 block, hipStream_t st, const StripProblem *dp, const WaveScoring &sc,
-                  const float *gtab, int ncodes, int groups = 1) {
+                  const float *gtab, int ncodes, int groups = 1, bool maxmode = false) {
+  if (maxmode) {                                // float engine only (locate_saturated)
+    if (gtab) hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripMax, true>), grid, block, (size_t)257 * ncodes * 4, st, dp, sc, gtab, ncodes, 1);
+    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripMax>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0, 1);
+    return;
+  }
   if (gtab) {                                   // table scoring (float engine): tab[257][ncodes] in dynamic LDS
     const size_t lds = (size_t)257 * ncodes * 4;
     if (track) hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripTrack, true>), grid, block, lds, st, dp, sc, gtab, ncodes, 1);
@@ -166,6 +172,7 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   const size_t n = jobs.size();
   if (n == 0) return 0;
   const bool track = jobs[0].track;
+  const bool maxmode = jobs[0].maxmode;
   size_t dirs_total = 0, gtotal = 0;
   int nwmax = 1, nsmax = 1;
   std::vector<size_t> goff(n, 0);
@@ -183,7 +190,7 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
     if (groups > 1) { goff[k] = gtotal; gtotal += (((size_t)groups * ((size_t)j.nb + 192) + 1) & ~(size_t)1) + 2 * (size_t)groups; }   // rows (even count) + 64-bit counters
     else if (ns > kStripMaxWaves) { goff[k] = gtotal; gtotal += 2 * ((size_t)j.nb + 192); }
   }
-  if (ctx->wprobs.ensure(n * sizeof(StripProblem)) || ctx->outs_i.ensure(n * 16) || ctx->outs_f.ensure(n * 4) ||
+  if (ctx->wprobs.ensure(n * sizeof(StripProblem)) || ctx->outs_i.ensure(n * 16) || ctx->outs_f.ensure(2 * n * 4) ||
       (dirs_total && ctx->dirs.ensure(dirs_total)) || (gtotal && ctx->brow.ensure(gtotal * 4)))
     return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(strip scratch) failed");
   std::vector<StripProblem> pr(n);
@@ -211,6 +218,7 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
     s.full_n = rg.hi - rg.lo;
     s.cell = ctx->outs_i.as<int64_t>() + 2 * k;
     s.status = ctx->outs_f.as<int32_t>() + k;
+    s.best = ctx->outs_f.as<float>() + n + k;
     s.fault = fault;
   }
   HIPCHK(ctx, hipMemsetAsync(ctx->outs_f.p, 0, n * 4, ctx->stream));
@@ -228,24 +236,27 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
     const int lds = 257 * ref.ncodes * 4;
 #define STRIP_LDS_ATTR(r)                                                                                              \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<r, false, kStripTrack, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<r, false, kStripDirs, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<r, false, kStripDirs, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_strip_kernel<r, false, kStripMax, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     STRIP_LDS_ATTR(3) STRIP_LDS_ATTR(5) STRIP_LDS_ATTR(8) STRIP_LDS_ATTR(10) STRIP_LDS_ATTR(16)
 #undef STRIP_LDS_ATTR
   }
-  if (R == 3) launch_strip<3>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups);
-  else if (R == 5) launch_strip<5>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups);
-  else if (R == 8) launch_strip<8>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups);
-  else if (R == 10) launch_strip<10>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups);
-  else launch_strip<16>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups);
+  if (R == 3) launch_strip<3>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups, maxmode);
+  else if (R == 5) launch_strip<5>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups, maxmode);
+  else if (R == 8) launch_strip<8>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups, maxmode);
+  else if (R == 10) launch_strip<10>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups, maxmode);
+  else launch_strip<16>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups, maxmode);
   HIPCHK(ctx, hipGetLastError());
   std::vector<int32_t> st(n);
   std::vector<int64_t> ci(2 * n);
+  std::vector<float> bv(maxmode ? n : 0);
+  if (maxmode) HIPCHK(ctx, hipMemcpyAsync(bv.data(), ctx->outs_f.as<float>() + n, n * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(st.data(), ctx->outs_f.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (track) HIPCHK(ctx, hipMemcpyAsync(ci.data(), ctx->outs_i.p, n * 16, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   for (size_t k = 0; k < n; ++k) {
     if (st[k] != 0) return fail(ctx, MI355_SW_ENODEV, "internal: strip pipeline wait expired");
-    if (track) { jobs[k].ci = ci[2 * k]; jobs[k].cj = ci[2 * k + 1]; jobs[k].best = ci[2 * k] > 0 ? jobs[k].target : -1.0f; }
+    if (track) { jobs[k].ci = ci[2 * k]; jobs[k].cj = ci[2 * k + 1]; jobs[k].best = maxmode ? bv[k] : (ci[2 * k] > 0 ? jobs[k].target : -1.0f); }
   }
   return 0;
 }

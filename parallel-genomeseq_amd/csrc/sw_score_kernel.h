@@ -95,6 +95,12 @@ struct ScoreArgs {
                              // type: float16 in the low half, or float32) — the uint8 engine swept WITHOUT saturation,
                              // see host_score.h make_buckets
   unsigned long long *keys;  // [nranges][nq]  (max << 32) | (0xFFFFFFFF - sub-chunk index in the range)
+  // Saturating sweep of the FLOAT engine (kSemF16 beyond its exact range, host_score.h make_buckets): every (query,
+  // sub-chunk) whose maximum reaches flag_value — the cell type's cap — is appended to flag_list; those sub-chunks are
+  // re-evaluated exactly afterwards (host_pipeline.h locate_saturated).  Null: not in use.
+  unsigned int *flag_count;
+  uint2 *flag_list;          // {query id, sub-chunk index in the range}
+  uint32_t flag_cap, flag_value;
   // strip-mined variant only (queries longer than 16*R rows): boundary rows between strips,
   // two ping-pong buffers of brow_stride dwords per tile, 16 dwords of front padding each
   uint32_t *brow;
@@ -410,6 +416,15 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
         }
       } else {
         uint32_t va = m32 & 0xFFFFu, vb = m32 >> 16;
+        if (a.flag_list != nullptr) {                                 // (positive float16 values order like their bits)
+          const unsigned int gsub = (unsigned int)(chunk * subs_per_tile + sub);
+          if (va >= a.flag_value) { const unsigned int at = atomicAdd(a.flag_count, 1u); if (at < a.flag_cap) a.flag_list[at] = make_uint2((unsigned int)qA, gsub); }
+          if (hasB && vb >= a.flag_value) { const unsigned int at = atomicAdd(a.flag_count, 1u); if (at < a.flag_cap) a.flag_list[at] = make_uint2((unsigned int)qB, gsub); }
+          if (TWIN && active2 && vb >= a.flag_value) {
+            const unsigned int at = atomicAdd(a.flag_count, 1u);
+            if (at < a.flag_cap) a.flag_list[at] = make_uint2((unsigned int)qA, gsub + (unsigned int)subs_per_tile);
+          }
+        }
         if (a.pubmax != 0u) { va = va > a.pubmax ? a.pubmax : va; vb = vb > a.pubmax ? a.pubmax : vb; }
         if (va > best_a) { best_a = va; key_max(k + qA, ((unsigned long long)va << 32) | tag); }
         if (hasB && vb > best_b) { best_b = vb; key_max(k + qB, ((unsigned long long)vb << 32) | tag); }

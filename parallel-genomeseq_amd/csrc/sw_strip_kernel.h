@@ -21,6 +21,9 @@
 // MODE kStripDirs : one greedy traceback decision per cell (smithwaterman.cpp:51-72), 2 bits, laid out
 //                   dirs[stream position][64 * strip + lane][W] dwords (W = 1 for R <= 16) — the layout of
 //                   sw_wave_kernel.h with 64*nstrips lanes instead of 16; sw_wave_walk_kernel reads both.
+// MODE kStripMax  : the MAXIMUM over the stream positions >= own_lo and the first cell holding it in the float engine's
+//                   storage order (similaritymatrix.cpp:21-28) -> *best, cell — for the sub-chunks in which the float
+//                   engine's saturating float16 score sweep reached its cap (host_pipeline.h locate_saturated).
 // MODE kStripTrack: the first cell in the engine's storage order (order_key<>, sw_exact_kernel.h) among the cells
 //                   equal to `target` at stream positions >= own_lo (the locate step of DESIGN.md §4).
 #pragma once
@@ -47,6 +50,7 @@ struct StripProblem {
   int64_t col_offset;    // true column of stream position t = col_offset + t + 1
   int64_t full_n;        // |y| of the full problem (uint8 storage order)
   int64_t *cell;         // [2] row, true column of the first cell equal to target; row 0 when none
+  float *best;           // kStripMax: the maximum (0 when no positive cell competes)
   int32_t *status;       // 0 = complete, 1 = a pipeline wait expired (result unusable)
   int32_t spg;           // > 0: the strips are dealt to several WORKGROUPS, spg consecutive strips each (one wavefront per
                          // strip, one round); the bottom row of a workgroup's last strip reaches the next workgroup
@@ -56,7 +60,7 @@ struct StripProblem {
                          // strip below it runs into the bounded wait and the workgroup takes the expiry path
 };
 
-enum : int { kStripDirs = 0, kStripTrack = 1 };
+enum : int { kStripDirs = 0, kStripTrack = 1, kStripMax = 2 };
 constexpr int kStripRing = 512;          // boundary positions held per strip (8 segments)
 constexpr int kStripMaxWaves = 16;
 constexpr int kStripSpinLimit = 1 << 22; // polls (with s_sleep) before a wait is declared dead
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
 
   unsigned long long bkey = ~0ull;                       // kStripTrack: this lane's first competing cell
   long long bi = 0, bj = 0;
+  float bval = 0.0f;                                     // kStripMax: this lane's best value so far
 
   auto wait_for = [&](long long *counter, long long need) {
     int spins = 0;
@@ -217,6 +222,8 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
             const uint32_t c_go = lowest != 0.0f ? 1u : 0u, c_nw = diag >= tmx ? 1u : 0u, c_w = wv >= north ? 1u : 0u;
             const uint32_t dir = c_go * (3u - c_w - c_nw * (2u - c_w));   // 0 stop, 1 NW, 2 W, 3 N
             dpack[r >> 4] |= (uint32_t)dir << (2 * (r & 15));
+          } else if (MODE == kStripMax) {
+            hit |= h >= bval && h > 0.0f;
           } else {
             hit |= h == P.target;
           }
@@ -238,6 +245,21 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
               if (i <= na) {
                 const unsigned long long key = U8 ? order_key<1>(i, j, na, P.full_n) : order_key<0>(i, j, na, P.full_n);
                 if (key < bkey) { bkey = key; bi = i; bj = j; }
+              }
+            }
+          }
+        }
+        if (MODE == kStripMax) {
+          // seldom: a cell reaches this lane's best so far (a later strip of the same lane sweeps the same columns again,
+          // so ties are settled by the storage-order key, not by time)
+          if (hit && t >= P.own_lo && t < nb) {
+            const long long j = P.col_offset + t + 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const long long i = (long long)(s * 64 + l) * R + r + 1;
+              if (H[r] >= bval && H[r] > 0.0f && i <= na) {
+                const unsigned long long key = order_key<0>(i, j, na, P.full_n);
+                if (H[r] > bval || key < bkey) { bval = H[r]; bkey = key; bi = i; bj = j; }
               }
             }
           }
@@ -280,6 +302,25 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
     __hip_atomic_store(&consumed[w], 0x7FFFFFFFFFFFFFFFll, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (!ok) *P.status = 1;
     if (multi && w == nw - 1) __hip_atomic_store(P.gcount + grp, 0x7FFFFFFFFFFFFFFFll, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (MODE == kStripMax) {
+    __shared__ float wval[kStripMaxWaves];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float ov = __shfl_xor(bval, off);
+      const unsigned long long ok2 = __shfl_xor(bkey, off);
+      const long long oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
+      if (ov > bval || (ov == bval && ok2 < bkey)) { bval = ov; bkey = ok2; bi = oi; bj = oj; }
+    }
+    if (l == 0) { wval[w] = bval; wkey[w] = bkey; wi[w] = bi; wj[w] = bj; }
+    __syncthreads();                                                     // every wavefront gets here: all waits are bounded
+    if (tid == 0) {
+      for (int k = 1; k < (int)(blockDim.x >> 6); ++k)
+        if (wval[k] > bval || (wval[k] == bval && wkey[k] < bkey)) { bval = wval[k]; bkey = wkey[k]; bi = wi[k]; bj = wj[k]; }
+      *P.best = bval;
+      P.cell[0] = bval > 0.0f ? bi : 0;
+      P.cell[1] = bval > 0.0f ? bj : 0;
+    }
   }
   if (MODE == kStripTrack) {
 #pragma unroll

@@ -880,3 +880,61 @@ def test_split_calls_on_the_single_alignment_chain(ctx, oracle, pgs):
                 _cmp(got, exp, ("split", npiece, sem, len(x)))
                 assert got["piece"] == exp["piece"]
         reads.pop()
+
+
+def test_float_engine_saturating_sweep(ctx, oracle, pgs):
+    """Float-engine reads beyond float16's exact range (match * (|x| + 1) > 2040, |x| <= 2048) are swept on packed
+    float16 cells that SATURATE at 2048; every sub-chunk whose maximum reaches the cap is re-evaluated exactly
+    (sw_strip_kernel in maximum mode) and the greatest exact value, first in storage order, wins (host_pipeline.h
+    locate_saturated).  Cases: hits far above the cap at several places with different true scores (the later, better
+    one must win), equal hits (the first one must win), a maximum of exactly 2048 and of 2046 / 2049, reads that never
+    reach the cap next to ones that do, lone calls, and a background that saturates everywhere (flag budget exceeded:
+    the exact int16 sweep takes over)."""
+    ref = bytearray(pgs.synth.dna(301, 200_000).tobytes())
+    def mutate(b, every, start):
+        b = bytearray(b)
+        for i in range(start, len(b), every):
+            b[i] = ord("ACGT"[("ACGT".index(chr(b[i])) + 1) % 4])
+        return bytes(b)
+    r1000 = bytes(ref[20_000:21_000])
+    ref[60_000:61_000] = mutate(r1000, 97, 40)                      # a worse copy first ... (both far above the cap)
+    ref[150_000:151_000] = r1000                                    # ... an exact copy later: three places, best = 20 000
+    ref[100_000:101_000] = mutate(r1000, 203, 11)
+    r1500 = bytes(ref[30_000:31_500])
+    ref[170_000:171_500] = r1500                                    # equal hits: the first wins
+    r2048 = bytes(ref[40_000:42_048])
+    refb = bytes(ref)
+    refa = np.frombuffer(refb, dtype=np.uint8)
+    reads = [r1000, mutate(r1000, 50, 7), r1500, r2048, bytes(ref[70_000:70_682]), bytes(ref[75_000:75_683]),
+             bytes(ref[80_000:80_700]), pgs.synth.dna(302, 900).tobytes(),
+             pgs.synth.read_from_ref(refa, 303, 1200, sub_rate=0.05, indel_rate=0.01)[0].tobytes(),
+             pgs.synth.read_from_ref(refa, 304, 2000, sub_rate=0.25, indel_rate=0.05)[0].tobytes()]
+    exp = [oracle.align(q, refb, 0) for q in reads]
+    got = ctx.align_batch(reads, refb, semantics=0)
+    name = ctx.last_kernel()["name"]
+    for k, (g, e) in enumerate(zip(got, exp)):
+        _cmp(g, e, ("saturating sweep", k, len(reads[k])))
+    assert "f16x2" in name and "saturating" in name, name
+    assert exp[0]["score"] == 3000.0 and exp[4]["score"] == 2046.0 and exp[5]["score"] == 2049.0
+    _cmp(ctx.align(r1500, refb, 0), exp[2], "lone 1500")
+    # exactly 2048 (the cap itself) and fractional scorings on the same path
+    q512 = [bytes(ref[90_000:90_512]), bytes(ref[95_000:95_513]), mutate(bytes(ref[110_000:110_600]), 61, 3)]
+    for sc in ((4.0, -3.0, 2.0), (3.5, -2.25, 1.75), (12.0, -9.0, 5.0)):
+        got = ctx.align_batch(q512 + reads[:2], refb, semantics=0, match=sc[0], mismatch=sc[1], gap=sc[2])
+        for q, g in zip(q512 + reads[:2], got):
+            _cmp(g, oracle.align(q, refb, 0, *sc), ("saturating sweep", sc, len(q)))
+    # a background that reaches the cap in a wide region: many flagged sub-chunks, all re-evaluated exactly
+    poly = bytearray(refb)
+    poly[100_000:180_000] = b"A" * 80_000
+    poly = bytes(poly)
+    pa = [b"A" * 800, b"A" * 700 + bytes(ref[10_000:10_200]), r1000]
+    got = ctx.align_batch(pa, poly, semantics=0)
+    for q, g in zip(pa, got):
+        _cmp(g, oracle.align(q, poly, 0), ("saturated region", len(q)))
+    # ... and everywhere: more flags than the budget (64 per query + 1024), the exact int16 sweep runs instead
+    poly = b"A" * 450_000
+    pa = [b"A" * 800, b"A" * 750 + b"C" + b"A" * 20, b"A" * 700]
+    got = ctx.align_batch(pa, poly, semantics=0)
+    assert "i16x2" in ctx.last_kernel()["name"], ctx.last_kernel()["name"]
+    for q, g in zip(pa, got):
+        _cmp(g, oracle.align(q, poly, 0), ("saturated background", len(q)))
