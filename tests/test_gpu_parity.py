@@ -933,7 +933,7 @@ def test_float_engine_saturating_sweep(ctx, oracle, pgs):
         _cmp(g, oracle.align(q, poly, 0), ("saturated region", len(q)))
     # ... and everywhere: more flags than the budget (64 per query + 1024), the exact int16 sweep runs instead
     poly = b"A" * 450_000
-    pa = [b"A" * 800, b"A" * 750 + b"C" + b"A" * 20, b"A" * 700]
+    pa = [b"A" * 800, b"A" * 750 + b"C" + b"A" * 49, b"A" * 799 + b"C", b"C" + b"A" * 799]
     got = ctx.align_batch(pa, poly, semantics=0)
     assert "i16x2" in ctx.last_kernel()["name"], ctx.last_kernel()["name"]
     for q, g in zip(pa, got):
