@@ -30,6 +30,7 @@ struct Bucket {
   int sem = kSemI16;          // kernel instance: kSemI16 / kSemU8 packed pairs, kSemF32 one query per slot
   bool strips = false;        // queries longer than one 512-row strip
   bool twin = false;          // lone long query: two tiles of it per packed register (sw_score_kernel TWIN)
+  bool comb = false;          // twin on 16-lane tiles, small alphabet: profile indexed by the pair of codes (COMB)
   bool unsat = false;         // uint8 engine swept by a float-engine instance WITHOUT saturation, maxima clamped at 255
   bool satflag = false;       // float engine swept on float16 cells BEYOND their exact range (the sweep saturates at 2048):
                               // sub-chunks that reach the cap are flagged and re-evaluated exactly (locate_saturated)
@@ -133,8 +134,16 @@ ScoreTable plan_table(const RefData &ref, const mi355_sw_params &p) {
   return f;
 }
 
-size_t profile_lds_bytes(int ncodes, int R, int SL = 16, bool twin = false) {
+size_t profile_lds_bytes(int ncodes, int R, int SL = 16, bool twin = false, bool comb = false) {
+  if (comb) return (size_t)ncodes * (size_t)ncodes * (size_t)std::max(16, SL) * lane_stride(R) * 4;
   return (size_t)ncodes * (size_t)std::max(16, SL) * lane_stride(twin ? R / 2 : R) * 4;
+}
+// twin tiles on 16-lane slots with the profile indexed by code PAIRS: while the ncodes^2 entries leave room for two
+// workgroups per CU (DNA incl. N and the pad code: 36 pairs)
+constexpr size_t kCombLdsMax = 64 * 1024;
+bool comb_ok(int ncodes, int R) {
+  static const bool off = std::getenv("MI355_SW_NO_COMB") != nullptr;
+  return !off && profile_lds_bytes(ncodes, R, 16, true, true) <= kCombLdsMax;
 }
 
 // Length classes of the batch: one bucket per kernel instance (R), plus one strip-mined bucket.
@@ -179,7 +188,9 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       // locate and traceback keep the saturating rule.
       if (std::getenv("MI355_SW_NO_UNSAT") == nullptr && std::getenv("MI355_SW_NO_F16") == nullptr && !t.htab.empty() && t.gap <= 2040) {
         if (b.count >= 2) { b.sem = kSemF16; b.unsat = true; b.twin = false; }
-        else if (twin16_ok && !b.strips && b.SL != 64) { b.sem = kSemF16; b.unsat = true; b.twin = true; b.SL = 16; b.R = pick_R(b.maxlen); }
+        else if (twin16_ok && !b.strips && b.SL != 64) {
+          b.sem = kSemF16; b.unsat = true; b.twin = true; b.SL = 16; b.R = pick_R(b.maxlen); b.comb = comb_ok(ref.ncodes, b.R);
+        }
         else if (twin_ok) { b.sem = kSemF16; b.unsat = true; b.twin = true; }
       }
     } else {
@@ -208,7 +219,7 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       // ... except a short one with small scores: two of its TILES per packed float16 register on 16-lane tiles
       if (b.count == 1 && b.sem == kSemI16 && twin16_ok && !t.htab.empty() && !b.strips && b.SL != 64 &&
           (int64_t)t.smax * b.maxlen + t.smax <= 2040 && std::getenv("MI355_SW_NO_F16") == nullptr) {
-        b.sem = kSemF16; b.twin = true; b.SL = 16; b.R = pick_R(b.maxlen);
+        b.sem = kSemF16; b.twin = true; b.SL = 16; b.R = pick_R(b.maxlen); b.comb = comb_ok(ref.ncodes, b.R);
       }
       else if (b.count == 1 && b.sem == kSemI16 && twin_ok && std::getenv("MI355_SW_LONG_TWIN") != nullptr) b.twin = true;   // A/B switch
       else if (b.count == 1 && b.sem == kSemI16 && (double)t.smax * b.maxlen < 1.6e7) b.sem = kSemF32;
@@ -259,7 +270,7 @@ double valu_ops_per_cell(const Bucket &b) {
     case kSemU8:    per_step = 5.0 * R + (R + 1) / 2 + R % 2 + over; break;
     default:        per_step = 4.0 * R + (R + 1) / 2 + R % 2 + over; break;
   }
-  if (b.twin) per_step += R;                                                                    // one v_perm_b32 per row
+  if (b.twin && !b.comb) per_step += R;                                                         // one v_perm_b32 per row
   return per_step / (double)(cells_per_row * R);
 }
 
@@ -290,7 +301,15 @@ int launch_score_twin(int R, bool strips, dim3 grid, size_t shmem, hipStream_t s
 }
 
 // a lone short query on 16-lane tiles, two TILES of it per packed float16 register
-int launch_score_twin16(int R, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
+int launch_score_twin16(int R, bool comb, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
+  if (comb) {
+    switch (R) {
+#define CASE_C16(r) case r: launch_score(sw_score_kernel<r, kSemF16, false, 16, true, true>, grid, shmem, st, a); return 0;
+      CASE_C16(2) CASE_C16(4) CASE_C16(6) CASE_C16(8) CASE_C16(10) CASE_C16(12) CASE_C16(16) CASE_C16(20) CASE_C16(24) CASE_C16(32)
+#undef CASE_C16
+    }
+    return -1;
+  }
   switch (R) {
 #define CASE_T16(r) case r: launch_score(sw_score_kernel<r, kSemF16, false, 16, true>, grid, shmem, st, a); return 0;
     CASE_T16(2) CASE_T16(4) CASE_T16(6) CASE_T16(8) CASE_T16(10) CASE_T16(12) CASE_T16(16) CASE_T16(20) CASE_T16(24) CASE_T16(32)
@@ -549,7 +568,7 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   const size_t pn = std::min(pairs_per_launch, npairs - p0);
   a.qfirst = b.first + (int)(p0 * nqw);
   a.qcount = std::min(b.count - (int)(p0 * nqw), (int)(pn * nqw));
-  size_t shmem = profile_lds_bytes(ref.ncodes, b.R, b.SL, b.twin) + (size_t)(b.twin ? 2 : 1) * nslot * codebuf_bytes(b.SL);
+  size_t shmem = profile_lds_bytes(ref.ncodes, b.R, b.SL, b.twin, b.comb) + (size_t)(b.twin ? 2 : 1) * nslot * codebuf_bytes(b.SL);
   dim3 grid((unsigned)(pn * cgroups), (unsigned)nr);
   a.brow = nullptr;
   a.brow_stride = 0;
@@ -571,7 +590,7 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   }
   HIPCHK(ctx, hipEventRecord(ctx->score_ev[ctx->score_ev_used], ctx->stream));
   int rc = b.twin ? (b.sem == kSemF16 ? (b.SL == 64 ? launch_score_twin<kSemF16>(b.R, b.strips, grid, shmem, ctx->stream, a)
-                                                    : launch_score_twin16(b.R, grid, shmem, ctx->stream, a))
+                                                    : launch_score_twin16(b.R, b.comb, grid, shmem, ctx->stream, a))
                      : b.sem == kSemU8H ? launch_score_twin<kSemU8H>(b.R, b.strips, grid, shmem, ctx->stream, a)
                      : b.sem == kSemU8 ? launch_score_twin<kSemU8>(b.R, b.strips, grid, shmem, ctx->stream, a)
                                        : launch_score_twin<kSemI16>(b.R, b.strips, grid, shmem, ctx->stream, a))
@@ -598,7 +617,7 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     ki.valu_ops_per_cell = valu_ops_per_cell(b);
     static const char *cellname[] = {"i16x2", "u8 as i16x2", "f32", "u8 as f32", "f16x2", "u8 as f16x2"};
     std::snprintf(ki.name, sizeof ki.name, "sw_score_kernel<R=%d, %s, SL=%d%s%s>%s", b.R, cellname[b.sem], b.SL,
-                  b.strips ? ", strips" : "", b.twin ? ", twin" : "",
+                  b.strips ? ", strips" : "", b.twin ? (b.comb ? ", twin, code-pair profile" : ", twin") : "",
                   b.unsat ? " uint8 engine swept unsaturated, maxima clamped at 255"
                           : b.satflag ? " float engine swept saturating at 2048, saturated sub-chunks re-evaluated exactly" : "");
   }

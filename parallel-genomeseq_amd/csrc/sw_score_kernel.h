@@ -210,13 +210,18 @@ __device__ __forceinline__ uint32_t row_shr1(uint32_t v) {
 // TWIN = true (packed instances, SL = 64): ONE query per workgroup; the two halves of every register hold two
 // neighbouring TILES of it (chunks 2T and 2T+1).  The halves then see different reference codes, so the profile
 // holds 16-bit scores and a step reads it twice (once per code); one v_perm_b32 per row merges the two reads.
-template <int R, int SEM, bool STRIPS = false, int SL = 16, bool TWIN = false>
+// COMB = true (with TWIN, small alphabets): the profile is indexed by the PAIR of codes the two tiles see
+// (ncodes^2 entries of ready-made packed pairs), so a step reads it once and needs no merge — the cell costs what it
+// costs in the two-query instances.
+template <int R, int SEM, bool STRIPS = false, int SL = 16, bool TWIN = false, bool COMB = false>
 __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   static_assert(SL == 64 || SL == 16 || SL == 8, "a slot is a whole wavefront, a DPP row or half a DPP row");
   static_assert(!(STRIPS && SL == 8), "the strip-mined instances use whole DPP rows or whole wavefronts");
   static_assert(!TWIN || ((SL == 64 || SL == 16) && !sem_is_float(SEM) && R % 2 == 0), "twin tiles: packed cells on whole-wavefront or 16-lane tiles");
-  constexpr int LS = TWIN ? lane_stride(R / 2) : lane_stride(R);    // dwords between the profile rows of adjacent lanes
-  constexpr int NQ4 = TWIN ? (R / 2 + 3) / 4 : (R + 3) / 4;
+  static_assert(!COMB || (TWIN && !STRIPS), "the code-pair profile belongs to the twin instances");
+  constexpr bool HALF = TWIN && !COMB;                             // the profile holds 16-bit entries, two rows per dword
+  constexpr int LS = HALF ? lane_stride(R / 2) : lane_stride(R);   // dwords between the profile rows of adjacent lanes
+  constexpr int NQ4 = HALF ? (R / 2 + 3) / 4 : (R + 3) / 4;
   constexpr int NSLOT = 256 / SL;                                  // tiles per workgroup
   constexpr int CPL = kSeg / SL;                                   // reference codes fetched per lane per segment
   constexpr int PL = SL > 16 ? SL : 16;                            // lane positions of the profile
@@ -224,8 +229,8 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
   constexpr int CB = codebuf_bytes(SL);
   constexpr int VPL = kSeg / SL >= 4 ? 4 : 1;                      // boundary-row values moved per lane per segment
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  uint32_t *prof = smem;                                           // [ncodes][PL lane positions][LS]
-  uint8_t *codebuf = reinterpret_cast<uint8_t *>(smem + a.ncodes * PL * LS);
+  uint32_t *prof = smem;                                           // [ncodes (COMB: ncodes^2)][PL lane positions][LS]
+  uint8_t *codebuf = reinterpret_cast<uint8_t *>(smem + (COMB ? a.ncodes * a.ncodes : a.ncodes) * PL * LS);
   // STRIPS: [NSLOT][64] boundary-in window, then [NSLOT][64] boundary-out staging
   uint32_t *bwin = reinterpret_cast<uint32_t *>(codebuf + (TWIN ? 2 : 1) * NSLOT * CB);
 
@@ -251,12 +256,22 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
     const uint8_t *xA = a.qbytes + a.qoff[qA];
     const uint8_t *xB = a.qbytes + a.qoff[qB];
     const int per_code = PL * R;
-    for (int e = tid; e < a.ncodes * per_code; e += 256) {
+    for (int e = tid; e < (COMB ? a.ncodes * a.ncodes : a.ncodes) * per_code; e += 256) {
       const int c = e / per_code;
       const int rem = e - c * per_code;
       const int ll = rem / R, r = rem - ll * R;
       const int i = row0 + (ll & (SL - 1)) * R + r;
       uint32_t e32;
+      if (COMB) {
+        // entry (cA * ncodes + cB): low half = this row against the first tile's code, high half = against the second's
+        const int16_t *st = static_cast<const int16_t *>(a.stab);
+        constexpr int kPadEntry = SEM == kSemF16 ? (int)(int16_t)0xC800 : (SEM == kSemU8H ? (int)(int16_t)0xD400 : kPadScore);
+        const int cA = c / a.ncodes, cB = c - cA * a.ncodes;
+        const int sa = (i < mA) ? st[(int)xA[i] * a.ncodes + cA] : kPadEntry;
+        const int sb = (i < mA) ? st[(int)xA[i] * a.ncodes + cB] : kPadEntry;
+        prof[(c * PL + ll) * LS + r] = (uint32_t)(uint16_t)sa | ((uint32_t)(uint16_t)sb << 16);
+        continue;
+      }
       if (TWIN) {
         const int16_t *st = static_cast<const int16_t *>(a.stab);
         const int sa = (i < mA) ? st[(int)xA[i] * a.ncodes + c]
@@ -504,10 +519,10 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
     for (int seg = 0; seg < nseg; ++seg) {
 #pragma unroll 4
       for (int k = 0; k < kSeg; ++k) {
-        const uint32_t c = buf_lane[k];
+        const uint32_t c = COMB ? (uint32_t)buf_lane[k] * (uint32_t)a.ncodes + (uint32_t)buf2_lane[k] : (uint32_t)buf_lane[k];
         const u32x4 *pp = static_cast<const u32x4 *>(__builtin_assume_aligned(prof_lane + c * code_stride, 16));
-        uint32_t p[TWIN ? R : NQ4 * 4];
-        if (TWIN) {
+        uint32_t p[HALF ? R : NQ4 * 4];
+        if (HALF) {
           // 16-bit scores of this lane's rows for the two tiles' codes, merged row by row: low half = first tile
           const u32x4 *pp2 = static_cast<const u32x4 *>(__builtin_assume_aligned(prof_lane + (uint32_t)buf2_lane[k] * code_stride, 16));
           uint32_t d1[NQ4 * 4], d2[NQ4 * 4];
