@@ -61,7 +61,7 @@ while time.time() - t0 < budget:
         tick = time.time()
         print("... %d cases, %d mismatches, %.0f s" % (ncase, nbad, tick - t0), flush=True)
     alpha = ALPH[int(rng.integers(0, len(ALPH)))]
-    kind = int(rng.integers(0, 12))
+    kind = int(rng.integers(0, 13))
     ma, mi, gp = SC[int(rng.integers(0, len(SC)))]
     sem = int(rng.integers(0, 2))
     if kind <= 5:       # single alignment, oracle cost bounded to ~3e8 cells
@@ -87,6 +87,33 @@ while time.time() - t0 < budget:
                   (len(q), n, sem, (ma, mi, gp), lut is not None, len(alpha), bad, {k: got[k] for k in bad[:2]},
                    {k: exp[k] for k in bad[:2]}), flush=True)
         ncase += 1
+    elif kind == 12:    # float engine beyond float16's exact range: the saturating sweep + re-evaluated flags
+        n = int(rng.choice([20000, 60000, 120000]))
+        ref = bytearray(rseq(n, alpha))
+        base = int(rng.choice([690, 800, 1000, 1024, 1500, 2048]))
+        qs = []
+        for _ in range(int(rng.integers(2, 7))):
+            m = max(1, base - int(rng.integers(0, 8)))
+            q = plant(bytes(ref), m, alpha)
+            qs.append(q)
+            if rng.random() < 0.4 and len(q) + 10 < n:     # the same hit again somewhere else (ties / better copies)
+                at = int(rng.integers(0, n - len(q)))
+                ref[at:at + len(q)] = q
+        if rng.random() < 0.15:
+            c = alpha[:1]
+            at = int(rng.integers(0, n // 2))
+            ref[at:at + n // 3] = c * (n // 3)             # a background that saturates in a wide region
+            qs[0] = c * len(qs[0])
+        ref = bytes(ref)
+        res = ctx.align_batch(qs, ref, semantics=0, match=ma, mismatch=mi, gap=gp)
+        for q, got in zip(qs, res):
+            exp = ob.align(q, ref, 0, ma, mi, gp)
+            bad = [k for k in KEYS if got[k] != exp[k]]
+            if bad:
+                nbad += 1
+                print("MISMATCH long batch |q|=%d n=%d sc=%s keys=%s got=%s exp=%s" % (len(q), n, (ma, mi, gp), bad,
+                      {k: got[k] for k in bad[:2]}, {k: exp[k] for k in bad[:2]}), flush=True)
+            ncase += 1
     elif kind <= 7:     # ragged batch
         n = int(rng.choice([1500, 20000, 150000]))
         ref = rseq(n, alpha)
