@@ -404,7 +404,7 @@ int64_t score_sub_len(int semantics, const Bucket &b) {
 }
 
 int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int SL = 16, bool twin = false, int maxlen = 0,
-                       int64_t sub_len = 0) {
+                       int64_t sub_len = 0, int64_t quant = 0) {
   int64_t cl = 65536;
   while (cl < 8 * warm) cl *= 2;                 // long queries: keep the warm-up redundancy bounded
   // fill the chip: 256 CUs x 32 waves x 4 slots; shrink tiles while they stay >> warm-up
@@ -423,6 +423,33 @@ int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int S
                                                                                        // 0.30 ms per 150 bp x 1 Mbp call at 128 columns, 0.33 at 256)
   const double per_wg = 256.0 / SL * (twin ? 2.0 : 1.0);
   while (cl / 2 >= floor_cl && (double)npairs * (double)((max_range_len + cl - 1) / cl) / per_wg < 256.0) cl /= 2;
+  // Few workgroups per CU: the launch's duration is (workgroups per CU, rounded UP) x (one tile's sweep), so a tile length
+  // that lets the workgroup count land just under a multiple of the 256 CUs beats the power of two next to it
+  // (50 Mbp, one 400 bp read: 763 workgroups of 2048-column tiles = 3 per CU, 509 of 3072-column tiles = 2 per CU:
+  // 2.54 -> 2.14 ms; config 5: 131072 -> 122880 columns).  Candidates are multiples of `quant` (the sub-chunk length).
+  static const bool no_quant = std::getenv("MI355_SW_NO_QUANT") != nullptr;
+  if (quant > 0 && !no_quant) {
+    const int64_t tiles_per_wg = (int64_t)per_wg;
+    auto rounds = [&](int64_t c) {
+      const int64_t tiles = (max_range_len + c - 1) / c;
+      const double wgs = (double)npairs * (double)((tiles + tiles_per_wg - 1) / tiles_per_wg);
+      return std::ceil(wgs / 256.0);
+    };
+    auto cost = [&](int64_t c) { return rounds(c) * (double)(c + warm + SL); };
+    const double r0 = rounds(cl);
+    if (r0 <= 8.0) {
+      const double need_rounds = std::min(2.0, r0);                // keep two workgroups per CU where there were two
+      int64_t best = cl;
+      double best_cost = cost(cl) * 0.96;                          // switch for >= 4 % (predicted)
+      const int64_t lo = std::max<int64_t>({quant, floor_cl, (cl / 2 + quant - 1) / quant * quant});
+      for (int64_t c = lo; c <= 2 * cl; c += quant) {
+        if (rounds(c) < need_rounds) continue;
+        const double k = cost(c);
+        if (k < best_cost) { best_cost = k; best = c; }
+      }
+      cl = best;
+    }
+  }
   if (const char *e = std::getenv("MI355_SW_CHUNK")) { const long v = std::atol(e); if (v >= 64) cl = v / 64 * 64; }   // tuning aid
   return cl;
 }
@@ -511,7 +538,12 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   // report maxima per sub-chunk of >= 256 columns (>= query length, so that the uint8 storage order stays
   // within two neighbouring sub-chunks): that is what locate re-runs; the strip-mined instance reports per tile
   b.sub_len = score_sub_len(p.semantics, b);
-  b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm, b.SL, b.twin, b.maxlen, b.sub_len);
+  // float engine, strip-mined: the sub-chunk is any multiple of 64 columns (1/64 of the tile: the strip-mined instances keep
+  // <= 64 sub-chunk maxima in LDS); the uint8 engine's stays a power of two >= |x| (storage order, see above)
+  const bool free_sub = p.semantics == MI355_SW_F32 && b.strips;
+  b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm, b.SL, b.twin, b.maxlen, b.sub_len,
+                               free_sub ? 64 * kSeg : (b.strips ? 0 : b.sub_len));
+  if (free_sub && b.chunk_len % (64 * kSeg) == 0) b.sub_len = b.chunk_len / 64;
   if (b.strips) while (b.chunk_len / b.sub_len > 64) b.sub_len *= 2;      // the strip-mined instances keep <= 64 sub-chunk maxima in LDS
   if (b.sub_len > b.chunk_len || b.chunk_len % b.sub_len != 0) b.sub_len = b.chunk_len;
   const int64_t cpr = (maxlen + b.chunk_len - 1) / b.chunk_len;
