@@ -191,6 +191,13 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
         else if (twin16_ok && !b.strips && b.SL != 64) {
           b.sem = kSemF16; b.unsat = true; b.twin = true; b.SL = 16; b.R = pick_R(b.maxlen); b.comb = comb_ok(ref.ncodes, b.R);
         }
+        // a lone LONG query (whole-wavefront tiles): the float engine's float32 cell (three ops per cell, one query per
+        // register; exact below 2^24), unsaturated and clamped at 255 the same way, sweeps it faster than two tiles per packed
+        // float16 register, whose halves need two profile reads and a merge op per row (config 5: 265 against 288 ms;
+        // 4096 rows x 50 Mbp: 26 against 34 ms).  MI355_SW_U8_LONG_TWIN=1 restores the twin tiles.
+        else if (b.count == 1 && b.SL == 64 && (double)t.smax * b.maxlen < 1.6e7 && std::getenv("MI355_SW_U8_LONG_TWIN") == nullptr) {
+          b.sem = kSemF32; b.unsat = true; b.twin = false;
+        }
         else if (twin_ok) { b.sem = kSemF16; b.unsat = true; b.twin = true; }
       }
     } else {
@@ -439,13 +446,18 @@ int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int S
     const double r0 = rounds(cl);
     if (r0 <= 8.0) {
       const double need_rounds = std::min(2.0, r0);                // keep two workgroups per CU where there were two
+      // switch for a predicted gain of >= 4 %; >= 7 % when it costs a workgroup per CU (fewer wavefronts to hide latency
+      // behind: measured, 1000-row float32 tiles 3 -> 2 per CU: predicted -5 %, measured +3 %)
+      const double base = cost(cl);
       int64_t best = cl;
-      double best_cost = cost(cl) * 0.96;                          // switch for >= 4 % (predicted)
+      double best_gain = 0.0;
       const int64_t lo = std::max<int64_t>({quant, floor_cl, (cl / 2 + quant - 1) / quant * quant});
       for (int64_t c = lo; c <= 2 * cl; c += quant) {
-        if (rounds(c) < need_rounds) continue;
-        const double k = cost(c);
-        if (k < best_cost) { best_cost = k; best = c; }
+        const double rc = rounds(c);
+        if (rc < need_rounds) continue;
+        const double gain = 1.0 - cost(c) / base;
+        if (gain < (rc < r0 ? 0.07 : 0.04)) continue;
+        if (gain > best_gain) { best_gain = gain; best = c; }
       }
       cl = best;
     }
@@ -541,8 +553,12 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   // float engine, strip-mined: the sub-chunk is any multiple of 64 columns (1/64 of the tile: the strip-mined instances keep
   // <= 64 sub-chunk maxima in LDS); the uint8 engine's stays a power of two >= |x| (storage order, see above)
   const bool free_sub = p.semantics == MI355_SW_F32 && b.strips;
-  b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm, b.SL, b.twin, b.maxlen, b.sub_len,
-                               free_sub ? 64 * kSeg : (b.strips ? 0 : b.sub_len));
+  if (b.strips && !free_sub) {
+    // the candidates of the refinement below reach twice the unrefined tile length: settle the sub-chunk for that first
+    const int64_t cl0 = pick_chunk_len(maxlen, npairs * nr, b.warm, b.SL, b.twin, b.maxlen, b.sub_len, 0);
+    while (2 * cl0 / b.sub_len > 64) b.sub_len *= 2;
+  }
+  b.chunk_len = pick_chunk_len(maxlen, npairs * nr, b.warm, b.SL, b.twin, b.maxlen, b.sub_len, free_sub ? 64 * kSeg : b.sub_len);
   if (free_sub && b.chunk_len % (64 * kSeg) == 0) b.sub_len = b.chunk_len / 64;
   if (b.strips) while (b.chunk_len / b.sub_len > 64) b.sub_len *= 2;      // the strip-mined instances keep <= 64 sub-chunk maxima in LDS
   if (b.sub_len > b.chunk_len || b.chunk_len % b.sub_len != 0) b.sub_len = b.chunk_len;
