@@ -363,7 +363,7 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
     // one launch per kernel instance (rows per lane)
     for (int R : {3, 5, 8, 10, 16}) {
       std::vector<WaveJob> group;
-      for (const WaveJob &j : sjobs) if (strip_R(q.len[j.q]) == R) group.push_back(j);
+      for (const WaveJob &j : sjobs) if (strip_R_few(q.len[j.q], sjobs.size(), true) == R) group.push_back(j);
       for (size_t lo = 0; lo < group.size(); lo += 4096) {
         std::vector<WaveJob> part(group.begin() + lo, group.begin() + std::min(group.size(), lo + 4096));
         int rc = run_strip(ctx, ref, q, rg, p, part, R);
@@ -407,7 +407,7 @@ int locate_saturated(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
   std::vector<unsigned long long> bestkey(q.nq, ~0ull);
   for (int R : {3, 5, 8, 10, 16}) {
     std::vector<WaveJob> group;
-    for (const WaveJob &j : jobs) if (strip_R(q.len[j.q]) == R) group.push_back(j);
+    for (const WaveJob &j : jobs) if (strip_R_few(q.len[j.q], jobs.size(), true) == R) group.push_back(j);
     for (size_t lo = 0; lo < group.size(); lo += 4096) {
       std::vector<WaveJob> part(group.begin() + lo, group.begin() + std::min(group.size(), lo + 4096));
       int rc = run_strip(ctx, ref, q, rg, p, part, R);

@@ -125,7 +125,22 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
 // concurrently; longer queries take several rounds).
 // Short queries get a whole wavefront with few rows per lane (latency mode, below): the recurrence's dependent chain
 // per step is R rows long, so 64 lanes x 3 rows sweep a 150 bp window three times faster than 16 lanes x 10 rows.
+inline int strip_count_of(int na, int R) { return std::max(1, (na + 64 * R - 1) / (64 * R)); }
 int strip_R(int na) { return na <= 192 ? 3 : (na <= 320 ? 5 : (na <= 512 ? 8 : (na <= 64 * kStripMaxWaves * 10 ? 10 : 16))); }
+// A FEW long problems (a lone read of 513+ rows: locate and traceback of one alignment are latency-bound on ONE workgroup):
+// the fewest rows per lane whose strips still run concurrently — sixteen wavefronts in the tracking modes, any number in
+// the decision mode, whose strips are dealt to several workgroups (run_strip) — because a step's dependent chain is R
+// rows long and more, shorter strips pipeline over more SIMDs.
+constexpr size_t kFewJobs = 64;            // fewer problems than a quarter of the CUs
+int strip_R_few(int na, size_t njobs, bool track) {
+  if (njobs > kFewJobs || na <= 512 || na > 64 * kStripMaxWaves * 10) return strip_R(na);
+  static const int forced = [] { const char *e = std::getenv("MI355_SW_FEW_R"); return e ? std::atoi(e) : 0; }();   // tuning aid
+  if (forced == 3 || forced == 5 || forced == 8 || forced == 10 || forced == 16) return forced;
+  static const int rs[] = {3, 5, 8, 10, 16};
+  if (!track) return na <= 2560 ? 3 : 5;
+  for (int r : rs) if (strip_count_of(na, r) <= kStripMaxWaves) return r;
+  return 16;
+}
 constexpr size_t kLatencyJobs = 64;            // up to this many short problems per call run in latency mode
 int strip_count(int na, int R) { return std::max(1, (na + 64 * R - 1) / (64 * R)); }
 size_t strip_dirs_bytes(int64_t nb, int nstrips, int R) { return (size_t)nb * 64 * (size_t)nstrips * (size_t)((R + 15) / 16) * 4 + 64; }
@@ -309,7 +324,8 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         const int64_t a_end = orient == 0 ? loc[k].ix : loc[k].iy;   // lane-side index of the argmax
         const int64_t wl = std::max<int64_t>(0, s_end - (budget[k] + std::min(warm[k], lane_need(a_end))));
         const int64_t nb = s_end - wl;
-        const size_t need = strips ? strip_dirs_bytes(nb, strip_count((int)na, 5), 5)
+        const int rfew = strip_R_few((int)na, 1, false);        // the instance with the most decision bytes this job can get
+        const size_t need = strips ? strip_dirs_bytes(nb, strip_count((int)na, rfew), rfew)
                                    : wave_dirs_bytes(nb, 32);      // upper bound whatever instance the group gets
         if (need > kDirsBudget) return fail(ctx, MI355_SW_ENOTSUP, "traceback window exceeds the device scratch budget");
         if (!jobs.empty() && bytes + need > kDirsBudget) break;
@@ -323,8 +339,8 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
       for (const WaveJob &j : jobs) gmax = std::max(gmax, orient == 0 ? q.len[j.q] : (int)nref);
       int groupR = strips ? strip_R(gmax) : wave_R(gmax);           // the instance this group runs on
       // a few long alignments whose strips are dealt to several workgroups (run_strip): five rows per lane make twice
-      // the strips, i.e. twice the workgroups, of ten (config 5: 32 strips on 8 CUs)
-      if (strips && groupR == 10 && jobs.size() <= 8 && gmax > 2560 && std::getenv("MI355_SW_NO_STRIP_GROUPS") == nullptr) groupR = 5;
+      // the strips, i.e. twice the workgroups, of ten (config 5: 32 strips on 8 CUs); three below 2560 rows
+      if (strips && std::getenv("MI355_SW_NO_STRIP_GROUPS") == nullptr) groupR = strip_R_few(gmax, jobs.size(), false);
       int rc = strips ? run_strip(ctx, ref, q, rg, p, jobs, groupR) : run_wave(ctx, ref, q, rg, p, jobs);
       if (rc) return rc;
       // walk: measure, lay out, write (only the bytes that exist are copied back)
