@@ -25,6 +25,8 @@ for cfg in "1000000 0" "1000000 1" "50000000 0" "50000000 1"; do
   set -- $cfg
   rocprofv3 --kernel-trace --stats -d $OUT/kt_lat_$1_$2 --output-format csv -- python3 $R/tools/lat_probe.py $1 $2 > $OUT/lat_$1_$2.log 2>&1
 done
+python3 $R/tools/lone_probe.py > $OUT/lone_reads_by_length.log 2>&1
+python3 $R/tools/lone_short.py > $OUT/lone_short_reads.log 2>&1
 cd $R
 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 for t in bench_FETCH_SIZE:bench_WRITE_SIZE:bench_SQ_INSTS_VALU:bench_SQ_INSTS_LDS wide600_SQ_INSTS_VALU:wide600_SQ_INSTS_LDS u8_2048_SQ_INSTS_VALU:u8_2048_SQ_INSTS_LDS f32_2048_SQ_INSTS_VALU:f32_2048_SQ_INSTS_LDS; do
