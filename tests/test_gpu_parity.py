@@ -938,3 +938,25 @@ def test_float_engine_saturating_sweep(ctx, oracle, pgs):
     assert "i16x2" in ctx.last_kernel()["name"], ctx.last_kernel()["name"]
     for q, g in zip(pa, got):
         _cmp(g, oracle.align(q, poly, 0), ("saturated background", len(q)))
+
+
+def test_lone_reads_by_length_with_n(ctx, oracle, pgs):
+    """One read per call — the reference drivers' unchanged loop — at 120 .. 2048 bp against a reference that contains `N`
+    (six codes with the pad code: the code-pair profile of the twin tiles holds 36 pairs), both engines: the single-alignment
+    chain (<= 320 rows), twin tiles with the code-pair profile (<= 512 rows), float32 cells on whole-wavefront tiles beyond,
+    tile lengths off the power of two, and the few-problem strip instances of locate / traceback."""
+    rng = np.random.default_rng(2024)
+    ref = pgs.synth.dna(611, 300_000).copy()
+    ref[rng.integers(0, len(ref), 600)] = ord("N")
+    ref[150_000:150_040] = ord("N")
+    refb = ref.tobytes()
+    for k, m in enumerate((120, 150, 333, 400, 700, 1000, 2048)):
+        q = pgs.synth.read_from_ref(ref, 620 + k, m, sub_rate=0.03, indel_rate=0.005)[0].copy()
+        q[rng.integers(0, len(q), max(1, m // 60))] = ord("N")
+        qb = q.tobytes()
+        for sem in (0, 1):
+            _cmp(ctx.align(qb, refb, sem), oracle.align(qb, refb, sem), ("lone read", m, sem))
+    name = ctx.last_kernel()["name"]
+    qb = pgs.synth.read_from_ref(ref, 640, 150)[0].tobytes()
+    _cmp(ctx.align(qb, refb, 0), oracle.align(qb, refb, 0), "lone 150")
+    assert "code-pair profile" in ctx.last_kernel()["name"], (name, ctx.last_kernel()["name"])
