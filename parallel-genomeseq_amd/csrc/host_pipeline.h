@@ -456,16 +456,18 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
     std::vector<Bucket> buckets;
     // the float engine's saturating float16 sweep (make_buckets) needs the strip kernel for its flagged sub-chunks
     bool allow_sat = p.semantics == MI355_SW_F32 && strip_scoring_ok(ref, p);
+    // ... and so does the sampled running maximum (sw_score_kernel MK), for the sub-chunks within its slack of the key
+    bool allow_sample = allow_sat;
     std::vector<char> qfast(nq, 0), qfloat(nq, 0), qsat(nq, 0), qdone(nq, 0);
     std::vector<int64_t> qchunk(nq, 0), qwarm(nq, 0);
     std::vector<unsigned long long> keys;
     bool any_fast = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
       buckets.clear();
-      if (n >= 1024) buckets = make_buckets(ref, q, table, p, n, allow_sat);
+      if (n >= 1024) buckets = make_buckets(ref, q, table, p, n, allow_sat, allow_sample);
       any_fast = false;
       bool any_sat = false;
-      for (Bucket &b : buckets) { b.fast = bucket_fast_ok(ref, table, b, n, p); any_fast |= b.fast; any_sat |= b.fast && b.satflag; }
+      for (Bucket &b : buckets) { b.fast = bucket_fast_ok(ref, table, b, n, p); any_fast |= b.fast; any_sat |= b.fast && (b.satflag || b.sampled); }
       if (!any_fast) break;
       const std::vector<Range> ranges{rg};
       int rc = score_begin(ctx, q, ranges, table);
@@ -477,7 +479,7 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
         if (rc) return rc;
         for (int k = 0; k < b.count; ++k) {
           const int id = q.order[b.first + k];
-          qfast[id] = 1; qchunk[id] = b.sub_len; qwarm[id] = b.warm; qsat[id] = b.satflag ? 1 : 0;
+          qfast[id] = 1; qchunk[id] = b.sub_len; qwarm[id] = b.warm; qsat[id] = b.satflag ? 1 : (b.sampled ? 2 : 0);
           qfloat[id] = b.sem == kSemF16 ? 2 : (b.sem == kSemU8H ? 3 : (b.sem == kSemF32 ? 4 : (sem_is_float(b.sem) ? 1 : 0)));
         }
       }
@@ -495,6 +497,7 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       if (nflag > kFlagCap || (double)nflag > 64.0 * (double)nsatq + 1024.0) {
         // saturated nearly everywhere (a background that reaches the cap): the exact packed int16 sweep instead
         allow_sat = false;
+        allow_sample = false;
         ctx->last_kernel.cells = 0;                                  // the sweep that counts is the one that follows
         continue;
       }
@@ -511,8 +514,8 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       ctx->timings[1] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
       // every query whose key sits at the cap must have been resolved by a flagged sub-chunk
       for (size_t k = 0; k < nq; ++k)
-        if (qsat[k] && !qdone[k] && half_value((uint16_t)(keys[k] >> 32)) * kF16Scale >= kF16Scale)
-          return fail(ctx, MI355_SW_ENODEV, "internal: a saturated query without a flagged sub-chunk");
+        if (qsat[k] && !qdone[k] && half_value((uint16_t)(keys[k] >> 32)) * kF16Scale >= (qsat[k] == 2 ? 1.0f / 2048.0f : kF16Scale))
+          return fail(ctx, MI355_SW_ENODEV, "internal: a saturated or sampled query without a flagged sub-chunk");
       break;
     }
     if (any_fast) {

@@ -32,6 +32,8 @@ struct Bucket {
   bool twin = false;          // lone long query: two tiles of it per packed register (sw_score_kernel TWIN)
   bool comb = false;          // twin on 16-lane tiles, small alphabet: profile indexed by the pair of codes (COMB)
   bool unsat = false;         // uint8 engine swept by a float-engine instance WITHOUT saturation, maxima clamped at 255
+  bool sampled = false;       // running maximum folded every 4th step (sw_score_kernel MK = 4): sub-chunk values are lower bounds
+                              // within 3 gaps of the truth; sub-chunks within that slack of the key are re-evaluated exactly
   bool satflag = false;       // float engine swept on float16 cells BEYOND their exact range (the sweep saturates at 2048):
                               // sub-chunks that reach the cap are flagged and re-evaluated exactly (locate_saturated)
   int64_t warm = 0;           // exactness margin in columns
@@ -147,8 +149,14 @@ bool comb_ok(int ncodes, int R) {
 }
 
 // Length classes of the batch: one bucket per kernel instance (R), plus one strip-mined bucket.
+bool sampled_instance(int SL, int R) {
+  if (SL == 8) return R == 13 || R == 16 || R == 19 || R == 26 || R == 32;
+  if (SL == 16 || SL == 64) return R == 10 || R == 12 || R == 16 || R == 20 || R == 24 || R == 32;
+  return false;
+}
+
 std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const ScoreTable &t, const mi355_sw_params &p, int64_t n,
-                                 bool allow_sat = false) {
+                                 bool allow_sat = false, bool allow_sample = false) {
   std::vector<Bucket> out;
   // queries beyond 512 rows: whole-wavefront tiles (64 lanes x R rows: one strip up to 2048 rows, 2048-row
   // strips beyond) when the 64-position profile fits LDS, else 16-lane tiles in 512-row strips
@@ -207,8 +215,11 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       // small scores on short reads: packed float16 cells (clamped add + three-input maximum: 3.5 instead of 4.5 ops per cell)
       static const bool f16_wide = std::getenv("MI355_SW_NO_F16_WIDE") == nullptr;               // A/B switch
       if (fits && !t.htab.empty() && !b.strips && (b.SL != 64 || f16_wide) && b.count >= 2 &&
-          (int64_t)t.smax * b.maxlen + t.smax <= 2040 && std::getenv("MI355_SW_NO_F16") == nullptr)
+          (int64_t)t.smax * b.maxlen + t.smax <= 2040 && std::getenv("MI355_SW_NO_F16") == nullptr) {
         b.sem = kSemF16;
+        // the running maximum every 4th step, the sub-chunks within 3 gaps of the key re-evaluated exactly (sw_score_kernel MK)
+        b.sampled = allow_sample && sampled_instance(b.SL, b.R) && std::getenv("MI355_SW_NO_SAMPLE") == nullptr;
+      }
       // Beyond float16's exact range (reads above 680 bp at match 3) the packed int16 cell costs 4.5 ops.  The float16
       // cell still sweeps them when its clamp is allowed to SATURATE the values at 2048: if the true maximum M is below
       // 2048 nothing saturated and the sweep is exact; if not, the first cell holding M has 2048 in the sweep (every
@@ -272,7 +283,7 @@ double valu_ops_per_cell(const Bucket &b) {
   switch (b.sem) {
     case kSemF32:   per_step = 3.0 * R + (R + 1) / 2 + 1 + over; cells_per_row = 1; break;      // add clamp, max3, sub; max3 per two cells
     case kSemF32U8: per_step = 6.0 * R + (R + 1) / 2 + over; cells_per_row = 1; break;          // add, min, max, sub, max, max
-    case kSemF16:   per_step = 3.0 * R + (R + 1) / 2 + 1 + over; break;
+    case kSemF16:   per_step = 3.0 * R + (b.sampled ? 0.25 : 1.0) * ((R + 1) / 2) + 1 + over; break;
     case kSemU8H:   { const int odd = R / 2; per_step = 4.0 * R + odd / 2 + odd % 2 + R % 2 + over; break; }
     case kSemU8:    per_step = 5.0 * R + (R + 1) / 2 + R % 2 + over; break;
     default:        per_step = 4.0 * R + (R + 1) / 2 + R % 2 + over; break;
@@ -335,6 +346,18 @@ int launch_score_f16(int R, int SL, bool strips, dim3 grid, size_t shmem, hipStr
 #define CASE_HS(r) case r: launch_score(sw_score_kernel<r, SEM, true, 64>, grid, shmem, st, a); return 0;
       CASE_HS(20) CASE_HS(24) CASE_HS(32)
 #undef CASE_HS
+    }
+    return -1;
+  }
+  if (a.submax_out != nullptr) {                // sampled running maximum (MK = 4)
+    if constexpr (SEM == kSemF16) {
+      switch (SL * 100 + R) {
+#define CASE_M(sl, r) case sl * 100 + r: launch_score(sw_score_kernel<r, kSemF16, false, sl, false, false, 4>, grid, shmem, st, a); return 0;
+        CASE_M(8, 13) CASE_M(8, 16) CASE_M(8, 19) CASE_M(8, 26) CASE_M(8, 32)
+        CASE_M(16, 10) CASE_M(16, 12) CASE_M(16, 16) CASE_M(16, 20) CASE_M(16, 24) CASE_M(16, 32)
+        CASE_M(64, 10) CASE_M(64, 12) CASE_M(64, 16) CASE_M(64, 20) CASE_M(64, 24) CASE_M(64, 32)
+#undef CASE_M
+      }
     }
     return -1;
   }
@@ -599,6 +622,8 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   }
   a.keys = io ? io->keys : ctx->keys.as<unsigned long long>();
   a.flag_count = nullptr; a.flag_list = nullptr; a.flag_cap = 0; a.flag_value = 0;
+  a.submax_out = nullptr; a.submax_stride = 0;
+  if (b.sampled && nr != 1) b.sampled = false;                        // (per-range value rows are not laid out)
   if (b.satflag) {
     a.flag_count = ctx->flags.as<unsigned int>();
     a.flag_list = reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2);
@@ -617,6 +642,13 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   a.qfirst = b.first + (int)(p0 * nqw);
   a.qcount = std::min(b.count - (int)(p0 * nqw), (int)(pn * nqw));
   size_t shmem = profile_lds_bytes(ref.ncodes, b.R, b.SL, b.twin, b.comb) + (size_t)(b.twin ? 2 : 1) * nslot * codebuf_bytes(b.SL);
+  const int64_t nsub = cpr * (b.chunk_len / b.sub_len);                // sub-chunks of the range (sampled sweep: one value each)
+  if (b.sampled) {
+    if (ctx->submax.ensure((size_t)pn * 2 * (size_t)nsub * 2 + 64)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(sub-chunk values) failed");
+    a.submax_out = ctx->submax.as<uint16_t>();
+    a.submax_stride = nsub;
+    a.flag_count = nullptr; a.flag_list = nullptr;                  // (the filter below appends, not the sweep)
+  }
   dim3 grid((unsigned)(pn * cgroups), (unsigned)nr);
   a.brow = nullptr;
   a.brow_stride = 0;
@@ -650,6 +682,13 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
                               : launch_score_R<kSemI16>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a);
   if (rc) return fail(ctx, MI355_SW_ENOTSUP, "no score kernel instance for this R");
   HIPCHK(ctx, hipGetLastError());
+  if (b.sampled) {
+    const dim3 fgrid((unsigned)std::min<int64_t>(64, (nsub + 255) / 256), (unsigned)a.qcount);
+    hipLaunchKernelGGL(sw_sample_filter, fgrid, dim3(256), 0, ctx->stream, (const uint16_t *)a.submax_out, nsub, nsub,
+                       (const int32_t *)a.qsel, a.qfirst, a.qcount, (const unsigned long long *)a.keys, 3.0f * (float)t.gap,
+                       ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), (uint32_t)kFlagCap);
+    HIPCHK(ctx, hipGetLastError());
+  }
   HIPCHK(ctx, hipEventRecord(ctx->score_ev[ctx->score_ev_used + 1], ctx->stream));
   ctx->score_ev_used += 2;                                // read by score_fetch, after the launches have drained
   ctx->timings[4] += 1;
@@ -666,6 +705,7 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     static const char *cellname[] = {"i16x2", "u8 as i16x2", "f32", "u8 as f32", "f16x2", "u8 as f16x2"};
     std::snprintf(ki.name, sizeof ki.name, "sw_score_kernel<R=%d, %s, SL=%d%s%s>%s", b.R, cellname[b.sem], b.SL,
                   b.strips ? ", strips" : "", b.twin ? (b.comb ? ", twin, code-pair profile" : ", twin") : "",
+                  b.sampled ? " maximum folded every 4th step, sub-chunks within 3 gaps of the key re-evaluated exactly" :
                   b.unsat ? " uint8 engine swept unsaturated, maxima clamped at 255"
                           : b.satflag ? " float engine swept saturating at 2048, saturated sub-chunks re-evaluated exactly" : "");
   }

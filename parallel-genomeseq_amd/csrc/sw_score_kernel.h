@@ -101,6 +101,11 @@ struct ScoreArgs {
   unsigned int *flag_count;
   uint2 *flag_list;          // {query id, sub-chunk index in the range}
   uint32_t flag_cap, flag_value;
+  // Sampled running maximum (template parameter MK > 1): the per-sub-chunk values — lower bounds within (MK - 1) * gap of
+  // the truth — of launch-local query position p, sub-chunk s go to submax_out[p * submax_stride + s]; sw_sample_filter
+  // turns those within that slack of the query's final key into flagged sub-chunks.  Null: not in use.
+  uint16_t *submax_out;
+  int64_t submax_stride;
   // strip-mined variant only (queries longer than 16*R rows): boundary rows between strips,
   // two ping-pong buffers of brow_stride dwords per tile, 16 dwords of front padding each
   uint32_t *brow;
@@ -213,8 +218,14 @@ __device__ __forceinline__ uint32_t row_shr1(uint32_t v) {
 // COMB = true (with TWIN, small alphabets): the profile is indexed by the PAIR of codes the two tiles see
 // (ncodes^2 entries of ready-made packed pairs), so a step reads it once and needs no merge — the cell costs what it
 // costs in the two-query instances.
-template <int R, int SEM, bool STRIPS = false, int SL = 16, bool TWIN = false, bool COMB = false>
+// MK > 1 (packed float16, two-query tiles): the running maximum is folded only every MK-th step.  A cell holding the
+// maximum M decays by exactly one gap per column along its row (H(i, j + k) >= M - k g), so the value seen at the next
+// folded step is within (MK - 1) g of M: the sweep's sub-chunk values become lower bounds with that slack, every
+// sub-chunk within the slack of the query's final key is re-evaluated exactly (host_pipeline.h), and the cell costs
+// 3 + 1/(2 MK) instead of 3.5 ops.
+template <int R, int SEM, bool STRIPS = false, int SL = 16, bool TWIN = false, bool COMB = false, int MK = 1>
 __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
+  static_assert(MK == 1 || (MK == 4 && SEM == kSemF16 && !STRIPS && !TWIN), "sampled maximum: packed float16 two-query tiles");
   static_assert(SL == 64 || SL == 16 || SL == 8, "a slot is a whole wavefront, a DPP row or half a DPP row");
   static_assert(!(STRIPS && SL == 8), "the strip-mined instances use whole DPP rows or whole wavefronts");
   static_assert(!TWIN || ((SL == 64 || SL == 16) && !sem_is_float(SEM) && R % 2 == 0), "twin tiles: packed cells on whole-wavefront or 16-lane tiles");
@@ -440,6 +451,11 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
             if (at < a.flag_cap) a.flag_list[at] = make_uint2((unsigned int)qA, gsub + (unsigned int)subs_per_tile);
           }
         }
+        if (MK > 1 && a.submax_out != nullptr) {
+          const size_t at = (size_t)(2 * pair) * (size_t)a.submax_stride + (size_t)(chunk * subs_per_tile + sub);
+          a.submax_out[at] = (uint16_t)va;
+          if (hasB) a.submax_out[at + (size_t)a.submax_stride] = (uint16_t)vb;
+        }
         if (a.pubmax != 0u) { va = va > a.pubmax ? a.pubmax : va; vb = vb > a.pubmax ? a.pubmax : vb; }
         if (va > best_a) { best_a = va; key_max(k + qA, ((unsigned long long)va << 32) | tag); }
         if (hasB && vb > best_b) { best_b = vb; key_max(k + qB, ((unsigned long long)vb << 32) | tag); }
@@ -573,9 +589,11 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
             const T w = H[r];
             const T x = C::add(diag, C::from_bits(p[r]), a.clamp2);
             const T h = C::vmax3(x, Hg[r], ng);
-            if (r & 1) mx = C::vmax3(mx, tpend, h);
-            else if (r + 1 < R) tpend = h;
-            else mx = C::vmax(mx, h);
+            if (MK == 1 || (k & (MK - 1)) == MK - 1) {             // (compile-time per unrolled step)
+              if (r & 1) mx = C::vmax3(mx, tpend, h);
+              else if (r + 1 < R) tpend = h;
+              else mx = C::vmax(mx, h);
+            }
             diag = w;
             H[r] = h;
             ng = Hg[r] = C::sub_gap(h, a.gap2);
@@ -644,6 +662,27 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
     }
   } else {
     publish(sub);                                                  // the tile's last (or only) sub-chunk
+  }
+}
+
+// Sampled sweep (MK > 1): every sub-chunk whose value lies within `slack` (in H units) of its query's final key may hold
+// the true maximum — append it to the flag list.  grid.y = launch-local query position, threads stride over sub-chunks.
+__global__ __launch_bounds__(256) void sw_sample_filter(const uint16_t *submax, int64_t stride, int64_t nsub, const int32_t *qsel,
+                                                        int qfirst, int qcount, const unsigned long long *keys, float slack,
+                                                        unsigned int *flag_count, uint2 *flag_list, uint32_t flag_cap) {
+  const int pos = blockIdx.y;
+  if (pos >= qcount) return;
+  const int q = qsel[qfirst + pos];
+  const float best = (float)__builtin_bit_cast(_Float16, (uint16_t)(keys[q] >> 32)) * 2048.0f;
+  if (!(best > 0.0f)) return;
+  const float thr = best - slack;
+  const uint16_t *row = submax + (size_t)pos * (size_t)stride;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nsub; s += (int64_t)gridDim.x * blockDim.x) {
+    const float v = (float)__builtin_bit_cast(_Float16, row[s]) * 2048.0f;
+    if (v > 0.0f && v >= thr) {
+      const unsigned int at = atomicAdd(flag_count, 1u);
+      if (at < flag_cap) flag_list[at] = make_uint2((unsigned int)q, (unsigned int)s);
+    }
   }
 }
 
