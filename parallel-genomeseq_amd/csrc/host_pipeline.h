@@ -414,7 +414,7 @@ int locate_saturated(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       if (rc) return rc;
       for (const WaveJob &j : part) {
         if (!(j.best > 0) || j.ci <= 0) continue;
-        const unsigned long long kk = host_order_key(MI355_SW_F32, j.ci, j.cj, q.len[j.q], n);
+        const unsigned long long kk = host_order_key(p.semantics, j.ci, j.cj, q.len[j.q], n);
         Located &L = loc[j.q];
         if (j.best > L.score || (j.best == L.score && kk < bestkey[j.q])) { L.score = j.best; L.ix = j.ci; L.iy = j.cj; bestkey[j.q] = kk; }
         done[j.q] = 1;
@@ -457,7 +457,7 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
     // the float engine's saturating float16 sweep (make_buckets) needs the strip kernel for its flagged sub-chunks
     bool allow_sat = p.semantics == MI355_SW_F32 && strip_scoring_ok(ref, p);
     // ... and so does the sampled running maximum (sw_score_kernel MK), for the sub-chunks within its slack of the key
-    bool allow_sample = allow_sat;
+    bool allow_sample = strip_scoring_ok(ref, p);
     std::vector<char> qfast(nq, 0), qfloat(nq, 0), qsat(nq, 0), qdone(nq, 0);
     std::vector<int64_t> qchunk(nq, 0), qwarm(nq, 0);
     std::vector<unsigned long long> keys;
@@ -479,7 +479,7 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
         if (rc) return rc;
         for (int k = 0; k < b.count; ++k) {
           const int id = q.order[b.first + k];
-          qfast[id] = 1; qchunk[id] = b.sub_len; qwarm[id] = b.warm; qsat[id] = b.satflag ? 1 : (b.sampled ? 2 : 0);
+          qfast[id] = 1; qchunk[id] = b.sub_len; qwarm[id] = b.warm; qsat[id] = b.sampled ? 2 : (b.satflag ? 1 : 0);
           qfloat[id] = b.sem == kSemF16 ? 2 : (b.sem == kSemU8H ? 3 : (b.sem == kSemF32 ? 4 : (sem_is_float(b.sem) ? 1 : 0)));
         }
       }

@@ -195,7 +195,16 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       // for ANY query length.  3.5 ops per cell pair instead of 4.25 (kSemU8H) or 6 per cell (lone query, float32).
       // locate and traceback keep the saturating rule.
       if (std::getenv("MI355_SW_NO_UNSAT") == nullptr && std::getenv("MI355_SW_NO_F16") == nullptr && !t.htab.empty() && t.gap <= 2040) {
-        if (b.count >= 2) { b.sem = kSemF16; b.unsat = true; b.twin = false; }
+        if (b.count >= 2) {
+          b.sem = kSemF16; b.unsat = true; b.twin = false;
+          // sampled maximum: every cell that holds the uint8 maximum reads at least that in the unsaturated sweep (a clamp at
+          // 255 only lowers values), hence >= it - 3 gaps at the next folded step: its sub-chunk is a candidate
+          // ... provided a random background stays clear of 255: with cheap gaps it grows with the read (about 0.2 M per
+          // row at 3 / -3 / 2), longer reads reach 255 everywhere and every sub-chunk would be a candidate (measured: 1000 bp
+          // reads overflow the flag budget and the call repeats the sweep unsampled)
+          b.sampled = allow_sample && !b.strips && sampled_instance(b.SL, b.R) && std::getenv("MI355_SW_NO_SAMPLE") == nullptr &&
+                      0.3 * (double)t.smax * (double)b.maxlen + 3.0 * (double)t.gap < 230.0;
+        }
         else if (twin16_ok && !b.strips && b.SL != 64) {
           b.sem = kSemF16; b.unsat = true; b.twin = true; b.SL = 16; b.R = pick_R(b.maxlen); b.comb = comb_ok(ref.ncodes, b.R);
         }
@@ -230,6 +239,9 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       else if (allow_sat && fits && !t.htab.empty() && !b.strips && b.count >= 2 && b.maxlen <= 2048 &&
                std::getenv("MI355_SW_NO_F16") == nullptr && std::getenv("MI355_SW_NO_SATFLAG") == nullptr) {
         b.sem = kSemF16; b.satflag = true;
+        // with the sampled maximum the flags come from the filter alone (threshold: key - slack, key <= cap): a cell that holds
+        // the true maximum reads 2048 in the saturating sweep and >= 2048 - 3 gaps at the next folded step
+        b.sampled = allow_sample && sampled_instance(b.SL, b.R) && std::getenv("MI355_SW_NO_SAMPLE") == nullptr;
       }
       // a lone query would fill both halves of every packed register with itself: the float32 instance (one query per
       // slot, exact for integer scores below 2^24) sweeps it faster — also than two of its tiles per packed integer
@@ -705,9 +717,12 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     static const char *cellname[] = {"i16x2", "u8 as i16x2", "f32", "u8 as f32", "f16x2", "u8 as f16x2"};
     std::snprintf(ki.name, sizeof ki.name, "sw_score_kernel<R=%d, %s, SL=%d%s%s>%s", b.R, cellname[b.sem], b.SL,
                   b.strips ? ", strips" : "", b.twin ? (b.comb ? ", twin, code-pair profile" : ", twin") : "",
-                  b.sampled ? " maximum folded every 4th step, sub-chunks within 3 gaps of the key re-evaluated exactly" :
                   b.unsat ? " uint8 engine swept unsaturated, maxima clamped at 255"
-                          : b.satflag ? " float engine swept saturating at 2048, saturated sub-chunks re-evaluated exactly" : "");
+                  : b.satflag ? (b.sampled ? " float engine swept saturating at 2048" : " float engine swept saturating at 2048, saturated sub-chunks re-evaluated exactly") : "");
+    if (b.sampled) {
+      const size_t at = std::strlen(ki.name);
+      std::snprintf(ki.name + at, sizeof ki.name - at, "; maximum folded every 4th step (candidates re-evaluated)");
+    }
   }
   return 0;
 }

@@ -148,7 +148,11 @@ size_t strip_dirs_bytes(int64_t nb, int nstrips, int R) { return (size_t)nb * 64
 template <int R>
 void launch_strip(bool u8, bool track, dim3 grid, dim3 block, hipStream_t st, const StripProblem *dp, const WaveScoring &sc,
                   const float *gtab, int ncodes, int groups = 1, bool maxmode = false) {
-  if (maxmode) {                                // float engine only (locate_saturated)
+  if (maxmode && u8) {                          // maximum + first cell in the uint8 engine's storage order (sampled sweep)
+    hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripMax>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0, 1);
+    return;
+  }
+  if (maxmode) {                                // float engine (locate_saturated)
     if (gtab) hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripMax, true>), grid, block, (size_t)257 * ncodes * 4, st, dp, sc, gtab, ncodes, 1);
     else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripMax>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0, 1);
     return;

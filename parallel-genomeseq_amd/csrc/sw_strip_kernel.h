@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
             for (int r = 0; r < R; ++r) {
               const long long i = (long long)(s * 64 + l) * R + r + 1;
               if (H[r] >= bval && H[r] > 0.0f && i <= na) {
-                const unsigned long long key = order_key<0>(i, j, na, P.full_n);
+                const unsigned long long key = U8 ? order_key<1>(i, j, na, P.full_n) : order_key<0>(i, j, na, P.full_n);
                 if (H[r] > bval || key < bkey) { bval = H[r]; bkey = key; bi = i; bj = j; }
               }
             }
