@@ -539,7 +539,7 @@ def worker(args):
             "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ki["dtype"] if sem == pgs.F32 else "u8",
-            "dtype_note": "f16 = packed 2x float16 cells holding H / 2048 (every H an integer within +-2048: exact); i16 = packed 2x16-bit integer cells; both exact for the float32 engine's integer scores; u8 = saturating uint8 semantics held in packed float16 lanes as (H + 1) / 256 (exact); f32 = float32 cells (fractional scoring); the instance is the library's choice, reported by mi355_sw_last_kernel",
+            "dtype_note": "f16 = packed 2x float16 cells holding H / 2048 (every H an integer within +-2048: exact); i16 = packed 2x16-bit integer cells; both exact for the float32 engine's integer scores; u8 = the uint8 engine's score pass on the same packed float16 cells, unsaturated, published maxima clamped at 255 (locate / traceback evaluate the saturating rule exactly); f32 = float32 cells (fractional scoring); the instance is the library's choice, reported by mi355_sw_last_kernel",
             "data": "synthetic",
             "config": {"workload": "configs[2]: %d x %d bp reads per GPU per step vs %d bp reference (one batch of the 100k-read set)"
                                    % (args.reads, args.read_len, args.ref_len),
