@@ -386,23 +386,42 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
 // cell from the sub-chunks the sweep flagged — each re-evaluated on the pipelined strip kernel (kStripMax) over a window
 // with the general warm-up margin in front.  `flagged` = {query id, sub-chunk}; done[k] is set for every query resolved.
 int locate_saturated(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg, const mi355_sw_params &p,
-                     const std::vector<int64_t> &qchunk, const std::vector<int64_t> &qwarm,
+                     const std::vector<int64_t> &qchunk, const std::vector<int64_t> &qwarm, const std::vector<float> &qlower,
+                     const ScoreTable &table,
                      const std::vector<std::pair<uint32_t, uint32_t>> &flagged, std::vector<Located> &loc, std::vector<char> &done) {
   HostTrace trace_("locate_saturated");
   const int64_t n = rg.hi - rg.lo;
   std::vector<WaveJob> jobs;
   jobs.reserve(flagged.size());
+  // long queries are few and each window occupies one workgroup: cut their sub-chunks into pieces (each with its own
+  // margin) so that the idle CUs share the work, as locate_fast does
+  size_t nlong = 0;
+  for (const auto &f : flagged) nlong += q.len[f.first] > 512 ? 1 : 0;
   for (const auto &f : flagged) {
     const int k = (int)f.first;
     const int64_t sub_len = qchunk[k];
     const int64_t sub_lo = std::max<int64_t>(0, (int64_t)f.second * sub_len - 63);   // the lane lag of the sweep
     const int64_t sub_hi = std::min(((int64_t)f.second + 1) * sub_len, n);
     if (sub_lo >= sub_hi) continue;
-    const int64_t wl = std::max<int64_t>(0, sub_lo - qwarm[k]);
-    WaveJob j;
-    j.q = k; j.orient = 0; j.s_lo = wl; j.nb = (int32_t)(sub_hi - wl); j.track = true; j.dirs = false; j.maxmode = true;
-    j.target = -1.0f; j.own_lo = (int32_t)(sub_lo - wl);
-    jobs.push_back(j);
+    // only cells that hold the maximum M >= qlower[k] (the sweep's key: a lower bound) must come out exact: a path that
+    // reaches M within |x| diagonal steps can afford fewer gap columns than the general margin allows (as locate_fast)
+    int64_t warm = qwarm[k];
+    const Margin mg = table.margin(q.len[k]);
+    if (mg.finite() && qlower[k] > 0) {
+      const double spare = std::max(0.0, mg.smax * (double)q.len[k] - (double)qlower[k]);
+      warm = std::min<int64_t>(warm, clamp_cols((double)q.len[k] + std::ceil(spare / mg.g) + 2.0));
+    }
+    int64_t pieces = 1;
+    if (q.len[k] > 512) pieces = std::max<int64_t>(1, std::min<int64_t>((sub_hi - sub_lo) / 256, 224 / (int64_t)std::max<size_t>(1, nlong)));
+    const int64_t plen = (sub_hi - sub_lo + pieces - 1) / pieces;
+    for (int64_t own_lo = sub_lo; own_lo < sub_hi; own_lo += plen) {
+      const int64_t own_hi = std::min(own_lo + plen, sub_hi);
+      const int64_t wl = std::max<int64_t>(0, own_lo - warm);
+      WaveJob j;
+      j.q = k; j.orient = 0; j.s_lo = wl; j.nb = (int32_t)(own_hi - wl); j.track = true; j.dirs = false; j.maxmode = true;
+      j.target = -1.0f; j.own_lo = (int32_t)(own_lo - wl);
+      jobs.push_back(j);
+    }
   }
   std::vector<unsigned long long> bestkey(q.nq, ~0ull);
   for (int R : {3, 5, 8, 10, 16}) {
@@ -508,13 +527,20 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       std::sort(flagged.begin(), flagged.end());
       flagged.erase(std::unique(flagged.begin(), flagged.end()), flagged.end());
       HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-      rc = locate_saturated(ctx, ref, q, rg, p, qchunk, qwarm, flagged, loc, qdone);
+      std::vector<float> qlower(nq, 0.0f);                          // the sweep's key: a lower bound of the query's maximum
+      for (size_t k = 0; k < nq; ++k) {
+        if (!qsat[k]) continue;
+        const uint32_t hi32 = (uint32_t)(keys[k] >> 32);
+        if (qfloat[k] == 2) qlower[k] = half_value((uint16_t)hi32) * kF16Scale;
+        else if (qfloat[k] == 4) { float v; memcpy(&v, &hi32, 4); qlower[k] = std::ldexp(v, ctx->fshift); }
+      }
+      rc = locate_saturated(ctx, ref, q, rg, p, qchunk, qwarm, qlower, table, flagged, loc, qdone);
       if (rc) return rc;
       HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
       ctx->timings[1] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
       // every query whose key sits at the cap must have been resolved by a flagged sub-chunk
       for (size_t k = 0; k < nq; ++k)
-        if (qsat[k] && !qdone[k] && half_value((uint16_t)(keys[k] >> 32)) * kF16Scale >= (qsat[k] == 2 ? 1.0f / 2048.0f : kF16Scale))
+        if (qsat[k] && !qdone[k] && (qsat[k] == 2 ? (keys[k] >> 32) != 0 : half_value((uint16_t)(keys[k] >> 32)) * kF16Scale >= kF16Scale))
           return fail(ctx, MI355_SW_ENODEV, "internal: a saturated or sampled query without a flagged sub-chunk");
       break;
     }

@@ -254,6 +254,10 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       else if (b.count == 1 && b.sem == kSemI16 && twin_ok && std::getenv("MI355_SW_LONG_TWIN") != nullptr) b.twin = true;   // A/B switch
       else if (b.count == 1 && b.sem == kSemI16 && (double)t.smax * b.maxlen < 1.6e7) b.sem = kSemF32;
       else if (b.count == 1 && b.sem == kSemI16 && twin_ok) b.twin = true;
+      // a lone long query on float32 cells (config 5): the same sampled maximum; integer scores only (exact arithmetic)
+      if (b.sem == kSemF32 && b.count == 1 && b.SL == 64 && !b.twin && t.integral && allow_sample &&
+          (b.strips ? (b.R == 20 || b.R == 24 || b.R == 32) : sampled_instance(64, b.R)) && std::getenv("MI355_SW_NO_SAMPLE") == nullptr)
+        b.sampled = true;
     }
     const Margin mg = t.margin(b.maxlen);
     if (!(mg.smax > 0)) b.warm = 0;
@@ -293,7 +297,7 @@ double valu_ops_per_cell(const Bucket &b) {
   double per_step;
   int cells_per_row = 2;
   switch (b.sem) {
-    case kSemF32:   per_step = 3.0 * R + (R + 1) / 2 + 1 + over; cells_per_row = 1; break;      // add clamp, max3, sub; max3 per two cells
+    case kSemF32:   per_step = 3.0 * R + (b.sampled ? 0.25 : 1.0) * ((R + 1) / 2) + 1 + over; cells_per_row = 1; break;   // add clamp, max3, sub; max3 per two cells
     case kSemF32U8: per_step = 6.0 * R + (R + 1) / 2 + over; cells_per_row = 1; break;          // add, min, max, sub, max, max
     case kSemF16:   per_step = 3.0 * R + (b.sampled ? 0.25 : 1.0) * ((R + 1) / 2) + 1 + over; break;
     case kSemU8H:   { const int odd = R / 2; per_step = 4.0 * R + odd / 2 + odd % 2 + R % 2 + over; break; }
@@ -400,6 +404,19 @@ int launch_score_f16(int R, int SL, bool strips, dim3 grid, size_t shmem, hipStr
 
 template <int SEM>
 int launch_score_R(int R, int SL, bool strips, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
+  if (a.submax_out != nullptr) {                // sampled running maximum (MK = 4): a lone long query on float32 cells
+    if constexpr (SEM == kSemF32) {
+      if (SL != 64) return -1;
+      switch ((strips ? 100 : 0) + R) {
+#define CASE_MF(r) case r: launch_score(sw_score_kernel<r, kSemF32, false, 64, false, false, 4>, grid, shmem, st, a); return 0;
+#define CASE_MFS(r) case 100 + r: launch_score(sw_score_kernel<r, kSemF32, true, 64, false, false, 4>, grid, shmem, st, a); return 0;
+        CASE_MF(10) CASE_MF(12) CASE_MF(16) CASE_MF(20) CASE_MF(24) CASE_MF(32) CASE_MFS(20) CASE_MFS(24) CASE_MFS(32)
+#undef CASE_MF
+#undef CASE_MFS
+      }
+    }
+    return -1;
+  }
   if (strips) {
     if (SL == 16) { if (R != 32) return -1; launch_score(sw_score_kernel<32, SEM, true, 16>, grid, shmem, st, a); return 0; }
     if (SL != 64) return -1;
@@ -656,7 +673,8 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   size_t shmem = profile_lds_bytes(ref.ncodes, b.R, b.SL, b.twin, b.comb) + (size_t)(b.twin ? 2 : 1) * nslot * codebuf_bytes(b.SL);
   const int64_t nsub = cpr * (b.chunk_len / b.sub_len);                // sub-chunks of the range (sampled sweep: one value each)
   if (b.sampled) {
-    if (ctx->submax.ensure((size_t)pn * 2 * (size_t)nsub * 2 + 64)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(sub-chunk values) failed");
+    if (ctx->submax.ensure((size_t)pn * (size_t)nqw * (size_t)nsub * (b.sem == kSemF32 ? 4 : 2) + 64))
+      return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(sub-chunk values) failed");
     a.submax_out = ctx->submax.as<uint16_t>();
     a.submax_stride = nsub;
     a.flag_count = nullptr; a.flag_list = nullptr;                  // (the filter below appends, not the sweep)
@@ -696,9 +714,14 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   HIPCHK(ctx, hipGetLastError());
   if (b.sampled) {
     const dim3 fgrid((unsigned)std::min<int64_t>(64, (nsub + 255) / 256), (unsigned)a.qcount);
-    hipLaunchKernelGGL(sw_sample_filter, fgrid, dim3(256), 0, ctx->stream, (const uint16_t *)a.submax_out, nsub, nsub,
-                       (const int32_t *)a.qsel, a.qfirst, a.qcount, (const unsigned long long *)a.keys, 3.0f * (float)t.gap,
-                       ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), (uint32_t)kFlagCap);
+    if (b.sem == kSemF32)
+      hipLaunchKernelGGL(sw_sample_filter<true>, fgrid, dim3(256), 0, ctx->stream, (const void *)a.submax_out, nsub, nsub,
+                         (const int32_t *)a.qsel, a.qfirst, a.qcount, (const unsigned long long *)a.keys, std::ldexp(3.0f * t.gapf, -ctx->fshift),
+                         ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), (uint32_t)kFlagCap);
+    else
+      hipLaunchKernelGGL(sw_sample_filter<false>, fgrid, dim3(256), 0, ctx->stream, (const void *)a.submax_out, nsub, nsub,
+                         (const int32_t *)a.qsel, a.qfirst, a.qcount, (const unsigned long long *)a.keys, 3.0f * (float)t.gap,
+                         ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), (uint32_t)kFlagCap);
     HIPCHK(ctx, hipGetLastError());
   }
   HIPCHK(ctx, hipEventRecord(ctx->score_ev[ctx->score_ev_used + 1], ctx->stream));

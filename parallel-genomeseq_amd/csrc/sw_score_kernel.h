@@ -225,7 +225,8 @@ __device__ __forceinline__ uint32_t row_shr1(uint32_t v) {
 // 3 + 1/(2 MK) instead of 3.5 ops.
 template <int R, int SEM, bool STRIPS = false, int SL = 16, bool TWIN = false, bool COMB = false, int MK = 1>
 __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
-  static_assert(MK == 1 || (MK == 4 && SEM == kSemF16 && !STRIPS && !TWIN), "sampled maximum: packed float16 two-query tiles");
+  static_assert(MK == 1 || (MK == 4 && !TWIN && ((SEM == kSemF16 && !STRIPS) || SEM == kSemF32)),
+                "sampled maximum: packed float16 two-query tiles, or float32 cells (one query per tile)");
   static_assert(SL == 64 || SL == 16 || SL == 8, "a slot is a whole wavefront, a DPP row or half a DPP row");
   static_assert(!(STRIPS && SL == 8), "the strip-mined instances use whole DPP rows or whole wavefronts");
   static_assert(!TWIN || ((SL == 64 || SL == 16) && !sem_is_float(SEM) && R % 2 == 0), "twin tiles: packed cells on whole-wavefront or 16-lane tiles");
@@ -435,6 +436,8 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
       const unsigned long long tag = 0xFFFFFFFFull - (unsigned long long)(chunk * subs_per_tile + sub);
       unsigned long long *k = a.keys + (size_t)range * a.nq;
       if (sem_is_float(SEM)) {
+        if (MK > 1 && a.submax_out != nullptr)                       // (one query per workgroup: launch-local position = pair)
+          reinterpret_cast<uint32_t *>(a.submax_out)[(size_t)pair * (size_t)a.submax_stride + (size_t)(chunk * subs_per_tile + sub)] = m32;
         if (a.pubmax != 0u && m32 > a.pubmax) m32 = a.pubmax;       // non-negative floats order like their bits
         if (m32 > best_a) {
           best_a = m32;
@@ -667,18 +670,22 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
 
 // Sampled sweep (MK > 1): every sub-chunk whose value lies within `slack` (in H units) of its query's final key may hold
 // the true maximum — append it to the flag list.  grid.y = launch-local query position, threads stride over sub-chunks.
-__global__ __launch_bounds__(256) void sw_sample_filter(const uint16_t *submax, int64_t stride, int64_t nsub, const int32_t *qsel,
+// F32V: float32 cells (values and key are float bit patterns in the sweep's scaled units, and so is `slack`).
+template <bool F32V>
+__global__ __launch_bounds__(256) void sw_sample_filter(const void *submax, int64_t stride, int64_t nsub, const int32_t *qsel,
                                                         int qfirst, int qcount, const unsigned long long *keys, float slack,
                                                         unsigned int *flag_count, uint2 *flag_list, uint32_t flag_cap) {
   const int pos = blockIdx.y;
   if (pos >= qcount) return;
   const int q = qsel[qfirst + pos];
-  const float best = (float)__builtin_bit_cast(_Float16, (uint16_t)(keys[q] >> 32)) * 2048.0f;
+  const float best = F32V ? __uint_as_float((uint32_t)(keys[q] >> 32))
+                          : (float)__builtin_bit_cast(_Float16, (uint16_t)(keys[q] >> 32)) * 2048.0f;
   if (!(best > 0.0f)) return;
   const float thr = best - slack;
-  const uint16_t *row = submax + (size_t)pos * (size_t)stride;
   for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nsub; s += (int64_t)gridDim.x * blockDim.x) {
-    const float v = (float)__builtin_bit_cast(_Float16, row[s]) * 2048.0f;
+    const size_t at = (size_t)pos * (size_t)stride + (size_t)s;
+    const float v = F32V ? __uint_as_float(static_cast<const uint32_t *>(submax)[at])
+                         : (float)__builtin_bit_cast(_Float16, static_cast<const uint16_t *>(submax)[at]) * 2048.0f;
     if (v > 0.0f && v >= thr) {
       const unsigned int at = atomicAdd(flag_count, 1u);
       if (at < flag_cap) flag_list[at] = make_uint2((unsigned int)q, (unsigned int)s);
