@@ -960,3 +960,40 @@ def test_lone_reads_by_length_with_n(ctx, oracle, pgs):
     qb = pgs.synth.read_from_ref(ref, 640, 150)[0].tobytes()
     _cmp(ctx.align(qb, refb, 0), oracle.align(qb, refb, 0), "lone 150")
     assert "code-pair profile" in ctx.last_kernel()["name"], (name, ctx.last_kernel()["name"])
+
+
+def test_sampled_maximum_candidates(ctx, oracle, pgs):
+    """Batches sweep with the running maximum folded every 4th step (sw_score_kernel MK = 4): per sub-chunk the sweep holds a
+    lower bound within 3 gaps of the truth, and every sub-chunk within that slack of the query's key is re-evaluated exactly.
+    Edges of that argument: hits that END in the last columns of a sub-chunk / of a tile / of the reference (their value is
+    seen by the next fold, possibly in the next sub-chunk, or only by the fold of the tile's last step), near-copies whose
+    scores lie 1 .. 6 below the best one in other sub-chunks (candidates that must lose), equal copies (the first in the
+    engine's storage order must win), both engines, against the oracle."""
+    n = 3 * 65536 + 4096
+    ref = bytearray(pgs.synth.dna(911, n).tobytes())
+    reads = [bytes(ref[1000 + 331 * k:1000 + 331 * k + 150]) for k in range(6)]
+    def put(at_end, seq):                                            # plant seq so that its last base sits at 0-based column at_end
+        ref[at_end - len(seq) + 1:at_end + 1] = seq
+    def worse(seq, nsub):                                            # nsub substitutions near the start: score - 6 each (3/-3/2)
+        b = bytearray(seq)
+        for t in range(nsub):
+            b[5 + 9 * t] = ord("ACGT"[("ACGT".index(chr(b[5 + 9 * t])) + 1) % 4])
+        return bytes(b)
+    put(70_000 + 255 - 70_000 % 256, reads[0])                       # ends in the last column of a sub-chunk
+    put(65536 - 1, reads[1])                                         # ... of a tile (65536-column tiles at this size, if chosen)
+    put(n - 1, reads[2])                                             # ... of the reference
+    put(120_000, reads[3]); put(150_000, reads[3])                   # equal copies
+    put(90_001, worse(reads[4], 1))                                  # the original at 1000 + 331 * 4 stays the best; this one is 6 below
+    put(180_002, reads[5][:149])                                     # 3 below the original (one base short)
+    refb = bytes(ref)
+    batch = reads + [worse(reads[0], 2), pgs.synth.dna(912, 150).tobytes()]
+    for sem in (0, 1):
+        got = ctx.align_batch(batch, refb, semantics=sem)
+        name = ctx.last_kernel()["name"]
+        for k, (q, g) in enumerate(zip(batch, got)):
+            _cmp(g, oracle.align(q, refb, sem), ("sampled maximum", sem, k))
+        assert "every 4th step" in name, name
+    for sc in ((5.0, -4.0, 3.0), (2.0, -1.0, 1.0)):
+        got = ctx.align_batch(batch, refb, semantics=0, match=sc[0], mismatch=sc[1], gap=sc[2])
+        for k, (q, g) in enumerate(zip(batch, got)):
+            _cmp(g, oracle.align(q, refb, 0, *sc), ("sampled maximum", sc, k))
