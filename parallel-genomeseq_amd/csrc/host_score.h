@@ -258,6 +258,11 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       if (b.sem == kSemF32 && b.count == 1 && b.SL == 64 && !b.twin && t.integral && allow_sample &&
           (b.strips ? (b.R == 20 || b.R == 24 || b.R == 32) : sampled_instance(64, b.R)) && std::getenv("MI355_SW_NO_SAMPLE") == nullptr)
         b.sampled = true;
+      // ... and batches on float32 cells (fractional scoring; scores beyond 16 bits): the decay bound then holds up to the
+      // rounding of three subtractions, which the filter's slack allows for (score_launch)
+      if (b.sem == kSemF32 && b.count >= 2 && !b.twin && !b.strips && (b.SL == 8 || b.SL == 16) && sampled_instance(b.SL, b.R) &&
+          allow_sample && std::getenv("MI355_SW_NO_SAMPLE") == nullptr)
+        b.sampled = true;
     }
     const Margin mg = t.margin(b.maxlen);
     if (!(mg.smax > 0)) b.warm = 0;
@@ -406,6 +411,16 @@ template <int SEM>
 int launch_score_R(int R, int SL, bool strips, dim3 grid, size_t shmem, hipStream_t st, const ScoreArgs &a) {
   if (a.submax_out != nullptr) {                // sampled running maximum (MK = 4): a lone long query on float32 cells
     if constexpr (SEM == kSemF32) {
+      if (SL == 8 || SL == 16) {                 // batches on float32 cells (fractional scoring)
+        if (strips) return -1;
+        switch (SL * 100 + R) {
+#define CASE_MB(sl, r) case sl * 100 + r: launch_score(sw_score_kernel<r, kSemF32, false, sl, false, false, 4>, grid, shmem, st, a); return 0;
+          CASE_MB(8, 13) CASE_MB(8, 16) CASE_MB(8, 19) CASE_MB(8, 26) CASE_MB(8, 32)
+          CASE_MB(16, 10) CASE_MB(16, 12) CASE_MB(16, 16) CASE_MB(16, 20) CASE_MB(16, 24) CASE_MB(16, 32)
+#undef CASE_MB
+        }
+        return -1;
+      }
       if (SL != 64) return -1;
       switch ((strips ? 100 : 0) + R) {
 #define CASE_MF(r) case r: launch_score(sw_score_kernel<r, kSemF32, false, 64, false, false, 4>, grid, shmem, st, a); return 0;
@@ -716,7 +731,8 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     const dim3 fgrid((unsigned)std::min<int64_t>(64, (nsub + 255) / 256), (unsigned)a.qcount);
     if (b.sem == kSemF32)
       hipLaunchKernelGGL(sw_sample_filter<true>, fgrid, dim3(256), 0, ctx->stream, (const void *)a.submax_out, nsub, nsub,
-                         (const int32_t *)a.qsel, a.qfirst, a.qcount, (const unsigned long long *)a.keys, std::ldexp(3.0f * t.gapf, -ctx->fshift),
+                         (const int32_t *)a.qsel, a.qfirst, a.qcount, (const unsigned long long *)a.keys,
+                         std::ldexp(3.0f * t.gapf + (t.integral ? 0.0f : std::ldexp(t.smaxf * (float)(b.maxlen + 1), -20)), -ctx->fshift),
                          ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), (uint32_t)kFlagCap);
     else
       hipLaunchKernelGGL(sw_sample_filter<false>, fgrid, dim3(256), 0, ctx->stream, (const void *)a.submax_out, nsub, nsub,
