@@ -203,6 +203,7 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
           // row at 3 / -3 / 2), longer reads reach 255 everywhere and every sub-chunk would be a candidate (measured: 1000 bp
           // reads overflow the flag budget and the call repeats the sweep unsampled)
           b.sampled = allow_sample && !b.strips && sampled_instance(b.SL, b.R) && std::getenv("MI355_SW_NO_SAMPLE") == nullptr &&
+                      ref.ncodes - 1 >= 4 &&             // (two- and three-letter alphabets: random matches every other column)
                       0.3 * (double)t.smax * (double)b.maxlen + 3.0 * (double)t.gap < 230.0;
         }
         else if (twin16_ok && !b.strips && b.SL != 64) {
