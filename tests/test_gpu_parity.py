@@ -997,3 +997,18 @@ def test_sampled_maximum_candidates(ctx, oracle, pgs):
         got = ctx.align_batch(batch, refb, semantics=0, match=sc[0], mismatch=sc[1], gap=sc[2])
         for k, (q, g) in enumerate(zip(batch, got)):
             _cmp(g, oracle.align(q, refb, 0, *sc), ("sampled maximum", sc, k))
+
+
+def test_sampled_maximum_falls_back_on_repeats(ctx, oracle, pgs):
+    """Reads with equal maxima in thousands of sub-chunks (poly-A against a poly-A reference) exceed the candidate budget of
+    the sampled sweep (64 per query + 1024): the call repeats the sweep with the exact per-step maximum, and the first maximum
+    in the engine's storage order still wins."""
+    n = 600_000
+    refb = b"A" * n
+    batch = [b"A" * 150, b"A" * 149 + b"C", b"C" + b"A" * 149, b"A" * 100 + b"G" + b"A" * 49, b"A" * 150, b"A" * 148 + b"TT"]
+    for sem in (0, 1):
+        got = ctx.align_batch(batch, refb, semantics=sem)
+        name = ctx.last_kernel()["name"]
+        for k, (q, g) in enumerate(zip(batch, got)):
+            _cmp(g, oracle.align(q, refb, sem), ("repeats", sem, k))
+        assert "every 4th step" not in name, name
