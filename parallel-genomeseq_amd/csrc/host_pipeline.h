@@ -513,7 +513,7 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       static const bool trace_on = std::getenv("MI355_SW_TRACE") != nullptr;
       if (trace_on) std::fprintf(stderr, "[mi355_sw] saturating sweep: %u flagged sub-chunks of %zu queries (budget %.0f)\n", nflag, nsatq,
                                  64.0 * (double)nsatq + 1024.0);
-      if (nflag > kFlagCap || (double)nflag > 64.0 * (double)nsatq + 1024.0) {
+      if (nflag > ctx->flag_cap || (double)nflag > 64.0 * (double)nsatq + 1024.0) {
         // saturated nearly everywhere (a background that reaches the cap): the exact packed int16 sweep instead
         allow_sat = false;
         allow_sample = false;

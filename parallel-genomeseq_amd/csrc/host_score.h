@@ -596,7 +596,9 @@ int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range>
   int rc = score_tables(ctx, q.maxlen, maxrange, t);
   if (rc) return rc;
   HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, nq * nr * 8, ctx->stream));
-  if (ctx->flags.ensure(8 + (size_t)kFlagCap * 8)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
+  // room for the flagged (query, sub-chunk) pairs: a few per query (sampled / saturating sweeps), at least kFlagCap
+  ctx->flag_cap = (uint32_t)std::min<size_t>(0x7FFFFFFFu, std::max<size_t>(kFlagCap, 4 * q.nq + 4096));
+  if (ctx->flags.ensure(8 + (size_t)ctx->flag_cap * 8)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
   HIPCHK(ctx, hipMemsetAsync(ctx->flags.p, 0, 8, ctx->stream));
   return 0;
 }
@@ -672,7 +674,7 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   if (b.satflag) {
     a.flag_count = ctx->flags.as<unsigned int>();
     a.flag_list = reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2);
-    a.flag_cap = kFlagCap;
+    a.flag_cap = ctx->flag_cap;
     a.flag_value = (uint32_t)half_bits(1.0f);                       // cells hold H / 2048: the clamp's upper end
   }
 
@@ -729,17 +731,22 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   if (rc) return fail(ctx, MI355_SW_ENOTSUP, "no score kernel instance for this R");
   HIPCHK(ctx, hipGetLastError());
   if (b.sampled) {
-    const dim3 fgrid((unsigned)std::min<int64_t>(64, (nsub + 255) / 256), (unsigned)a.qcount);
-    if (b.sem == kSemF32)
-      hipLaunchKernelGGL(sw_sample_filter<true>, fgrid, dim3(256), 0, ctx->stream, (const void *)a.submax_out, nsub, nsub,
-                         (const int32_t *)a.qsel, a.qfirst, a.qcount, (const unsigned long long *)a.keys,
-                         std::ldexp(3.0f * t.gapf + (t.integral ? 0.0f : std::ldexp(t.smaxf * (float)(b.maxlen + 1), -20)), -ctx->fshift),
-                         ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), (uint32_t)kFlagCap);
-    else
-      hipLaunchKernelGGL(sw_sample_filter<false>, fgrid, dim3(256), 0, ctx->stream, (const void *)a.submax_out, nsub, nsub,
-                         (const int32_t *)a.qsel, a.qfirst, a.qcount, (const unsigned long long *)a.keys, 3.0f * (float)t.gap,
-                         ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), (uint32_t)kFlagCap);
-    HIPCHK(ctx, hipGetLastError());
+    // grid.y = query positions of this launch, at most 65535 per filter launch
+    for (int f0 = 0; f0 < a.qcount; f0 += 65535) {
+      const int fc = std::min(65535, a.qcount - f0);
+      const dim3 fgrid((unsigned)std::min<int64_t>(64, (nsub + 255) / 256), (unsigned)fc);
+      const void *rows = reinterpret_cast<const uint8_t *>(a.submax_out) + (size_t)f0 * (size_t)nsub * (b.sem == kSemF32 ? 4 : 2);
+      if (b.sem == kSemF32)
+        hipLaunchKernelGGL(sw_sample_filter<true>, fgrid, dim3(256), 0, ctx->stream, rows, nsub, nsub,
+                           (const int32_t *)a.qsel, a.qfirst + f0, fc, (const unsigned long long *)a.keys,
+                           std::ldexp(3.0f * t.gapf + (t.integral ? 0.0f : std::ldexp(t.smaxf * (float)(b.maxlen + 1), -20)), -ctx->fshift),
+                           ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), ctx->flag_cap);
+      else
+        hipLaunchKernelGGL(sw_sample_filter<false>, fgrid, dim3(256), 0, ctx->stream, rows, nsub, nsub,
+                           (const int32_t *)a.qsel, a.qfirst + f0, fc, (const unsigned long long *)a.keys, 3.0f * (float)t.gap,
+                           ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), ctx->flag_cap);
+      HIPCHK(ctx, hipGetLastError());
+    }
   }
   HIPCHK(ctx, hipEventRecord(ctx->score_ev[ctx->score_ev_used + 1], ctx->stream));
   ctx->score_ev_used += 2;                                // read by score_fetch, after the launches have drained
