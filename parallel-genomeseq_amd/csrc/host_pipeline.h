@@ -511,7 +511,7 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       size_t nsatq = 0;
       for (size_t k = 0; k < nq; ++k) nsatq += qsat[k] ? 1 : 0;
       static const bool trace_on = std::getenv("MI355_SW_TRACE") != nullptr;
-      if (trace_on) std::fprintf(stderr, "[mi355_sw] saturating sweep: %u flagged sub-chunks of %zu queries (budget %.0f)\n", nflag, nsatq,
+      if (trace_on) std::fprintf(stderr, "[mi355_sw] saturating / sampled sweep: %u candidate sub-chunks of %zu queries (budget %.0f)\n", nflag, nsatq,
                                  64.0 * (double)nsatq + 1024.0);
       if (nflag > ctx->flag_cap || (double)nflag > 64.0 * (double)nsatq + 1024.0) {
         // saturated nearly everywhere (a background that reaches the cap): the exact packed int16 sweep instead
