@@ -338,9 +338,55 @@ def extra_config5(pgs, device, ref_len, qlen):
             out[name] = {"wall_ms": dt * 1e3, "gcups": cells / dt * 1e-9, "score_kernel_ms": tm["score_us"] * 1e-3,
                          "locate_ms": tm["locate_us"] * 1e-3, "traceback_ms": tm["trace_us"] * 1e-3,
                          "kernel": ctx.last_kernel()["name"], "score": r["score"], "pos": r["pos"]}
+        out["rank_share"] = rank_share_config5(pgs, ctx, q, ref_len, qlen)
         return out
     finally:
         ctx.close()
+
+
+def rank_share_config5(pgs, ctx, q, ref_len, qlen):
+    """One rank's share of configs[4] at world = 1 / 2 / 4 / 8, measured on ONE GPU (the 8-GPU node is the driver's):
+    npiece = 2 * world pieces of _make_string_range(npiece, |q|, |ref|, 2.0) (plocalaligner.cpp:44-67) dealt round-robin
+    (piece p -> rank p mod world, plocalaligner.cpp:110-129).  Timed: the share of the rank on the job's critical path — the
+    owner of the winning piece: it sweeps its pieces on the resident reference (score_ranges: what every rank does, all shares
+    are the same size) and then finishes the winner (argmax + traceback from the sweep's keys, align_scored_range).
+    predicted_speedup = T(world = 1) / T(share): what the sharded job reaches when every rank is as fast as this GPU and the
+    8-byte all-reduce is free; predicted_speedup_score_pass: the same for the sweep alone."""
+    out = {"note": "the pieces of the rank that owns the winning piece, swept on one GPU against the resident %d bp reference; "
+                   "finish = argmax + traceback of the winning piece from the sweep's keys" % ref_len, "worlds": {}}
+    base = None
+    for world in (1, 2, 4, 8):
+        npiece = 2 * world
+        ranges = pgs.capi.make_string_range(npiece, qlen, ref_len, 2.0)
+        full = ctx.score_ranges(ranges, semantics=pgs.F32)[:, 0]
+        winner = int(full.argmax())                                          # first piece with the greatest maximum
+        owner = winner % world
+        mine = ranges[owner::world]
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            mx = ctx.score_ranges(mine, semantics=pgs.F32)[:, 0]
+            t1 = time.perf_counter()
+            tm_score = ctx.last_timings()["score_us"]
+            k = int(mx.argmax())
+            r = ctx.align_scored_range(k, semantics=pgs.F32)
+            t2 = time.perf_counter()
+            tm = ctx.last_timings()
+            if best is None or (t2 - t0) < best[0]:
+                best = (t2 - t0, t1 - t0, t2 - t1, tm_score, tm["locate_us"], tm["trace_us"], r)
+        assert mine[k] == ranges[winner] and best[6]["score"] == float(full[winner])
+        rec = {"pieces": len(mine), "columns": int(sum(b - a for a, b in mine)), "share_ms": best[0] * 1e3,
+               "score_ms": best[1] * 1e3, "score_kernel_ms": best[3] * 1e-3, "finish_ms": best[2] * 1e3,
+               "finish_locate_ms": best[4] * 1e-3, "finish_traceback_ms": best[5] * 1e-3,
+               "winning_piece": winner, "owner_rank": owner, "pos": best[6]["pos"] + ranges[winner][0]}
+        if base is None:
+            base = rec
+        rec["predicted_speedup"] = base["share_ms"] / rec["share_ms"]
+        rec["predicted_speedup_score_pass"] = base["score_ms"] / rec["score_ms"]
+        out["worlds"][str(world)] = rec
+    ctx.score_ranges(ranges[:1], semantics=pgs.F32)
+    out["kernel"] = ctx.last_kernel()["name"]
+    return out
 
 
 def extra_latency(pgs, device):
@@ -428,7 +474,9 @@ def strong_config5(pgs, D, args, device):
             piece = 0xFFFFFFFF - (key & 0xFFFFFFFF)
             res = None
             if piece in mine:
-                r = ctx.align(q, parts[mine.index(piece)].tobytes(), pgs.F32)
+                # the owner finishes its piece from the sweep's keys (default scoring in both roles: the per-piece sweep IS the
+                # sweep of LAT(x, piece), plocalaligner.cpp:132-137) instead of sweeping the winning piece a second time
+                r = ctx.align_scored_range(mine.index(piece), semantics=pgs.F32)
                 res = {"score": r["score"], "pos": r["pos"] + ranges[piece][0], "piece": piece, "cons_len": len(r["cons_x"])}
             got = [g for g in D.gather_objects(res) if g is not None]
             return got[0]

@@ -87,6 +87,14 @@ void mi355_sw_destroy(mi355_sw_ctx *ctx);
 const char *mi355_sw_last_error(const mi355_sw_ctx *ctx);
 void mi355_sw_default_params(mi355_sw_params *p); /* 3 / -3 / 2, F32, no table */
 
+/* A/B and diagnostic switches of one context (DESIGN.md §8.1 lists them; NONE changes a result — each selects another
+ * kernel instance or pipeline for the same answer, which is what the parity tests use them for).  Defaults come from the
+ * environment, MI355_SW_<NAME IN CAPITALS>, read once by mi355_sw_create.  key: e.g. "no_f16" (or "MI355_SW_NO_F16");
+ * value: NULL, "", "0", "off", "false" = off, anything else = on (integer options: the number).
+ * mi355_sw_option_names(): comma-separated list of the keys this build knows.  MI355_SW_EINVAL for an unknown key. */
+int mi355_sw_set_option(mi355_sw_ctx *ctx, const char *key, const char *value);
+const char *mi355_sw_option_names(void);
+
 /* One alignment of x (rows) against y (columns).  The last y of such calls stays resident on the device and is
  * used again when a later call passes the same bytes: same length and same 128-bit content hash (two independent
  * 64-bit hashes; re-hashed on every call, on helper threads, while the call already runs on the resident copy; a
@@ -138,6 +146,15 @@ int mi355_sw_align_split(mi355_sw_ctx *ctx, const char *x, size_t nx, const char
  * maxima[k * n_queries + q].  Used by multi-GPU reference sharding: every rank sweeps its own pieces. */
 int mi355_sw_score_ranges(mi355_sw_ctx *ctx, size_t nranges, const int64_t *lefts, const int64_t *rights,
                           const mi355_sw_params *params, float *maxima);
+
+/* Finishes range `range_index` of the LAST mi355_sw_score_ranges call on this context as a stand-alone problem: argmax
+ * cell and traceback of every resident query within [lefts[k], rights[k]) — what LAT(sequence_x, winning piece) computes
+ * (plocalaligner.cpp:132-137); pos / end_y are relative to the range start (the caller adds `left`, :137).  When `params`
+ * equals the scoring and engine of that sweep, its per-range keys are used and only the argmax window and the traceback
+ * run (the reference sweeps the winning piece a second time); otherwise the range is swept again under `params`.
+ * outs[n_queries].  MI355_SW_EINVAL when reference or batch changed since the sweep. */
+int mi355_sw_align_scored_range(mi355_sw_ctx *ctx, size_t range_index, const mi355_sw_params *params, int flags,
+                                mi355_sw_result *outs);
 
 /* Host-only helper: piece ranges [left,right). Returns MI355_SW_ERANGE where the reference asserts. */
 int mi355_sw_make_string_range(int npiece, int64_t shortlen, int64_t longlen, float overlap_ratio,
@@ -202,6 +219,7 @@ enum {
 int mi355_sw_multi_create(mi355_sw_multi **m, int ndev, const int *devices, int flags);
 void mi355_sw_multi_destroy(mi355_sw_multi *m);
 const char *mi355_sw_multi_last_error(const mi355_sw_multi *m);
+int mi355_sw_multi_set_option(mi355_sw_multi *m, const char *key, const char *value);   /* mi355_sw_set_option on every device's context */
 int mi355_sw_multi_device_count(const mi355_sw_multi *m);
 int mi355_sw_multi_rccl_version(const mi355_sw_multi *m);   /* ncclGetVersion code, 0 without MI355_SW_MULTI_RCCL */
 

@@ -14,12 +14,13 @@ SCORE_ONLY = 1
 EXPORTS = [
     "mi355_sw_create", "mi355_sw_destroy", "mi355_sw_last_error", "mi355_sw_default_params",
     "mi355_sw_align", "mi355_sw_set_reference", "mi355_sw_align_batch", "mi355_sw_batch_upload",
-    "mi355_sw_batch_run", "mi355_sw_score_ranges", "mi355_sw_align_split", "mi355_sw_make_string_range", "mi355_sw_fill_matrix",
+    "mi355_sw_batch_run", "mi355_sw_score_ranges", "mi355_sw_align_scored_range", "mi355_sw_align_split", "mi355_sw_make_string_range", "mi355_sw_fill_matrix",
     "mi355_sw_argmax", "mi355_sw_true2raw", "mi355_sw_raw2true", "mi355_sw_last_timings", "mi355_sw_free_result", "mi355_sw_free_results",
     "mi355_sw_build_info", "mi355_sw_last_kernel", "mi355_sw_batch_run_view",
     "mi355_sw_multi_create", "mi355_sw_multi_destroy", "mi355_sw_multi_last_error", "mi355_sw_multi_device_count",
     "mi355_sw_multi_rccl_version", "mi355_sw_multi_align_split", "mi355_sw_multi_set_reference",
     "mi355_sw_multi_align_batch", "mi355_sw_multi_last_timings",
+    "mi355_sw_set_option", "mi355_sw_option_names", "mi355_sw_multi_set_option",
 ]
 MULTI_RCCL = 1
 
@@ -77,6 +78,7 @@ def lib():
         L.mi355_sw_last_error.restype = C.c_char_p
         L.mi355_sw_build_info.restype = C.c_char_p
         L.mi355_sw_multi_last_error.restype = C.c_char_p
+        L.mi355_sw_option_names.restype = C.c_char_p
         for name in EXPORTS:
             getattr(L, name)
         _LIB = L
@@ -133,6 +135,11 @@ class Context:
     def _chk(self, rc):
         if rc:
             raise MI355Error(rc, (self._L.mi355_sw_last_error(self._ctx) or b"").decode())
+
+    def set_option(self, key, value=True):
+        """A/B and diagnostic switches of this context (mi355_sw_set_option); none changes a result."""
+        v = None if value in (None, False, 0) else ("1" if value is True else str(value))
+        self._chk(self._L.mi355_sw_set_option(self._ctx, key.encode(), v.encode() if v is not None else None))
 
     # -- single alignment ---------------------------------------------------------------------
     def align(self, x, y, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None):
@@ -229,6 +236,17 @@ class Context:
                                                 out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
+    def align_scored_range(self, k, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None, flags=0, query=0):
+        """Range k of the last score_ranges call finished as a stand-alone problem (argmax + traceback from the sweep's
+        keys when the scoring is the same); result of resident query `query`, pos relative to the range start."""
+        p, keep = make_params(semantics, match, mismatch, gap, lut)
+        n = self._nbatch
+        res = (Result * max(1, n))()
+        self._chk(self._L.mi355_sw_align_scored_range(self._ctx, C.c_size_t(k), C.byref(p), C.c_int(flags), res))
+        out = _take(res[query])
+        self._L.mi355_sw_free_results(res, C.c_size_t(n))
+        return out
+
     def align_batch(self, xs, y=None, **kw):
         if y is not None:
             self.set_reference(y)
@@ -281,6 +299,10 @@ class MultiContext:
         if rc:
             raise MI355Error(rc, (self._L.mi355_sw_multi_last_error(self._m) or b"").decode())
 
+    def set_option(self, key, value=True):
+        v = None if value in (None, False, 0) else ("1" if value is True else str(value))
+        self._chk(self._L.mi355_sw_multi_set_option(self._m, key.encode(), v.encode() if v is not None else None))
+
     def align_split(self, x, y, npiece, overlap_ratio, sm_semantics=F32, la_semantics=F32, match=3.0,
                     mismatch=-3.0, gap=2.0, lut=None):
         x, y = _bytes(x), _bytes(y)
@@ -325,6 +347,10 @@ class MultiContext:
         t = (C.c_double * 6)()
         self._L.mi355_sw_multi_last_timings(self._m, t)
         return dict(score_us=t[0], locate_us=t[1], trace_us=t[2], total_us=t[3], score_launches=int(t[4]), cells=t[5])
+
+
+def option_names():
+    return lib().mi355_sw_option_names().decode().split(",")
 
 
 def make_string_range(npiece, shortlen, longlen, ratio):

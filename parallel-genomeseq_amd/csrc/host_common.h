@@ -7,15 +7,76 @@ constexpr int kMaxRowsFast = 512;             // 16 lanes x R <= 32 rows in one 
 constexpr size_t kDirsBudget = 16ull << 30;    // bytes of traceback decisions per exact launch
 constexpr size_t kExactLdsMax = 159 * 1024;    // dynamic part; the wide instance adds < 1 KiB of static LDS
 
-// MI355_SW_TRACE=1: wall-clock of the host-side phases of every call on stderr (diagnostic)
+// ---- options: A/B and diagnostic switches, none of which changes results -------------------------------
+// Every context carries its own set: defaults come from the environment (MI355_SW_<NAME>, read ONCE when the context is
+// created), mi355_sw_set_option overrides them.  The host code reads them through opt(): each C-ABI entry binds the
+// calling thread to its context's options for the duration of the call (a context serves one host thread at a time).
+#define MI355_SW_BOOL_OPTIONS(X) \
+  X(no_f16) X(no_unsat) X(no_sample) X(no_satflag) X(no_solo) X(no_wave) X(no_comb) X(no_twin) X(no_wide) X(no_strip) \
+  X(no_quant) X(no_f16_wide) X(no_devlist) X(no_ref_cache) X(no_strip_groups) X(u8_long_twin) X(long_twin) X(no_long) \
+  X(no_requery) X(trace)
+#define MI355_SW_INT_OPTIONS(X) X(strip_r) X(slot) X(few_r) X(chunk) X(long_pipes) X(long_wgs) X(long_sub) X(long_r)
+struct Options {
+#define X(n) bool n = false;
+  MI355_SW_BOOL_OPTIONS(X)
+#undef X
+#define X(n) long n = 0;
+  MI355_SW_INT_OPTIONS(X)
+#undef X
+  int fault_inject = 0;           // test hook, only through mi355_sw_set_option("fault_inject", "strip_stall"): never from the environment
+};
+inline std::string option_env_name(const char *n) {
+  std::string e = "MI355_SW_";
+  for (const char *c = n; *c; ++c) e += (char)std::toupper((unsigned char)*c);
+  return e;
+}
+inline Options options_from_env() {
+  Options o;
+#define X(n) o.n = std::getenv(option_env_name(#n).c_str()) != nullptr;
+  MI355_SW_BOOL_OPTIONS(X)
+#undef X
+#define X(n) if (const char *e = std::getenv(option_env_name(#n).c_str())) o.n = std::atol(e);
+  MI355_SW_INT_OPTIONS(X)
+#undef X
+  return o;
+}
+// 0: set; -1: unknown key.  value NULL / "" / "0" / "off" / "false" = off (0), anything else = on / the integer.
+inline int option_set(Options &o, const char *key, const char *value) {
+  std::string k;
+  for (const char *c = key; *c; ++c) k += (char)std::tolower((unsigned char)*c);
+  if (k.compare(0, 9, "mi355_sw_") == 0) k = k.substr(9);
+  const std::string v = value ? value : "";
+  const bool on = !(v.empty() || v == "0" || v == "off" || v == "false");
+#define X(n) if (k == #n) { o.n = on; return 0; }
+  MI355_SW_BOOL_OPTIONS(X)
+#undef X
+#define X(n) if (k == #n) { o.n = on ? std::atol(v.c_str()) : 0; return 0; }
+  MI355_SW_INT_OPTIONS(X)
+#undef X
+  if (k == "fault_inject") { o.fault_inject = v == "strip_stall" ? 1 : 0; return 0; }
+  return -1;
+}
+inline const char *option_names() {
+  return ""
+#define X(n) #n ","
+  MI355_SW_BOOL_OPTIONS(X) MI355_SW_INT_OPTIONS(X)
+#undef X
+  "fault_inject";
+}
+thread_local const Options *tl_opt = nullptr;
+inline const Options &opt() {
+  static const Options env = options_from_env();       // before any context exists on this thread
+  return tl_opt ? *tl_opt : env;
+}
+
+// option `trace`: wall-clock of the host-side phases of every call on stderr (diagnostic)
 struct HostTrace {
   const char *name;
   std::chrono::steady_clock::time_point t0;
   explicit HostTrace(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
   ~HostTrace() {
-    static const bool on = std::getenv("MI355_SW_TRACE") != nullptr;
-    if (on) std::fprintf(stderr, "[mi355_sw] %-28s %9.3f ms\n", name,
-                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (opt().trace) std::fprintf(stderr, "[mi355_sw] %-28s %9.3f ms\n", name,
+                                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
 };
 
@@ -75,7 +136,8 @@ struct QueryBatch {
   std::vector<int64_t> cumlen;    // host copy of `cum`
   size_t nq = 0;
   int maxlen = 0;
-  void release() { bytes.release(); lens.release(); offs.release(); sel.release(); cum.release(); }
+  uint64_t version = 0;           // bumped by every upload (caches keyed on the batch's content)
+  void release() { bytes.release(); lens.release(); offs.release(); sel.release(); cum.release(); ++version; }
 };
 
 struct Range { int64_t lo, hi; };
@@ -154,6 +216,19 @@ struct Located {
 
 }  // namespace
 
+// What mi355_sw_score_ranges leaves behind for mi355_sw_align_scored_range: the sweep's keys per (range, query) and the
+// tile geometry they were made with, valid while reference, batch and scoring stay the same.
+struct ScoredRanges {
+  bool valid = false;
+  uint64_t ref_version = 0, batch_version = 0;
+  mi355_sw_params params = {};
+  std::vector<Range> ranges;
+  std::vector<unsigned long long> keys;   // [nranges][nq]
+  std::vector<char> qfast, qfloat;        // per query: swept by the score kernel; cell type of its key
+  std::vector<int64_t> qchunk, qwarm;     // per query: sub-chunk length and warm-up margin of its bucket
+  int fshift = 0;
+};
+
 // results of mi355_sw_batch_run_view: arrays the context owns until its next call
 struct ViewStore {
   std::vector<float> score;
@@ -175,6 +250,7 @@ struct mi355_sw_ctx {
   QueryBatch one;                 // the single query of such a call
   // scratch
   uint32_t flag_cap = 0;          // entries of `flags` (score_begin)
+  bool long_launched = false;     // a sw_long_kernel launch since the last score_fetch (its status word is flags[1])
   DevBuf keys, ranges, stab, ftab, ftab_s, htab, htab8, soloblk, flags, submax, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs, scan;
   // host sides of small per-call uploads: they must outlive the asynchronous copies, and the tables are only
   // sent again when they change
@@ -194,12 +270,21 @@ struct mi355_sw_ctx {
   std::vector<PinBuf> pin_cons;
   size_t cons_used = 0;
   double timings[6] = {0, 0, 0, 0, 0, 0};
+  Options opts;                   // see Options above
   ViewStore view;
+  ScoredRanges scored;
   Helpers helpers;
   mi355_sw_kernel_info last_kernel = {};   // score-kernel instance that swept the most cells in the running call
 };
 
 namespace {
+
+// binds the calling thread to a context's options for the duration of a C-ABI call (nests)
+struct OptScope {
+  const Options *prev;
+  explicit OptScope(const mi355_sw_ctx *c) : prev(tl_opt) { if (c) tl_opt = &c->opts; }
+  ~OptScope() { tl_opt = prev; }
+};
 
 #define HIPCHK(ctx, call)                                                                  \
   do {                                                                                     \
@@ -379,11 +464,8 @@ Hash128 content_hash(const char *p, size_t n) {
   return r;
 }
 
-// MI355_SW_NO_REF_CACHE=1: never reuse the resident copy of a single-alignment call's reference (every call uploads).
-bool adhoc_cache_enabled() {
-  static const bool on = std::getenv("MI355_SW_NO_REF_CACHE") == nullptr;
-  return on;
-}
+// option no_ref_cache: never reuse the resident copy of a single-alignment call's reference (every call uploads).
+bool adhoc_cache_enabled() { return !opt().no_ref_cache; }
 
 // Reference of a single-alignment call: re-used from the previous call when length and 128-bit content hash match.
 // `known_hash`: the caller has already hashed y.
@@ -447,6 +529,7 @@ bool adhoc_confirm(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData **
 int upload_queries(mi355_sw_ctx *ctx, QueryBatch &q, size_t n, const char *const *xs, const size_t *nxs) {
   HostTrace trace_("upload_queries");
   q.nq = n;
+  ++q.version;
   q.len.resize(n);
   q.off.resize(n);
   size_t mx = 0, tot = 0;

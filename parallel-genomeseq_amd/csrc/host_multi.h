@@ -163,6 +163,12 @@ void mi355_sw_multi_destroy(mi355_sw_multi *m) {
 }
 
 const char *mi355_sw_multi_last_error(const mi355_sw_multi *m) { return m ? m->err.c_str() : "null handle"; }
+int mi355_sw_multi_set_option(mi355_sw_multi *m, const char *key, const char *value) {
+  if (!m || !key) return MI355_SW_EINVAL;
+  for (mi355_sw_ctx *c : m->ctx)
+    if (option_set(c->opts, key, value)) return mfail(m, MI355_SW_EINVAL, std::string("unknown option: ") + key);
+  return 0;
+}
 int mi355_sw_multi_device_count(const mi355_sw_multi *m) { return m ? (int)m->ctx.size() : 0; }
 int mi355_sw_multi_rccl_version(const mi355_sw_multi *m) { return m ? m->rccl_version : 0; }
 
@@ -185,6 +191,7 @@ int mi355_sw_multi_align_split(mi355_sw_multi *m, const char *x, size_t nx, cons
   memset(out, 0, sizeof *out);
   const int ndev = (int)m->ctx.size();
   // one hash of the caller's reference for all devices (each keeps its copy resident across calls)
+  OptScope opt_scope0_(m->ctx[0]);
   const Hash128 h = adhoc_cache_enabled() ? content_hash(y, ny) : Hash128();
   mi355_sw_params ps = *params;
   ps.semantics = sm_semantics;
@@ -193,6 +200,7 @@ int mi355_sw_multi_align_split(mi355_sw_multi *m, const char *x, size_t nx, cons
   std::vector<const RefData *> refs(ndev, nullptr);
   rc = on_devices(m, [&](int d) -> int {
     mi355_sw_ctx *c = m->ctx[d];
+    OptScope opt_scope_(c);
     HIPCHK(c, hipSetDevice(c->device));
     reset_timings(c);
     std::vector<Range> mine;
@@ -228,6 +236,7 @@ int mi355_sw_multi_align_split(mi355_sw_multi *m, const char *x, size_t nx, cons
   const int bp = (int)(0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull));   // first piece with the strictly greatest maximum
   const int owner = bp % ndev;
   mi355_sw_ctx *c = m->ctx[owner];
+  OptScope opt_scope_(c);
   double t_score = 0;
   for (mi355_sw_ctx *cc : m->ctx) t_score = std::max(t_score, cc->timings[0]);
   if (hipSetDevice(c->device) != hipSuccess) return mfail(m, MI355_SW_ENODEV, "hipSetDevice failed");
@@ -251,6 +260,7 @@ int mi355_sw_multi_set_reference(mi355_sw_multi *m, const char *y, size_t ny) {
   if (!m || (!y && ny)) return MI355_SW_EINVAL;
   return on_devices(m, [&](int d) -> int {
     mi355_sw_ctx *c = m->ctx[d];
+    OptScope opt_scope_(c);
     HIPCHK(c, hipSetDevice(c->device));
     return upload_reference(c, c->ref, y, ny);                     // replicated: every device streams all of it
   });
@@ -289,6 +299,7 @@ int mi355_sw_multi_align_batch(mi355_sw_multi *m, size_t n, const char *const *x
   std::vector<unsigned long long> gkey(ndev, 0ull);
   rc = on_devices(m, [&](int d) -> int {
     mi355_sw_ctx *c = m->ctx[d];
+    OptScope opt_scope_(c);
     HIPCHK(c, hipSetDevice(c->device));
     reset_timings(c);
     const std::vector<uint32_t> &idx = part[d];

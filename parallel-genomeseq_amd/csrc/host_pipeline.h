@@ -31,7 +31,7 @@ int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, co
   std::vector<size_t> todo;
   // short reads with identity scoring: decisions by the register-wavefront kernel (lanes = rows of x);
   // long queries (identity scoring, or any table in the float engine): the pipelined strip kernel
-  const bool wave_ok = wave_scoring_ok(p) && std::getenv("MI355_SW_NO_WAVE") == nullptr;
+  const bool wave_ok = wave_scoring_ok(p) && !opt().no_wave;
   const bool strip_ok = strip_scoring_ok(ref, p);
   for (int pass = 0; pass < 2; ++pass) {
     std::vector<int> sub;
@@ -163,7 +163,7 @@ int exact_full(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
   const int64_t n = rg.hi - rg.lo;
   loc.assign(qidx.size(), Located());
   tout.assign(qidx.size(), TraceOut());
-  const bool wave_ok = wave_scoring_ok(p) && std::getenv("MI355_SW_NO_WAVE") == nullptr;
+  const bool wave_ok = wave_scoring_ok(p) && !opt().no_wave;
   const bool u8 = p.semantics == MI355_SW_U8SAT;
   // orientation per query: -1 = LDS kernel for everything
   std::vector<int> orient(qidx.size(), -1);
@@ -254,7 +254,7 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
   // float order = (column, row): no cell left of the sub-chunk can equal the maximum (it would have been reported
   // by an earlier sub-chunk), so the wave kernel's plain first-maximum tracking over the whole window is the answer
   // the uint8 order needs the storage-order key of every cell that equals the maximum: keyed tracking
-  const bool wave_locate = wave_scoring_ok(p) && std::getenv("MI355_SW_NO_WAVE") == nullptr;
+  const bool wave_locate = wave_scoring_ok(p) && !opt().no_wave;
   const bool wave_keyed = p.semantics == MI355_SW_U8SAT;
   auto key_score = [&](size_t k) {
     float score;
@@ -452,8 +452,11 @@ float elapsed_us(mi355_sw_ctx *ctx, hipEvent_t a, hipEvent_t b) {
 
 // All queries of `q` against one range of the reference: argmax cells and traceback views (into buffers the context
 // keeps until its next call), indexed by query id.
+// `pre` (mi355_sw_align_scored_range): the keys of an earlier mi355_sw_score_ranges sweep over this very range stand in
+// for the score pass.
 int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
-                     const mi355_sw_params &p, int flags, std::vector<Located> &loc, std::vector<TraceOut> &tout) {
+                     const mi355_sw_params &p, int flags, std::vector<Located> &loc, std::vector<TraceOut> &tout,
+                     const ScoredRanges *pre = nullptr, size_t pre_range = 0) {
   HostTrace trace_("align_range");
   const bool want_trace = !(flags & MI355_SW_SCORE_ONLY);
   const size_t nq = q.nq;
@@ -481,7 +484,13 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
     std::vector<int64_t> qchunk(nq, 0), qwarm(nq, 0);
     std::vector<unsigned long long> keys;
     bool any_fast = false;
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    if (pre) {
+      qfast = pre->qfast; qfloat = pre->qfloat; qchunk = pre->qchunk; qwarm = pre->qwarm;
+      keys.assign(pre->keys.begin() + pre_range * nq, pre->keys.begin() + (pre_range + 1) * nq);
+      ctx->fshift = pre->fshift;
+      for (size_t k = 0; k < nq; ++k) any_fast |= qfast[k] != 0;
+    }
+    for (int attempt = 0; attempt < 2 && !pre; ++attempt) {
       buckets.clear();
       if (n >= 1024) buckets = make_buckets(ref, q, table, p, n, allow_sat, allow_sample);
       any_fast = false;
@@ -510,7 +519,7 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       HIPCHK(ctx, hipMemcpy(&nflag, ctx->flags.p, 4, hipMemcpyDeviceToHost));
       size_t nsatq = 0;
       for (size_t k = 0; k < nq; ++k) nsatq += qsat[k] ? 1 : 0;
-      static const bool trace_on = std::getenv("MI355_SW_TRACE") != nullptr;
+      const bool trace_on = opt().trace;
       if (trace_on) std::fprintf(stderr, "[mi355_sw] saturating / sampled sweep: %u candidate sub-chunks of %zu queries (budget %.0f)\n", nflag, nsatq,
                                  64.0 * (double)nsatq + 1024.0);
       if (nflag > ctx->flag_cap || (double)nflag > 64.0 * (double)nsatq + 1024.0) {
@@ -567,8 +576,8 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
     // Many small whole problems (short reference or short queries: nothing took the score kernel): float engine with
     // identity scoring runs them on device-built job lists, one sorted range per orientation (host_batch.h)
     std::vector<char> handled(nq, 0);
-    if (!any_fast && p.semantics == MI355_SW_F32 && wave_scoring_ok(p) && std::getenv("MI355_SW_NO_WAVE") == nullptr &&
-        std::getenv("MI355_SW_NO_DEVLIST") == nullptr) {
+    if (!any_fast && p.semantics == MI355_SW_F32 && wave_scoring_ok(p) && !opt().no_wave &&
+        !opt().no_devlist) {
       auto len_at = [&](size_t pos) { return (int64_t)q.len[q.order[pos]]; };
       auto first_above = [&](int64_t v) {                          // first sorted position whose length exceeds v
         size_t lo = 0, hi = nq;
@@ -609,12 +618,12 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
 
 // ... as an array of results with library-owned (malloc) strings: the C-ABI's classic form
 int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg,
-                const mi355_sw_params &p, int flags, mi355_sw_result *outs) {
+                const mi355_sw_params &p, int flags, mi355_sw_result *outs, const ScoredRanges *pre = nullptr, size_t pre_range = 0) {
   const bool want_trace = !(flags & MI355_SW_SCORE_ONLY);
   const size_t nq = q.nq;
   std::vector<Located> loc;
   std::vector<TraceOut> tout;
-  int rc = align_range_core(ctx, ref, q, rg, p, flags, loc, tout);
+  int rc = align_range_core(ctx, ref, q, rg, p, flags, loc, tout, pre, pre_range);
   if (rc) return rc;
   HostTrace trace_results("set_results");
   const float t_iter = (float)(ctx->timings[0] > 0 ? ctx->timings[0] : ctx->timings[3]);
@@ -667,6 +676,7 @@ int align_range_view(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
 int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const std::vector<Range> &ranges,
                  const mi355_sw_params &p, float *maxima /* [nranges][nq] */) {
   const size_t nq = q.nq, nr = ranges.size();
+  ctx->scored.valid = false;
   if (nq == 0 || nr == 0) return 0;
   const ScoreTable table = plan_table(ref, p);
   // no positive score possible (see align_range): every maximum is 0
@@ -683,6 +693,14 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     b.fast = true;
     for (auto &r : ranges) b.fast = b.fast && bucket_fast_ok(ref, table, b, r.hi - r.lo, p);
   }
+  // what a following mi355_sw_align_scored_range needs (one launch group only: the geometry is per launch)
+  ScoredRanges &sc = ctx->scored;
+  sc.valid = false;
+  const bool keep = &q == &ctx->batch && &ref == &ctx->ref && nr <= 32768 && p.lut == nullptr;
+  if (keep) {
+    sc.ref_version = ref.version; sc.batch_version = q.version; sc.params = p; sc.ranges = ranges;
+    sc.keys.assign(nr * nq, 0ull); sc.qfast.assign(nq, 0); sc.qfloat.assign(nq, 0); sc.qchunk.assign(nq, 0); sc.qwarm.assign(nq, 0);
+  }
   for (size_t lo = 0; lo < nr; lo += 32768) {
     const size_t hi = std::min(nr, lo + 32768);
     const std::vector<Range> sub(ranges.begin() + lo, ranges.begin() + hi);
@@ -695,11 +713,16 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
       if (!b.fast) continue;
       rc = score_launch(ctx, ref, q, sub, p, table, b);
       if (rc) return rc;
-      for (int k = 0; k < b.count; ++k) { qfast[q.order[b.first + k]] = 1; qfloat[q.order[b.first + k]] = b.sem == kSemF16 ? 2 : (b.sem == kSemU8H ? 3 : (b.sem == kSemF32 ? 4 : (sem_is_float(b.sem) ? 1 : 0))); }
+      for (int k = 0; k < b.count; ++k) {
+        const int id = q.order[b.first + k];
+        qfast[id] = 1; qfloat[id] = b.sem == kSemF16 ? 2 : (b.sem == kSemU8H ? 3 : (b.sem == kSemF32 ? 4 : (sem_is_float(b.sem) ? 1 : 0)));
+        if (keep) { sc.qchunk[id] = b.sub_len; sc.qwarm[id] = b.warm; }
+      }
     }
     std::vector<unsigned long long> keys;
     rc = score_fetch(ctx, nq * sub.size(), keys);
     if (rc) return rc;
+    if (keep) { std::copy(keys.begin(), keys.end(), sc.keys.begin()); sc.qfast = qfast; sc.qfloat = qfloat; sc.fshift = ctx->fshift; }
     for (size_t r = 0; r < sub.size(); ++r)
       for (size_t k = 0; k < nq; ++k)
         if (qfast[k]) {
@@ -721,6 +744,7 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     if (rc) return rc;
     for (size_t i = 0; i < slow.size(); ++i) maxima[r * nq + slow[i]] = loc[i].score;
   }
+  sc.valid = keep;
   return 0;
 }
 

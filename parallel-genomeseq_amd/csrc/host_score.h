@@ -34,6 +34,8 @@ struct Bucket {
   bool unsat = false;         // uint8 engine swept by a float-engine instance WITHOUT saturation, maxima clamped at 255
   bool sampled = false;       // running maximum folded every 4th step (sw_score_kernel MK = 4): sub-chunk values are lower bounds
                               // within 3 gaps of the truth; sub-chunks within that slack of the key are re-evaluated exactly
+  bool longp = false;         // lone long query on sw_long_kernel: the strips of a tile pipelined over the wavefronts of a workgroup
+  int nstrips = 0;            // ... strips (= wavefronts) per tile
   bool satflag = false;       // float engine swept on float16 cells BEYOND their exact range (the sweep saturates at 2048):
                               // sub-chunks that reach the cap are flagged and re-evaluated exactly (locate_saturated)
   int64_t warm = 0;           // exactness margin in columns
@@ -66,7 +68,7 @@ void pick_shape64(int len, int &R, bool &strips) {
     for (int r : one) if (64 * r >= len) { R = r; return; }
   }
   static const int many[] = {20, 24, 32};
-  if (const char *e = std::getenv("MI355_SW_STRIP_R")) { const int v = std::atoi(e); if (v == 20 || v == 24 || v == 32) { R = v; return; } }   // tuning aid
+  { const long v = opt().strip_r; if (v == 20 || v == 24 || v == 32) { R = (int)v; return; } }   // tuning aid
   int64_t best = -1;
   for (int r : many) {
     const int64_t rows = (int64_t)((len + 64 * r - 1) / (64 * r)) * 64 * r;
@@ -79,7 +81,7 @@ void pick_shape(int len, int &SL, int &R) {
   SL = 16; R = len < 1 ? 2 : pick_R(len);
   const int r8 = len < 36 ? 0 : pick_R8(len);
   if (r8 && 8 * r8 <= 16 * R) { SL = 8; R = r8; }
-  if (const char *e = std::getenv("MI355_SW_SLOT")) { if (std::atoi(e) == 16) { SL = 16; R = len < 1 ? 2 : pick_R(len); } }   // tuning aid
+  if (opt().slot == 16) { SL = 16; R = len < 1 ? 2 : pick_R(len); }   // tuning aid
 }
 
 ScoreTable plan_table(const RefData &ref, const mi355_sw_params &p) {
@@ -144,8 +146,26 @@ size_t profile_lds_bytes(int ncodes, int R, int SL = 16, bool twin = false, bool
 // workgroups per CU (DNA incl. N and the pad code: 36 pairs)
 constexpr size_t kCombLdsMax = 64 * 1024;
 bool comb_ok(int ncodes, int R) {
-  static const bool off = std::getenv("MI355_SW_NO_COMB") != nullptr;
-  return !off && profile_lds_bytes(ncodes, R, 16, true, true) <= kCombLdsMax;
+  return !opt().no_comb && profile_lds_bytes(ncodes, R, 16, true, true) <= kCombLdsMax;
+}
+
+// sw_long_kernel (a lone query beyond 2048 rows): rows per lane and strips per tile such that the whole float16 profile,
+// the rings and the sub-chunk maxima fit the CU's LDS with at most sixteen wavefronts — the shape with the fewest padded rows.
+constexpr size_t kLongLdsMax = 156 * 1024;
+constexpr int kLongSubsMax = 1024;            // sub-chunk maxima a tile keeps in LDS
+bool long_shape(int ncodes, int len, int &R, int &nstrips) {
+  int64_t best = -1;
+  const long forced = opt().long_r;                                       // tuning aid
+  for (int r : {20, 24, 32}) {
+    if ((forced == 20 || forced == 24 || forced == 32) && r != forced) continue;
+    const int ns = (len + 64 * r - 1) / (64 * r);
+    if (ns < 1 || ns > long_max_waves(r)) continue;
+    if (long_lds_bytes(ncodes, ns, 1, r, kLongSubsMax) > kLongLdsMax) continue;
+    const int64_t rows = (int64_t)ns * 64 * r;
+    if (best < 0 || rows < best) { best = rows; R = r; nstrips = ns; }    // ties: fewer rows per lane = more wavefronts (measured,
+                                                                          // 10 kbp x 250 Mbp: 8 x R=20 strips 244 ms, 5 x R=32 strips 306 ms)
+  }
+  return best > 0;
 }
 
 // Length classes of the batch: one bucket per kernel instance (R), plus one strip-mined bucket.
@@ -160,7 +180,7 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
   std::vector<Bucket> out;
   // queries beyond 512 rows: whole-wavefront tiles (64 lanes x R rows: one strip up to 2048 rows, 2048-row
   // strips beyond) when the 64-position profile fits LDS, else 16-lane tiles in 512-row strips
-  const bool wide_ok = profile_lds_bytes(ref.ncodes, 32, 64) <= kProfileLdsMax && std::getenv("MI355_SW_NO_WIDE") == nullptr;
+  const bool wide_ok = profile_lds_bytes(ref.ncodes, 32, 64) <= kProfileLdsMax && !opt().no_wide;
   for (size_t pos = 0; pos < q.nq; ++pos) {
     const int len = q.len[q.order[pos]];
     bool strips = false;
@@ -177,15 +197,15 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
     out.back().maxlen = std::max(out.back().maxlen, len);
   }
   for (Bucket &b : out) {
-    const bool twin_ok = b.count == 1 && b.SL == 64 && std::getenv("MI355_SW_NO_TWIN") == nullptr;
-    const bool twin16_ok = b.count == 1 && b.maxlen >= 1 && b.maxlen <= kMaxRowsFast && std::getenv("MI355_SW_NO_TWIN") == nullptr;
+    const bool twin_ok = b.count == 1 && b.SL == 64 && !opt().no_twin;
+    const bool twin16_ok = b.count == 1 && b.maxlen >= 1 && b.maxlen <= kMaxRowsFast && !opt().no_twin;
     if (p.semantics == MI355_SW_U8SAT) {
       // lone query: two of its tiles per packed register on whole-wavefront tiles, else one query per register
       b.twin = twin_ok;
       b.sem = b.count == 1 && !b.twin ? kSemF32U8 : kSemU8;
       // the same rule in packed float16 cells scaled by 1/256 (4.25 instead of 5.5 ops per cell); values never leave
       // 0..255, so this holds for every query length
-      if (b.sem == kSemU8 && std::getenv("MI355_SW_NO_F16") == nullptr) b.sem = kSemU8H;
+      if (b.sem == kSemU8 && !opt().no_f16) b.sem = kSemU8H;
       // The score pass only has to deliver, per query, the maximum and the FIRST sub-chunk that reaches it.  Sweep with
       // the FLOAT engine's packed float16 cell (kSemF16: max(0, NW + s, W - G, N - G) on the integer scores M, -X, G,
       // whose clamped add saturates the diagonal term at 2048 instead of 255) and clamp what is published at 255: left of
@@ -194,7 +214,7 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       // differ, but cannot change (maximum, first sub-chunk).  Every value stays an integer <= 2048, exact in float16
       // for ANY query length.  3.5 ops per cell pair instead of 4.25 (kSemU8H) or 6 per cell (lone query, float32).
       // locate and traceback keep the saturating rule.
-      if (std::getenv("MI355_SW_NO_UNSAT") == nullptr && std::getenv("MI355_SW_NO_F16") == nullptr && !t.htab.empty() && t.gap <= 2040) {
+      if (!opt().no_unsat && !opt().no_f16 && !t.htab.empty() && t.gap <= 2040) {
         if (b.count >= 2) {
           b.sem = kSemF16; b.unsat = true; b.twin = false;
           // sampled maximum: every cell that holds the uint8 maximum reads at least that in the unsaturated sweep (a clamp at
@@ -202,7 +222,7 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
           // ... provided a random background stays clear of 255: with cheap gaps it grows with the read (about 0.2 M per
           // row at 3 / -3 / 2), longer reads reach 255 everywhere and every sub-chunk would be a candidate (measured: 1000 bp
           // reads overflow the flag budget and the call repeats the sweep unsampled)
-          b.sampled = allow_sample && !b.strips && sampled_instance(b.SL, b.R) && std::getenv("MI355_SW_NO_SAMPLE") == nullptr &&
+          b.sampled = allow_sample && !b.strips && sampled_instance(b.SL, b.R) && !opt().no_sample &&
                       ref.ncodes - 1 >= 4 &&             // (two- and three-letter alphabets: random matches every other column)
                       0.3 * (double)t.smax * (double)b.maxlen + 3.0 * (double)t.gap < 230.0;
         }
@@ -213,8 +233,10 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
         // register; exact below 2^24), unsaturated and clamped at 255 the same way, sweeps it faster than two tiles per packed
         // float16 register, whose halves need two profile reads and a merge op per row (config 5: 265 against 288 ms;
         // 4096 rows x 50 Mbp: 26 against 34 ms).  MI355_SW_U8_LONG_TWIN=1 restores the twin tiles.
-        else if (b.count == 1 && b.SL == 64 && (double)t.smax * b.maxlen < 1.6e7 && std::getenv("MI355_SW_U8_LONG_TWIN") == nullptr) {
+        else if (b.count == 1 && b.SL == 64 && (double)t.smax * b.maxlen < 1.6e7 && !opt().u8_long_twin) {
           b.sem = kSemF32; b.unsat = true; b.twin = false;
+          int R = 0, ns = 0;
+          if (b.strips && !opt().no_long && long_shape(ref.ncodes, b.maxlen, R, ns)) { b.longp = true; b.R = R; b.nstrips = ns; }
         }
         else if (twin_ok) { b.sem = kSemF16; b.unsat = true; b.twin = true; }
       }
@@ -223,12 +245,12 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       const bool fits = t.integral && (int64_t)t.smax * std::min<int64_t>(b.maxlen, std::max<int64_t>(n, 1)) + t.smax <= 32000;
       b.sem = fits ? kSemI16 : kSemF32;
       // small scores on short reads: packed float16 cells (clamped add + three-input maximum: 3.5 instead of 4.5 ops per cell)
-      static const bool f16_wide = std::getenv("MI355_SW_NO_F16_WIDE") == nullptr;               // A/B switch
+      const bool f16_wide = !opt().no_f16_wide;                                                 // A/B switch
       if (fits && !t.htab.empty() && !b.strips && (b.SL != 64 || f16_wide) && b.count >= 2 &&
-          (int64_t)t.smax * b.maxlen + t.smax <= 2040 && std::getenv("MI355_SW_NO_F16") == nullptr) {
+          (int64_t)t.smax * b.maxlen + t.smax <= 2040 && !opt().no_f16) {
         b.sem = kSemF16;
         // the running maximum every 4th step, the sub-chunks within 3 gaps of the key re-evaluated exactly (sw_score_kernel MK)
-        b.sampled = allow_sample && sampled_instance(b.SL, b.R) && std::getenv("MI355_SW_NO_SAMPLE") == nullptr;
+        b.sampled = allow_sample && sampled_instance(b.SL, b.R) && !opt().no_sample;
       }
       // Beyond float16's exact range (reads above 680 bp at match 3) the packed int16 cell costs 4.5 ops.  The float16
       // cell still sweeps them when its clamp is allowed to SATURATE the values at 2048: if the true maximum M is below
@@ -238,31 +260,37 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       // the cap), which locate_saturated re-evaluates exactly: few windows per read instead of the whole reference.
       // Only where a random background stays well below the cap (<= 2048 rows) and the exact kernel takes the scoring.
       else if (allow_sat && fits && !t.htab.empty() && !b.strips && b.count >= 2 && b.maxlen <= 2048 &&
-               std::getenv("MI355_SW_NO_F16") == nullptr && std::getenv("MI355_SW_NO_SATFLAG") == nullptr) {
+               !opt().no_f16 && !opt().no_satflag) {
         b.sem = kSemF16; b.satflag = true;
         // with the sampled maximum the flags come from the filter alone (threshold: key - slack, key <= cap): a cell that holds
         // the true maximum reads 2048 in the saturating sweep and >= 2048 - 3 gaps at the next folded step
-        b.sampled = allow_sample && sampled_instance(b.SL, b.R) && std::getenv("MI355_SW_NO_SAMPLE") == nullptr;
+        b.sampled = allow_sample && sampled_instance(b.SL, b.R) && !opt().no_sample;
       }
       // a lone query would fill both halves of every packed register with itself: the float32 instance (one query per
       // slot, exact for integer scores below 2^24) sweeps it faster — also than two of its tiles per packed integer
       // register (config 5: 282 ms against 338 ms), which remains the uint8 engine's way (its cells are float16)
       // ... except a short one with small scores: two of its TILES per packed float16 register on 16-lane tiles
       if (b.count == 1 && b.sem == kSemI16 && twin16_ok && !t.htab.empty() && !b.strips && b.SL != 64 &&
-          (int64_t)t.smax * b.maxlen + t.smax <= 2040 && std::getenv("MI355_SW_NO_F16") == nullptr) {
+          (int64_t)t.smax * b.maxlen + t.smax <= 2040 && !opt().no_f16) {
         b.sem = kSemF16; b.twin = true; b.SL = 16; b.R = pick_R(b.maxlen); b.comb = comb_ok(ref.ncodes, b.R);
       }
-      else if (b.count == 1 && b.sem == kSemI16 && twin_ok && std::getenv("MI355_SW_LONG_TWIN") != nullptr) b.twin = true;   // A/B switch
+      else if (b.count == 1 && b.sem == kSemI16 && twin_ok && opt().long_twin) b.twin = true;   // A/B switch
       else if (b.count == 1 && b.sem == kSemI16 && (double)t.smax * b.maxlen < 1.6e7) b.sem = kSemF32;
       else if (b.count == 1 && b.sem == kSemI16 && twin_ok) b.twin = true;
+      // a lone query beyond 2048 rows on float32 cells, integer scores within float16's exact range: the strips of a tile
+      // pipelined over the wavefronts of a workgroup (sw_long_kernel.h) instead of one wavefront per tile
+      if (b.sem == kSemF32 && b.count == 1 && b.SL == 64 && b.strips && !b.twin && t.integral && !t.htab.empty() && !opt().no_long) {
+        int R = 0, ns = 0;
+        if (long_shape(ref.ncodes, b.maxlen, R, ns)) { b.longp = true; b.R = R; b.nstrips = ns; }
+      }
       // a lone long query on float32 cells (config 5): the same sampled maximum; integer scores only (exact arithmetic)
       if (b.sem == kSemF32 && b.count == 1 && b.SL == 64 && !b.twin && t.integral && allow_sample &&
-          (b.strips ? (b.R == 20 || b.R == 24 || b.R == 32) : sampled_instance(64, b.R)) && std::getenv("MI355_SW_NO_SAMPLE") == nullptr)
+          (b.strips ? (b.R == 20 || b.R == 24 || b.R == 32) : sampled_instance(64, b.R)) && !opt().no_sample)
         b.sampled = true;
       // ... and batches on float32 cells (fractional scoring; scores beyond 16 bits): the decay bound then holds up to the
       // rounding of three subtractions, which the filter's slack allows for (score_launch)
       if (b.sem == kSemF32 && b.count >= 2 && !b.twin && !b.strips && (b.SL == 8 || b.SL == 16) && sampled_instance(b.SL, b.R) &&
-          allow_sample && std::getenv("MI355_SW_NO_SAMPLE") == nullptr)
+          allow_sample && !opt().no_sample)
         b.sampled = true;
     }
     const Margin mg = t.margin(b.maxlen);
@@ -276,7 +304,7 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
 // May this bucket's queries be swept by the score kernel over a reference range of n columns?
 bool bucket_fast_ok(const RefData &ref, const ScoreTable &t, const Bucket &b, int64_t n, const mi355_sw_params &p) {
   if (!t.ok || n < 1 || b.maxlen < 1) return false;
-  if (profile_lds_bytes(ref.ncodes, b.R, b.SL) > kProfileLdsMax) return false;  // alphabet too large for this shape
+  if (!b.longp && profile_lds_bytes(ref.ncodes, b.R, b.SL) > kProfileLdsMax) return false;  // alphabet too large for this shape
   // codes travel as bytes: with all 256 byte values present the pad code (256) would alias code 0
   if (ref.ncodes > 256) return false;
   // the uint8 engine's storage order is only bounded to a few tiles when the reference is the longer side;
@@ -502,7 +530,7 @@ int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int S
   // that lets the workgroup count land just under a multiple of the 256 CUs beats the power of two next to it
   // (50 Mbp, one 400 bp read: 763 workgroups of 2048-column tiles = 3 per CU, 509 of 3072-column tiles = 2 per CU:
   // 2.54 -> 2.14 ms; config 5: 131072 -> 122880 columns).  Candidates are multiples of `quant` (the sub-chunk length).
-  static const bool no_quant = std::getenv("MI355_SW_NO_QUANT") != nullptr;
+  const bool no_quant = opt().no_quant;
   if (quant > 0 && !no_quant) {
     const int64_t tiles_per_wg = (int64_t)per_wg;
     auto rounds = [&](int64_t c) {
@@ -530,7 +558,7 @@ int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int S
       cl = best;
     }
   }
-  if (const char *e = std::getenv("MI355_SW_CHUNK")) { const long v = std::atol(e); if (v >= 64) cl = v / 64 * 64; }   // tuning aid
+  { const long v = opt().chunk; if (v >= 64) cl = v / 64 * 64; }   // tuning aid
   return cl;
 }
 
@@ -609,9 +637,114 @@ struct ScoreIO {
   unsigned long long *keys = nullptr;
 };
 
+// A lone long query on sw_long_kernel: one workgroup per tile (or `pipes` tiles), every strip of the tile on its own
+// wavefront.  Tile length: the ranges' columns dealt to as many workgroups as the chip holds at once (LDS decides how many
+// per CU), rounded up to whole sub-chunks — never more workgroups than that, a second round would double the launch.
+int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const std::vector<Range> &ranges,
+                      const mi355_sw_params &p, const ScoreTable &t, Bucket &b) {
+  HostTrace trace_("long_score_launch");
+  const size_t nr = ranges.size();
+  const int qid = q.order[b.first];
+  double total_cols = 0;
+  int64_t maxlen = 0;
+  for (auto &r : ranges) { total_cols += (double)(r.hi - r.lo); maxlen = std::max(maxlen, r.hi - r.lo); }
+  int pipes = (int)opt().long_pipes;
+  if (pipes < 1) pipes = long_max_waves(b.R) / b.nstrips;                             // as many wavefronts per CU as fit: the sweep
+                                                                                      // is bound by issue slots that only other wavefronts fill
+  pipes = std::max(1, std::min(pipes, long_max_waves(b.R) / b.nstrips));
+  while (pipes > 1 && long_lds_bytes(ref.ncodes, b.nstrips, pipes, b.R, kLongSubsMax) > kLongLdsMax) --pipes;
+  int64_t sub_len = opt().long_sub >= 64 ? opt().long_sub / 64 * 64 : 2048;
+  // uint8 engine: a power of two >= |x|, so that the skewed storage order stays within two neighbouring sub-chunks (locate_fast)
+  if (p.semantics == MI355_SW_U8SAT) sub_len = std::max<int64_t>(sub_len, score_sub_len(p.semantics, b));
+  int64_t chunk = 0;
+  int wg_per_cu = 1;
+  for (;;) {
+    const size_t lds = long_lds_bytes(ref.ncodes, b.nstrips, pipes, b.R, kLongSubsMax);
+    wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(long_max_waves(b.R) / (b.nstrips * pipes))));
+    const int64_t G = opt().long_wgs > 0 ? opt().long_wgs : (int64_t)256 * wg_per_cu;
+    chunk = std::max<int64_t>(sub_len, (int64_t)std::ceil(total_cols / (double)(G * pipes) / (double)sub_len) * sub_len);
+    auto wgs = [&](int64_t c) { int64_t n = 0; for (auto &r : ranges) n += (((r.hi - r.lo) + c - 1) / c + pipes - 1) / pipes; return n; };
+    while (wgs(chunk) > G) chunk += sub_len;
+    if (chunk / sub_len <= kLongSubsMax) break;
+    sub_len *= 2;
+  }
+  { const long v = opt().chunk; if (v >= sub_len) chunk = v / sub_len * sub_len; }   // tuning aid
+  b.chunk_len = chunk;
+  b.sub_len = sub_len;
+  const int64_t cpr = (maxlen + chunk - 1) / chunk;
+  const int subs_per_tile = (int)(chunk / sub_len);
+  if (b.sampled && nr != 1) b.sampled = false;                        // (per-range value rows are not laid out)
+
+  LongArgs a;
+  a.refcodes = ref.codes.as<uint8_t>();
+  a.range_lo = ctx->ranges.as<int64_t>();
+  a.range_hi = ctx->ranges.as<int64_t>() + nr;
+  a.chunk_len = chunk; a.sub_len = sub_len;
+  a.warm = (cpr == 1) ? 0 : b.warm;              // a single tile per range starts at the range's own border
+  a.qbytes = q.bytes.as<uint8_t>() + q.off[qid];
+  a.qlen = q.len[qid]; a.qid = qid; a.nq = (int)q.nq;
+  a.htab = ctx->htab.as<uint16_t>();
+  a.ncodes = ref.ncodes;
+  a.gap_s = std::ldexp(t.gapf, -ctx->fshift);
+  a.scale = std::ldexp(kF16Scale, -ctx->fshift);
+  a.pubmax = 0u;
+  if (b.unsat) { const float v = std::ldexp(255.0f, -ctx->fshift); memcpy(&a.pubmax, &v, 4); }
+  a.keys = ctx->keys.as<unsigned long long>();
+  a.submax_out = nullptr;
+  a.nstrips = b.nstrips; a.pipes = pipes; a.subs_per_tile = subs_per_tile;
+  a.status = reinterpret_cast<int32_t *>(ctx->flags.as<unsigned int>() + 1);      // zeroed by score_begin, read by score_fetch
+  const int64_t nsub = cpr * subs_per_tile;
+  if (b.sampled) {
+    if (ctx->submax.ensure((size_t)nsub * 4 + 64)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(sub-chunk values) failed");
+    a.submax_out = ctx->submax.as<uint32_t>();
+  }
+  const size_t shmem = long_lds_bytes(ref.ncodes, b.nstrips, pipes, b.R, subs_per_tile);
+  const dim3 grid((unsigned)((cpr + pipes - 1) / pipes), (unsigned)nr);
+  const dim3 block((unsigned)(64 * b.nstrips * pipes));
+  if (ctx->score_ev.size() < ctx->score_ev_used + 2) {
+    for (int e = 0; e < 2; ++e) { hipEvent_t ev; HIPCHK(ctx, hipEventCreate(&ev)); ctx->score_ev.push_back(ev); }
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->score_ev[ctx->score_ev_used], ctx->stream));
+  auto launch = [&](auto kernel) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(kernel, grid, block, shmem, ctx->stream, a);
+  };
+  if (b.R == 20) { if (b.sampled) launch(sw_long_kernel<20, 4>); else launch(sw_long_kernel<20, 1>); }
+  else if (b.R == 24) { if (b.sampled) launch(sw_long_kernel<24, 4>); else launch(sw_long_kernel<24, 1>); }
+  else if (b.R == 32) { if (b.sampled) launch(sw_long_kernel<32, 4>); else launch(sw_long_kernel<32, 1>); }
+  else return fail(ctx, MI355_SW_ENOTSUP, "no sw_long_kernel instance for this R");
+  HIPCHK(ctx, hipGetLastError());
+  ctx->long_launched = true;
+  if (b.sampled) {
+    const dim3 fgrid((unsigned)std::min<int64_t>(64, (nsub + 255) / 256), 1u);
+    hipLaunchKernelGGL(sw_sample_filter<true>, fgrid, dim3(256), 0, ctx->stream, (const void *)a.submax_out, nsub, nsub,
+                       q.sel.as<int32_t>(), b.first, 1, (const unsigned long long *)a.keys,
+                       std::ldexp(3.0f * t.gapf, -ctx->fshift),
+                       ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), ctx->flag_cap);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->score_ev[ctx->score_ev_used + 1], ctx->stream));
+  ctx->score_ev_used += 2;
+  ctx->timings[4] += 1;
+  double cells = 0;
+  for (auto &r : ranges) cells += (double)q.len[qid] * (double)(r.hi - r.lo);
+  ctx->timings[5] += cells;
+  if (cells > ctx->last_kernel.cells) {
+    mi355_sw_kernel_info &ki = ctx->last_kernel;
+    ki.cell = b.sem; ki.lanes = 64; ki.rows_per_lane = b.R; ki.strips = b.nstrips; ki.twin = 0;
+    ki.chunk_len = chunk; ki.sub_len = sub_len; ki.warm = a.warm; ki.cells = cells;
+    ki.valu_ops_per_cell = valu_ops_per_cell(b);
+    std::snprintf(ki.name, sizeof ki.name, "sw_long_kernel<R=%d, f32 cells, f16 profile; %d strips pipelined over a workgroup, %d tile(s) per workgroup>%s%s",
+                  b.R, b.nstrips, pipes, b.unsat ? " uint8 engine swept unsaturated, maxima clamped at 255" : "",
+                  b.sampled ? "; maximum folded every 4th step (candidates re-evaluated)" : "");
+  }
+  return 0;
+}
+
 // One score-kernel launch: bucket b over all ranges.  Device time is added to ctx->timings[0].
 int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const std::vector<Range> &ranges,
                  const mi355_sw_params &p, const ScoreTable &t, Bucket &b, const ScoreIO *io = nullptr) {
+  if (b.longp && io == nullptr) return long_score_launch(ctx, ref, q, ranges, p, t, b);
   HostTrace trace_("score_launch");
   const size_t nr = ranges.size();
   int64_t maxlen = 0;
@@ -777,7 +910,11 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
 int score_fetch(mi355_sw_ctx *ctx, size_t count, std::vector<unsigned long long> &keys) {
   keys.resize(count);
   HIPCHK(ctx, hipMemcpyAsync(keys.data(), ctx->keys.p, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+  int32_t long_status = 0;
+  if (ctx->long_launched) HIPCHK(ctx, hipMemcpyAsync(&long_status, ctx->flags.as<unsigned int>() + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->long_launched = false;
+  if (long_status != 0) return fail(ctx, MI355_SW_ENODEV, "sw_long_kernel: a pipeline wait expired (a wavefront of the workgroup made no progress)");
   for (size_t e = 0; e + 1 < ctx->score_ev_used; e += 2) {     // device time of the score launches
     float ms = 0;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->score_ev[e], ctx->score_ev[e + 1]));

@@ -31,8 +31,7 @@ static_assert(sizeof(SoloBlock) == 64, "layout of the call block");
 // returns 1: not applicable / the kernel declined (continue on the general path); 0: *out filled; < 0: error
 int solo_align(mi355_sw_ctx *ctx, const RefData &ref, const char *x, size_t nx, const std::vector<Range> &ranges,
                const mi355_sw_params &p, bool want_trace, mi355_sw_result *out, int *piece = nullptr) {
-  static const bool off = std::getenv("MI355_SW_NO_SOLO") != nullptr;
-  if (off || nx < 1 || nx > (size_t)kSoloMaxRows || ranges.empty() || ranges.size() > (size_t)kSoloMaxRanges || !wave_scoring_ok(p)) return 1;
+  if (opt().no_solo || nx < 1 || nx > (size_t)kSoloMaxRows || ranges.empty() || ranges.size() > (size_t)kSoloMaxRanges || !wave_scoring_ok(p)) return 1;
   int64_t n = 0, nmin = INT64_MAX;                 // longest / shortest range
   for (const Range &r : ranges) { n = std::max(n, r.hi - r.lo); nmin = std::min(nmin, r.hi - r.lo); }
   if (nmin < 1024) return 1;

@@ -134,8 +134,8 @@ int strip_R(int na) { return na <= 192 ? 3 : (na <= 320 ? 5 : (na <= 512 ? 8 : (
 constexpr size_t kFewJobs = 64;            // fewer problems than a quarter of the CUs
 int strip_R_few(int na, size_t njobs, bool track) {
   if (njobs > kFewJobs || na <= 512 || na > 64 * kStripMaxWaves * 10) return strip_R(na);
-  static const int forced = [] { const char *e = std::getenv("MI355_SW_FEW_R"); return e ? std::atoi(e) : 0; }();   // tuning aid
-  if (forced == 3 || forced == 5 || forced == 8 || forced == 10 || forced == 16) return forced;
+  const long forced = opt().few_r;   // tuning aid
+  if (forced == 3 || forced == 5 || forced == 8 || forced == 10 || forced == 16) return (int)forced;
   static const int rs[] = {3, 5, 8, 10, 16};
   if (!track) return na <= 2560 ? 3 : 5;
   for (int r : rs) if (strip_count_of(na, r) <= kStripMaxWaves) return r;
@@ -180,7 +180,7 @@ bool strip_table_ok(const RefData &ref, const mi355_sw_params &p) {
 }
 // Which long queries the strip kernel takes: identity scoring in both engines, any table in the float engine.
 bool strip_scoring_ok(const RefData &ref, const mi355_sw_params &p) {
-  if (std::getenv("MI355_SW_NO_STRIP") != nullptr) return false;
+  if (opt().no_strip) return false;
   return wave_scoring_ok(p) || strip_table_ok(ref, p);
 }
 
@@ -198,7 +198,7 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   for (size_t k = 0; k < n; ++k) nsmax = std::max(nsmax, strip_count(q.len[jobs[k].q], R));
   // the decisions of a FEW long alignments: the strips of each dealt to several workgroups, four wavefronts (one per
   // SIMD) each, instead of sixteen wavefronts on one CU (config 5: the sweep of the 26 k-column window)
-  static const bool no_groups = std::getenv("MI355_SW_NO_STRIP_GROUPS") != nullptr;
+  const bool no_groups = opt().no_strip_groups;
   const int spg = 4;
   const int groups = (!track && !no_groups && n <= 8 && nsmax > spg) ? (nsmax + spg - 1) / spg : 1;
   for (size_t k = 0; k < n; ++k) {
@@ -214,8 +214,7 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
     return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(strip scratch) failed");
   std::vector<StripProblem> pr(n);
   // test hook: drives the pipeline's bounded-wait expiry (the workgroup raises its status word and drains)
-  const char *inject = std::getenv("MI355_SW_FAULT_INJECT");
-  const int32_t fault = (inject && std::strcmp(inject, "strip_stall") == 0) ? 1 : 0;
+  const int32_t fault = opt().fault_inject == 1 ? 1 : 0;   // (mi355_sw_set_option only: never read from the environment)
   for (size_t k = 0; k < n; ++k) {
     const WaveJob &j = jobs[k];
     StripProblem &s = pr[k];
@@ -344,7 +343,7 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
       int groupR = strips ? strip_R(gmax) : wave_R(gmax);           // the instance this group runs on
       // a few long alignments whose strips are dealt to several workgroups (run_strip): five rows per lane make twice
       // the strips, i.e. twice the workgroups, of ten (config 5: 32 strips on 8 CUs); three below 2560 rows
-      if (strips && std::getenv("MI355_SW_NO_STRIP_GROUPS") == nullptr) groupR = strip_R_few(gmax, jobs.size(), false);
+      if (strips && !opt().no_strip_groups) groupR = strip_R_few(gmax, jobs.size(), false);
       int rc = strips ? run_strip(ctx, ref, q, rg, p, jobs, groupR) : run_wave(ctx, ref, q, rg, p, jobs);
       if (rc) return rc;
       // walk: measure, lay out, write (only the bytes that exist are copied back)

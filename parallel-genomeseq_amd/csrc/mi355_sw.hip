@@ -37,6 +37,7 @@
 #include "sw_strip_kernel.h"
 #include "sw_batch_kernels.h"
 #include "sw_solo_kernel.h"
+#include "sw_long_kernel.h"
 
 using namespace mi355sw;
 
@@ -68,6 +69,7 @@ int mi355_sw_create(mi355_sw_ctx **out, int device) {
   mi355_sw_ctx *c = new (std::nothrow) mi355_sw_ctx();
   if (!c) return MI355_SW_ENOMEM;
   c->device = device;
+  c->opts = options_from_env();
   if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return MI355_SW_ENODEV; }
   for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return MI355_SW_ENODEV; }
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_exact_kernel<0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kExactLdsMax);
@@ -95,19 +97,30 @@ void mi355_sw_destroy(mi355_sw_ctx *c) {
 
 const char *mi355_sw_last_error(const mi355_sw_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
+int mi355_sw_set_option(mi355_sw_ctx *ctx, const char *key, const char *value) {
+  if (!ctx || !key) return MI355_SW_EINVAL;
+  if (option_set(ctx->opts, key, value)) return fail(ctx, MI355_SW_EINVAL, std::string("unknown option: ") + key);
+  return 0;
+}
+
+const char *mi355_sw_option_names(void) { return option_names(); }
+
 int mi355_sw_set_reference(mi355_sw_ctx *ctx, const char *y, size_t ny) {
+  OptScope opt_scope_(ctx);
   if (!ctx || (!y && ny)) return MI355_SW_EINVAL;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   return upload_reference(ctx, ctx->ref, y, ny);
 }
 
 int mi355_sw_batch_upload(mi355_sw_ctx *ctx, size_t n, const char *const *xs, const size_t *nxs) {
+  OptScope opt_scope_(ctx);
   if (!ctx || !xs || !nxs) return MI355_SW_EINVAL;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   return upload_queries(ctx, ctx->batch, n, xs, nxs);
 }
 
 int mi355_sw_batch_run(mi355_sw_ctx *ctx, const mi355_sw_params *params, int flags, mi355_sw_result *outs) {
+  OptScope opt_scope_(ctx);
   int rc = check_params(ctx, params);
   if (rc) return rc;
   if (!outs) return fail(ctx, MI355_SW_EINVAL, "outs is NULL");
@@ -118,6 +131,7 @@ int mi355_sw_batch_run(mi355_sw_ctx *ctx, const mi355_sw_params *params, int fla
 }
 
 int mi355_sw_batch_run_view(mi355_sw_ctx *ctx, const mi355_sw_params *params, int flags, mi355_sw_batch_view *out) {
+  OptScope opt_scope_(ctx);
   int rc = check_params(ctx, params);
   if (rc) return rc;
   if (!out) return fail(ctx, MI355_SW_EINVAL, "out is NULL");
@@ -130,6 +144,7 @@ int mi355_sw_batch_run_view(mi355_sw_ctx *ctx, const mi355_sw_params *params, in
 
 int mi355_sw_align_batch(mi355_sw_ctx *ctx, size_t n, const char *const *xs, const size_t *nxs,
                          const mi355_sw_params *params, int flags, mi355_sw_result *outs) {
+  OptScope opt_scope_(ctx);
   int rc = check_params(ctx, params);
   if (rc) return rc;
   rc = mi355_sw_batch_upload(ctx, n, xs, nxs);
@@ -139,6 +154,7 @@ int mi355_sw_align_batch(mi355_sw_ctx *ctx, size_t n, const char *const *xs, con
 
 int mi355_sw_align(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, size_t ny,
                    const mi355_sw_params *params, mi355_sw_result *out) {
+  OptScope opt_scope_(ctx);
   int rc = check_params(ctx, params);
   if (rc) return rc;
   if (!out || (!x && nx) || (!y && ny)) return fail(ctx, MI355_SW_EINVAL, "null argument");
@@ -171,6 +187,7 @@ int mi355_sw_align(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, s
 
 int mi355_sw_argmax(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, size_t ny,
                     const mi355_sw_params *params, int64_t *index_x, int64_t *index_y, float *mx) {
+  OptScope opt_scope_(ctx);
   int rc = check_params(ctx, params);
   if (rc) return rc;
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -228,6 +245,7 @@ int mi355_sw_make_string_range(int npiece, int64_t shortlen, int64_t longlen, fl
 int mi355_sw_align_split(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, size_t ny,
                          const mi355_sw_params *params, int sm_semantics, int la_semantics,
                          int npiece, float overlap_ratio, mi355_sw_result *out, int *winning_piece) {
+  OptScope opt_scope_(ctx);
   int rc = check_params(ctx, params);
   if (rc) return rc;
   if (!out || npiece < 1) return fail(ctx, MI355_SW_EINVAL, "bad argument");
@@ -296,6 +314,7 @@ int mi355_sw_align_split(mi355_sw_ctx *ctx, const char *x, size_t nx, const char
 
 int mi355_sw_score_ranges(mi355_sw_ctx *ctx, size_t nranges, const int64_t *lefts, const int64_t *rights,
                           const mi355_sw_params *params, float *maxima) {
+  OptScope opt_scope_(ctx);
   int rc = check_params(ctx, params);
   if (rc) return rc;
   if (!lefts || !rights || !maxima) return fail(ctx, MI355_SW_EINVAL, "null argument");
@@ -314,8 +333,28 @@ int mi355_sw_score_ranges(mi355_sw_ctx *ctx, size_t nranges, const int64_t *left
   return range_maxima(ctx, ctx->ref, q, ranges, *params, maxima);
 }
 
+int mi355_sw_align_scored_range(mi355_sw_ctx *ctx, size_t range_index, const mi355_sw_params *params, int flags,
+                                mi355_sw_result *outs) {
+  OptScope opt_scope_(ctx);
+  int rc = check_params(ctx, params);
+  if (rc) return rc;
+  if (!outs) return fail(ctx, MI355_SW_EINVAL, "outs is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const ScoredRanges &sc = ctx->scored;
+  if (!sc.valid || sc.ref_version != ctx->ref.version || sc.batch_version != ctx->batch.version || range_index >= sc.ranges.size())
+    return fail(ctx, MI355_SW_EINVAL, "mi355_sw_align_scored_range: no mi355_sw_score_ranges call on this reference and batch covers that range");
+  reset_timings(ctx);
+  if (ctx->batch.nq == 0) return 0;
+  const Range rg = sc.ranges[range_index];
+  // the sweep's keys serve when it ran under the same engine and scoring; otherwise the range is swept again
+  const bool same = params->lut == nullptr && params->semantics == sc.params.semantics && params->match == sc.params.match &&
+                    params->mismatch == sc.params.mismatch && params->gap == sc.params.gap;
+  return align_range(ctx, ctx->ref, ctx->batch, rg, *params, flags, outs, same ? &sc : nullptr, range_index);
+}
+
 int mi355_sw_fill_matrix(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, size_t ny,
                          const mi355_sw_params *params, float *H) {
+  OptScope opt_scope_(ctx);
   int rc = check_params(ctx, params);
   if (rc) return rc;
   if (!H) return fail(ctx, MI355_SW_EINVAL, "H is NULL");

@@ -705,20 +705,20 @@ def test_float32_cells_scaling_extremes(ctx, oracle, pgs):
 
 
 def test_strip_pipeline_wait_expiry_is_reported(ctx, oracle, pgs):
-    """sw_strip_kernel's bounded waits: with MI355_SW_FAULT_INJECT=strip_stall wavefront 0 of every workgroup never
-    reports progress, the strip below runs into the spin limit, the workgroup raises its status word and DRAINS (nothing
-    hangs), and the host reports an error instead of a result.  The context stays usable afterwards."""
-    import os
+    """sw_strip_kernel's bounded waits: with the test hook fault_inject=strip_stall (mi355_sw_set_option only — the
+    environment cannot switch it on) wavefront 0 of every workgroup never reports progress, the strip below runs into the
+    spin limit, the workgroup raises its status word and DRAINS (nothing hangs), and the host reports an error instead of a
+    result.  The context stays usable afterwards."""
     ref = pgs.synth.dna(86, 60_000)
     q = pgs.synth.read_from_ref(ref, 87, 1500, sub_rate=0.02, indel_rate=0.004)[0].tobytes()   # three strips of 640 rows
     refb = ref.tobytes()
-    os.environ["MI355_SW_FAULT_INJECT"] = "strip_stall"
+    ctx.set_option("fault_inject", "strip_stall")
     try:
         with pytest.raises(pgs.MI355Error) as ei:
             ctx.align(q, refb, 0)
         assert "wait expired" in str(ei.value)
     finally:
-        del os.environ["MI355_SW_FAULT_INJECT"]
+        ctx.set_option("fault_inject", None)
     _cmp(ctx.align(q, refb, 0), oracle.align(q, refb, 0), "after the injected stall")
 
 
@@ -751,14 +751,13 @@ def test_config4_uniprot_shape_20k(ctx, oracle, pgs):
     assert raw["cons_len"].tolist() == [len(e["cons_x"]) for e in exp]
     for k in range(0, n, 37):
         assert ctx.consensus(k) == (exp[k]["cons_x"], exp[k]["cons_y"]), k
-    # the host-built job lists (MI355_SW_NO_DEVLIST=1) must agree with the device-built ones
-    import os
-    os.environ["MI355_SW_NO_DEVLIST"] = "1"
+    # the host-built job lists (option no_devlist) must agree with the device-built ones
+    ctx.set_option("no_devlist")
     try:
         for g, e in zip(ctx.align_batch(seqs[:3000], query, semantics=0), exp[:3000]):
             _cmp(g, e, "uniprot, host-built lists")
     finally:
-        del os.environ["MI355_SW_NO_DEVLIST"]
+        ctx.set_option("no_devlist", None)
     # four LPT partitions by cell count, each aligned on its own (what four ranks would do), scattered back
     parts = pd.shard_lpt(lens * len(query), 4)
     loads = [int(lens[p].sum()) for p in parts]

@@ -1,0 +1,16 @@
+#!/usr/bin/env bash
+# PMC counters of one kernel: tools/pmc_run.sh TAG KERNEL_SUBSTRING PROGRAM ARGS...   (PROGRAM = python3 or a binary: rocprofv3
+# gets it after `--`, never a shell).  Separate passes per counter set, kernel-trace-free; summary -> gpurun_out/pmc/TAG.json
+TAG=$1; KSUB=$2; shift 2
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/pmc/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+n=0
+for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVES"; do
+  n=$((n+1))
+  rocprofv3 --pmc $set -d $OUT/p$n --output-format csv -- "$@" > $OUT/p$n.log 2>&1 || echo "pass $n failed"
+done
+cd $R
+python tools/pmc_summary.py --kernel "$KSUB" $OUT/p1 $OUT/p2 > gpurun_out/pmc/$TAG.json
+cat gpurun_out/pmc/$TAG.json

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc passes (one directory per pass, CSV output) for the score kernel:
-python tools/pmc_summary.py <dir> [<dir> ...] > profiles/<name>.json
-Sums each counter over the dispatches of the dominant sw_score_kernel instance and divides by its launches."""
+"""Summarise rocprofv3 --pmc passes (one directory per pass, CSV output) for one kernel:
+python tools/pmc_summary.py [--kernel SUBSTRING] <dir> [<dir> ...] > profiles/<name>.json
+Sums each counter over the dispatches whose kernel name contains SUBSTRING (default sw_score_kernel; the first matching
+name is reported) and divides by its launches."""
 import csv
 import glob
 import json
@@ -11,9 +12,14 @@ import sys
 tot = {}
 launches = {}
 kernel = None
-for d in sys.argv[1:]:
+args = sys.argv[1:]
+want = "sw_score_kernel"
+if args and args[0] == "--kernel":
+    want = args[1]
+    args = args[2:]
+for d in args:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        rows = [r for r in csv.DictReader(open(f)) if "sw_score_kernel" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f)) if want in r["Kernel_Name"]]
         if not rows:
             continue
         kernel = kernel or rows[0]["Kernel_Name"]
@@ -38,5 +44,12 @@ if "GRBM_GUI_ACTIVE" in per and "SQ_INSTS_VALU" in per:
     d["valu_busy_frac"] = 4.0 * per["SQ_INSTS_VALU"] / simd_cycles
 if "SQ_LDS_BANK_CONFLICT" in per and "SQ_LDS_IDX_ACTIVE" in per:
     d["lds_bank_conflict_frac"] = per["SQ_LDS_BANK_CONFLICT"] / per["SQ_LDS_IDX_ACTIVE"]
+if "SQ_WAVE_CYCLES" in per:
+    for c, name in (("SQ_WAIT_ANY", "wait_any_frac"), ("SQ_WAIT_INST_ANY", "wait_inst_any_frac"), ("SQ_WAIT_INST_LDS", "wait_inst_lds_frac"),
+                    ("SQ_ACTIVE_INST_VALU", "active_inst_valu_frac"), ("SQ_ACTIVE_INST_LDS", "active_inst_lds_frac")):
+        if c in per:
+            d[name] = per[c] / per["SQ_WAVE_CYCLES"]
+if "SQ_WAVES" in per and "SQ_WAVE_CYCLES" in per and "GRBM_GUI_ACTIVE" in per:
+    d["mean_resident_waves_per_simd"] = per["SQ_WAVE_CYCLES"] / (per["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0) / 4.0 * 4.0
 out["derived"] = d
 print(json.dumps(out, indent=1))
