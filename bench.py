@@ -109,6 +109,66 @@ def cpu_baseline(pgs, ref, read_len, seconds_hint=20.0):
             "sample": "4 reads x %d bp vs first %d bp, scalar uint8 score-only port (oracle/sw_oracle.c)" % (read_len, n)}
 
 
+def measure_traffic(args, kernel_substr="sw_score_kernel", timeout=240):
+    """HBM bytes per launch of the dominant score kernel, MEASURED in this run: two child passes of this very script under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes: the TCC block has no room for both, and no trace
+    flag rides along — MI355X_MICROARCH.md §HBM / §rocprofv3 PMC slots), one step each, nothing else in the child.
+    FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B; x2.0 also calibrated for
+    this kernel's byte-wide reference loads by tools/ubench/fetch_calib.hip).  Returns (bytes per launch, description) or
+    (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--reads", str(args.reads),
+             "--read-len", str(args.read_len), "--ref-len", str(args.ref_len), "--semantics", args.semantics,
+             "--match", str(args.match), "--mismatch", str(args.mismatch), "--gap", str(args.gap),
+             "--no-cpu-baseline", "--no-extras", "--no-strong", "--no-traffic", "--no-parity"]
+    per = {}
+    t0 = time.time()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        try:
+            p = subprocess.run([exe, "--pmc", counter, "-d", out, "--output-format", "csv", "--"] + child, cwd="/tmp",
+                               env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+            if p.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed (exit %d)" % (counter, p.returncode)
+            tot, ids = 0.0, set()
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        tot += float(r["Counter_Value"])
+                        ids.add(r["Dispatch_Id"])
+            if not ids:
+                return None, "no %s dispatch in the %s pass" % (kernel_substr, counter)
+            per[counter] = tot / len(ids)
+        except subprocess.TimeoutExpired:
+            return None, "rocprofv3 --pmc %s timed out" % counter
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    nbytes = per["FETCH_SIZE"] * 1024.0 * 2.0 + per["WRITE_SIZE"] * 1024.0
+    return nbytes, ("measured: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child passes of `bench.py --steps 1 --warmup 0` in this run "
+                    "(%.0f s); FETCH_SIZE %.0f KiB x 1024 x 2.0 + WRITE_SIZE %.0f KiB x 1024 per launch"
+                    % (time.time() - t0, per["FETCH_SIZE"], per["WRITE_SIZE"]))
+
+
+def lds_model(ki, kern_cells_per_s):
+    """LDS traffic of the score kernel's inner loop from the instance the library reports: per step and lane ceil(R / 4)
+    16-byte profile reads (ds_read_b128) + 1 code byte, for R rows of 2 (packed) or 1 cells."""
+    R = ki["rows_per_lane"]
+    packed = ki["cell"] in (0, 1, 4, 5)
+    bytes_per_lane_step = 16.0 * ((R + 3) // 4) + 1.0
+    cells_per_lane_step = R * (2 if packed else 1)
+    bpc = bytes_per_lane_step / cells_per_lane_step
+    peak = 256 * 256 * 2.4e9 * 1e-12                                      # 256 CUs x 256 B/clk x 2.4 GHz (MI355X_MICROARCH.md §LDS)
+    ach = kern_cells_per_s * bpc * 1e-12
+    return {"bytes_per_cell": bpc, "achieved": ach, "peak": peak, "unit": "TB/s", "frac": ach / peak,
+            "note": "profile reads of the inner loop (ds_read_b128, conflict-free by layout: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE "
+                    "= 0.3 % in profiles/); peak = 256 CU x 256 B/clk x 2.4 GHz"}
+
+
 # ------------------------------------------------------------------------------------------------
 # launcher: N > 1 asked for, not yet under torch.distributed.run
 # ------------------------------------------------------------------------------------------------
@@ -275,22 +335,57 @@ def extra_read_lengths(pgs, device, ref_len):
         ctx.close()
 
 
+def extra_repeat_rich(pgs, device, args, headline_gcups):
+    """The headline workload on a REPEAT-RICH reference (synth.dna_repeats: four 300 bp families x 4000 copies at 3 %
+    divergence, 500 microsatellite runs, 500 poly-A runs in a uniform 50 Mbp background) with 1 % of the reads cut from inside
+    the repeats: what the candidate filters of the sampled sweep do on genome-like data.  Reports the rate, the fraction of
+    reads that exceeded their candidate cap and were swept again exactly, and whether the whole batch had to be."""
+    ref, planted = pgs.synth.dna_repeats(33, args.ref_len, families=4, family_len=300, copies=4000, divergence=0.03,
+                                         tandem_runs=500, tandem_len=400, polya_runs=500, polya_len=300)
+    reads, offs, which = pgs.synth.reads_with_repeats(ref, planted, 34, args.reads, args.read_len, repeat_fraction=0.01)
+    ctx = pgs.Context(device)
+    out = {"reads": args.reads, "reads_from_repeats": int(len(which)),
+           "reference": "50 Mbp uniform background + 4 x 4000 copies of 300 bp families (3 % divergence) + 500 microsatellite runs + 500 poly-A runs"}
+    try:
+        ctx.set_reference(ref)
+        ctx.batch_upload([r.tobytes() for r in reads])
+        for sem, name in ((pgs.F32, "f32"), (pgs.U8SAT, "u8")):
+            ctx.batch_run(semantics=sem, raw=True)
+            t0 = time.perf_counter()
+            res = ctx.batch_run(semantics=sem, raw=True)
+            dt = time.perf_counter() - t0
+            cnt = ctx.last_counters()
+            tm = ctx.last_timings()
+            g = float(args.reads) * args.read_len * args.ref_len / dt * 1e-9
+            found = int(np.sum(np.abs(res["pos"] - (offs + 1)) <= 64))
+            out[name] = {"gcups": g, "ms_per_step": dt * 1e3, "vs_headline": g / headline_gcups if headline_gcups else None,
+                         "queries_swept_again_exactly": cnt["requeried"], "fraction_swept_again": cnt["requeried"] / float(args.reads),
+                         "whole_batch_swept_again": cnt["whole_batch_again"], "candidate_subchunks": cnt["candidates"],
+                         "score_kernel_ms": tm["score_us"] * 1e-3, "locate_ms": tm["locate_us"] * 1e-3, "traceback_ms": tm["trace_us"] * 1e-3,
+                         "reads_found_at_their_origin": found, "kernel": ctx.last_kernel()["name"]}
+        return out
+    finally:
+        ctx.close()
+
+
 def extra_config4(pgs, device, nseq):
     """configs[3] shape on one GPU: nseq UniProt-shaped protein sequences (first argument) against the 144-aa P02232
     query (second), identity scoring 3/-3, gap 2, float engine (src/mpi_sw_solve_uniprot.cpp:120)."""
     lens = pgs.synth.lognormal_lengths(5, nseq)
     tot = int(lens.sum())
     allres = pgs.synth.protein(5, tot)
-    offs = np.concatenate([[0], np.cumsum(lens)])
-    seqs = [allres[offs[k]:offs[k + 1]].tobytes() for k in range(nseq)]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     cells = float(tot) * len(pgs.synth.P02232)
     ctx = pgs.Context(device)
     try:
         ctx.set_reference(pgs.synth.P02232)
+        # the database as a multi-FASTA reader holds it: one buffer of residues + offsets (mi355_sw_batch_upload_packed)
+        ctx.batch_upload_packed(allres, offs)                               # first call sizes the device buffers
         t0 = time.perf_counter()
-        ctx.batch_upload(seqs)
+        ctx.batch_upload_packed(allres, offs)
         up = time.perf_counter() - t0
-        out = {"sequences": nseq, "cells": cells, "upload_s": up}
+        out = {"sequences": nseq, "cells": cells, "residues": tot, "upload_s": up,
+               "upload_note": "mi355_sw_batch_upload_packed: one contiguous buffer + offsets, host buffer -> HBM incl. length sort"}
         for flags, name in ((pgs.capi.SCORE_ONLY, "score_argmax"), (0, "with_traceback")):
             ctx.batch_run(semantics=pgs.F32, flags=flags, raw=True)          # first call of a mode sizes its staging buffers
             best = None
@@ -300,7 +395,22 @@ def extra_config4(pgs, device, nseq):
                 dt = time.perf_counter() - t0
                 best = dt if best is None else min(best, dt)
             tm = ctx.last_timings()
-            out[name] = {"wall_ms": best * 1e3, "device_ms": tm["total_us"] * 1e-3, "gcups_wall": cells / best * 1e-9}
+            out[name] = {"wall_ms": best * 1e3, "device_ms": tm["total_us"] * 1e-3, "gcups_wall": cells / best * 1e-9,
+                         "upload_plus_run_ms": (up + best) * 1e3, "gcups_end_to_end": cells / (up + best) * 1e-9}
+        # in-run verification at full size: the device-built job lists against the host-built ones (option no_devlist: another
+        # pipeline — windowed locate + traceback per alignment), every (score, pos, end_x, end_y, cons_len) of all nseq alignments
+        a = ctx.batch_run(semantics=pgs.F32, flags=0, raw=True)
+        ctx.set_option("no_devlist")
+        try:
+            b = ctx.batch_run(semantics=pgs.F32, flags=0, raw=True)
+        finally:
+            ctx.set_option("no_devlist", None)
+        fields = ("score", "pos", "end_x", "end_y", "cons_len")
+        bad = np.zeros(nseq, dtype=bool)
+        for f in fields:
+            bad |= np.asarray(a[f]) != np.asarray(b[f])
+        out["parity_check"] = {"vs": "host-built job lists (option no_devlist)", "alignments": nseq, "fields": list(fields),
+                               "mismatches": int(bad.sum())}
         return out
     finally:
         ctx.close()
@@ -339,6 +449,12 @@ def extra_config5(pgs, device, ref_len, qlen):
                          "locate_ms": tm["locate_us"] * 1e-3, "traceback_ms": tm["trace_us"] * 1e-3,
                          "kernel": ctx.last_kernel()["name"], "score": r["score"], "pos": r["pos"]}
         out["rank_share"] = rank_share_config5(pgs, ctx, q, ref_len, qlen)
+        # in-run verification at full size: the 16-piece split (score_ranges + the winner finished from its keys) against the
+        # whole-reference alignment — where the serial reference logic says they agree (SURVEY.md §8d cfg 5)
+        rs = out["rank_share"]["worlds"]["8"]
+        out["parity_check"] = {"vs": "16-piece split on the resident reference (score_ranges + align_scored_range)",
+                               "fields": ["score", "pos"],
+                               "mismatches": int(rs["pos"] != out["f32"]["pos"]) + int(rs["score"] != out["f32"]["score"])}
         return out
     finally:
         ctx.close()
@@ -378,7 +494,7 @@ def rank_share_config5(pgs, ctx, q, ref_len, qlen):
         rec = {"pieces": len(mine), "columns": int(sum(b - a for a, b in mine)), "share_ms": best[0] * 1e3,
                "score_ms": best[1] * 1e3, "score_kernel_ms": best[3] * 1e-3, "finish_ms": best[2] * 1e3,
                "finish_locate_ms": best[4] * 1e-3, "finish_traceback_ms": best[5] * 1e-3,
-               "winning_piece": winner, "owner_rank": owner, "pos": best[6]["pos"] + ranges[winner][0]}
+               "winning_piece": winner, "owner_rank": owner, "pos": best[6]["pos"] + ranges[winner][0], "score": best[6]["score"]}
         if base is None:
             base = rec
         rec["predicted_speedup"] = base["share_ms"] / rec["share_ms"]
@@ -528,8 +644,24 @@ def worker(args):
         acc["kern_us"] += tm["score_us"]; acc["launches"] += tm["score_launches"]
         acc["locate_us"] += tm["locate_us"]; acc["trace_us"] += tm["trace_us"]
         return r
-    dt, _ = timed(D, timed_step, args.steps)
+    dt, last = timed(D, timed_step, args.steps)
     ki = ctx.last_kernel()                                                  # the instance the library chose (not re-derived here)
+    # in-run verification (outside the timed region): the same resident batch once more on float32 cells — another kernel
+    # instance, another candidate path (option force_f32) — every (score, pos, end_x, end_y, cons_len) must agree
+    parity = None
+    if not args.no_parity:
+        ctx.set_option("force_f32")
+        try:
+            chk = ctx.batch_run(semantics=sem, match=args.match, mismatch=args.mismatch, gap=args.gap, flags=flags, raw=True)
+            kchk = ctx.last_kernel()["name"]
+        finally:
+            ctx.set_option("force_f32", None)
+        fields = ("score", "pos", "end_x", "end_y", "cons_len")
+        bad = np.zeros(args.reads, dtype=bool)
+        for f in fields:
+            bad |= np.asarray(last[0][f]) != np.asarray(chk[f])
+        parity = {"vs": "the same resident batch on float32 cells (option force_f32): " + kchk, "reads": args.reads,
+                  "fields": list(fields), "mismatches": int(D.max_float(float(bad.sum())))}
 
     def side(fn, *a, **kw):
         """A side measurement never takes the headline down with it (at N = 1; with several ranks a failure must fail the
@@ -558,6 +690,7 @@ def worker(args):
         strong["config5"] = side(strong_config5, pgs, D, args, local_rank)
     if extras is not None:
         extras["read_lengths"] = side(extra_read_lengths, pgs, local_rank, args.ref_len)
+        extras["repeat_rich"] = side(extra_repeat_rich, pgs, local_rank, args, cells_per_step * args.steps / dt * 1e-9)
         extras["one_by_one_calls"] = side(extra_latency, pgs, local_rank)
         extras["config4_uniprot_shape"] = side(extra_config4, pgs, local_rank, args.c4_sequences)
         if not args.no_config5:
@@ -570,14 +703,20 @@ def worker(args):
         alg_bytes = float(args.reads) * (args.read_len + args.ref_len + 16)   # |x|+|y|+16 per alignment
         achieved = alg_bytes / avg_launch_s * 1e-9
         traffic, traffic_source = None, None
+        if world == 1 and not args.no_traffic:
+            ctx_closed_note = None
+            traffic, traffic_source = measure_traffic(args)
+            if traffic is None:
+                ctx_closed_note = traffic_source
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if traffic is None and os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 if (rec.get("reads") == args.reads and rec.get("ref_len") == args.ref_len and rec.get("semantics") == args.semantics
                         and rec.get("kernel", ki["name"]) == ki["name"]):
                     traffic = rec["hbm_bytes_per_launch"]
-                    traffic_source = "replay:profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command on this kernel; not measured in this run)"
+                    traffic_source = ("replay:profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command on this kernel; not measured in "
+                                      "this run%s)" % ("" if args.no_traffic or world > 1 else ": " + str(ctx_closed_note)))
             except Exception:
                 traffic = None
         kern_cells_per_s = cells_per_step / avg_launch_s
@@ -604,10 +743,16 @@ def worker(args):
                      "achieved_lane_ops_per_s": kern_cells_per_s * opc,
                      "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
                      "frac": kern_cells_per_s * opc / VALU_PEAK_LANE_OPS,
-                     "note": "peak = 2 cycles per wave64 instruction; packed 16-bit (VOP3P) ops issue at 4 (profiles/r01_valu_instruction_rates.txt)"},
+                     "frac_vop3p_issue": kern_cells_per_s * opc / (VALU_PEAK_LANE_OPS / 2.0),
+                     "note": "frac: against 2 cycles per wave64 instruction (what plain 32-bit VOP2 adds reach); frac_vop3p_issue: against 4 "
+                             "cycles per wave64 instruction, the issue rate of the packed 16-bit (VOP3P) ops, DPP moves and VOP3 ops this "
+                             "kernel consists of (profiles/r01_valu_instruction_rates.txt) — its own ceiling"},
+            "lds": lds_model(ki, kern_cells_per_s),
             "phases_ms_per_step": {"score_kernel": acc["kern_us"] / args.steps * 1e-3, "locate": acc["locate_us"] / args.steps * 1e-3,
                                    "traceback": acc["trace_us"] / args.steps * 1e-3},
         }
+        if parity is not None:
+            line["parity_check"] = parity
         if strong is not None:
             line["strong_scaling"] = strong
         if extras is not None:
@@ -641,7 +786,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the N = 1 side measurements (other engines, configs 4 / 5, one-by-one calls)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling passes")
     ap.add_argument("--no-config5", action="store_true", help="skip everything that needs the 250 Mbp reference")
-    ap.add_argument("--strong-reads", type=int, default=8192, help="total reads of the strong-scaling pass (all ranks together)")
+    ap.add_argument("--strong-reads", type=int, default=100_000,
+                    help="total reads of the strong-scaling pass (all ranks together): all of configs[2] by default")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure HBM traffic with rocprofv3 child passes (replay profiles/pmc_traffic.json)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity checks against other kernel instances")
     ap.add_argument("--c4-sequences", type=int, default=561_356)
     ap.add_argument("--c5-ref-len", type=int, default=250_000_000)
     ap.add_argument("--c5-query-len", type=int, default=10_000)

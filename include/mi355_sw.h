@@ -115,6 +115,11 @@ int mi355_sw_align_batch(mi355_sw_ctx *ctx, size_t n, const char *const *xs, con
 int mi355_sw_batch_upload(mi355_sw_ctx *ctx, size_t n, const char *const *xs, const size_t *nxs);
 int mi355_sw_batch_run(mi355_sw_ctx *ctx, const mi355_sw_params *params, int flags,
                        mi355_sw_result *outs);
+/* mi355_sw_batch_upload for a batch that already lies in ONE buffer: sequence k = buf[offsets[k], offsets[k + 1]), n + 1
+ * ascending offsets — what a multi-FASTA reader has (the reference concatenates the lines of each of its 561 356 files into
+ * one string, src/mpi_sw_solve_uniprot.cpp:97-110).  No pointer per sequence and no staging copy: the caller's bytes go to
+ * the device as they are while the index is built. */
+int mi355_sw_batch_upload_packed(mi355_sw_ctx *ctx, size_t n, const char *buf, const int64_t *offsets);
 
 /* mi355_sw_batch_run with the results as a struct of arrays in LIBRARY-OWNED memory (valid until the next call on this
  * context; nothing to free): for batches of very many small alignments (the 561 356 sequences of
@@ -179,6 +184,11 @@ int mi355_sw_argmax(mi355_sw_ctx *ctx, const char *x, size_t nx, const char *y, 
  * [0] score kernel(s), [1] argmax rescan, [2] traceback window + walk, [3] whole call (device),
  * [4] number of score-kernel launches, [5] cells swept by the score kernel(s). */
 int mi355_sw_last_timings(const mi355_sw_ctx *ctx, double out[6]);
+
+/* What the candidate filters of the last batch / align call did: [0] queries that exceeded their
+ * candidate cap and were swept a second time on the exact instances (per-query fallback), [1] times the WHOLE batch was swept
+ * again (more than half of it exceeded the cap), [2] candidate sub-chunks re-evaluated exactly, [3] reserved (0). */
+int mi355_sw_last_counters(const mi355_sw_ctx *ctx, uint64_t out[4]);
 
 /* Which sw_score_kernel instance swept the most cells in the last call (what the `iterate` of
  * similaritymatrix.cpp:99-264 / :386-561 became for this input): reporting aid for drivers and bench.py, so

@@ -3,10 +3,14 @@
 // gap 2, smithwaterman.cpp:8), getters and ownership: the aligner keeps string_views, the CALLER keeps both
 // sequences alive; consensus strings are owned by the aligner, reversed, '-' for gaps.
 // calculateScore() = one mi355_sw_align call (score pass -> argmax -> greedy traceback on the GPU).
-// Repeated calls REPLACE the consensus (the reference appends to it, an artefact nobody reads back).
+// Repeated calls REPLACE the consensus.  The reference APPENDS to it (traceback pushes onto strings that calculateScore
+// never clears, smithwaterman.cpp:40-78, :80-108 — an artefact its drivers never read back: sw_solve_big.cpp:84-88 only reads
+// pos / score / timings after repeats); a caller that depends on it gets the reference's behaviour with
+// PARSEQ_APPEND_CONSENSUS set in the environment (read once per process).
 #ifndef PARSEQ_SMITHWATERMAN_H_
 #define PARSEQ_SMITHWATERMAN_H_
 
+#include <cstdlib>
 #include <functional>
 #include <string>
 #include <string_view>
@@ -37,8 +41,10 @@ class SWAligner : public LocalAligner<Similarity_Matrix_Type> {
                                  sequence_y.size(), &p, &r), "SWAligner::calculateScore");
     max_score = r.score;
     pos = r.pos;
-    consensus_x.assign(r.cons_x, r.cons_len);
-    consensus_y.assign(r.cons_y, r.cons_len);
+    static const bool append = std::getenv("PARSEQ_APPEND_CONSENSUS") != nullptr;
+    if (!append) { consensus_x.clear(); consensus_y.clear(); }
+    consensus_x.append(r.cons_x, r.cons_len);
+    consensus_y.append(r.cons_y, r.cons_len);
     sm_timings.v[0] = r.timings_us[0];
     sm_timings.v[1] = r.timings_us[1];
     auto l = lut;

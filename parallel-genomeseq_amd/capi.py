@@ -20,7 +20,7 @@ EXPORTS = [
     "mi355_sw_multi_create", "mi355_sw_multi_destroy", "mi355_sw_multi_last_error", "mi355_sw_multi_device_count",
     "mi355_sw_multi_rccl_version", "mi355_sw_multi_align_split", "mi355_sw_multi_set_reference",
     "mi355_sw_multi_align_batch", "mi355_sw_multi_last_timings",
-    "mi355_sw_set_option", "mi355_sw_option_names", "mi355_sw_multi_set_option",
+    "mi355_sw_set_option", "mi355_sw_option_names", "mi355_sw_multi_set_option", "mi355_sw_last_counters", "mi355_sw_batch_upload_packed",
 ]
 MULTI_RCCL = 1
 
@@ -120,8 +120,11 @@ class Context:
         if rc:
             raise MI355Error(rc, "mi355_sw_create failed (no usable HIP device %d?)" % device)
         self.device = device
+        self._view = None              # struct-of-arrays view of the last batch_run(raw=True): library memory, see consensus()
+        self._nbatch = 0
 
     def close(self):
+        self._view = None
         if self._ctx:
             self._L.mi355_sw_destroy(self._ctx)
             self._ctx = C.c_void_p()
@@ -133,6 +136,7 @@ class Context:
             pass
 
     def _chk(self, rc):
+        self._view = None              # every library call invalidates the memory the last view points into
         if rc:
             raise MI355Error(rc, (self._L.mi355_sw_last_error(self._ctx) or b"").decode())
 
@@ -195,6 +199,20 @@ class Context:
         self._chk(self._L.mi355_sw_batch_upload(self._ctx, C.c_size_t(n), arr, lens))
         self._nbatch = n
 
+    def batch_upload_packed(self, buf, offsets):
+        """The batch as one contiguous buffer (bytes or uint8 array) and n + 1 ascending int64 offsets
+        (mi355_sw_batch_upload_packed): no per-sequence Python objects or pointers."""
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offs) - 1
+        if isinstance(buf, np.ndarray):
+            arr = np.ascontiguousarray(buf, dtype=np.uint8)
+            ptr = arr.ctypes.data_as(C.c_char_p)
+        else:
+            arr = bytes(buf)
+            ptr = C.c_char_p(arr)
+        self._chk(self._L.mi355_sw_batch_upload_packed(self._ctx, C.c_size_t(n), ptr, offs.ctypes.data_as(C.POINTER(C.c_int64))))
+        self._nbatch = n
+
     def batch_run(self, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None, flags=0, raw=False):
         p, keep = make_params(semantics, match, mismatch, gap, lut)
         n = self._nbatch
@@ -220,6 +238,11 @@ class Context:
     def consensus(self, k):
         """(cons_x, cons_y) of alignment k of the last batch_run(raw=True) (valid until the next call)."""
         v = self._view
+        if v is None:
+            raise RuntimeError("consensus(k): no batch_run(raw=True) result is current (the view dies with the next call on "
+                               "this context, with an empty batch and with close())")
+        if not 0 <= k < int(v.n):
+            raise IndexError("consensus(%d): the batch has %d alignments" % (k, int(v.n)))
         ln = int(v.cons_len[k])
         if ln == 0:
             return "", ""
@@ -258,6 +281,12 @@ class Context:
         self._L.mi355_sw_last_timings(self._ctx, t)
         return dict(score_us=t[0], locate_us=t[1], trace_us=t[2], total_us=t[3], score_launches=int(t[4]), cells=t[5])
 
+
+    def last_counters(self):
+        """Candidate-filter counters of the last call (mi355_sw_last_counters)."""
+        c = (C.c_uint64 * 4)()
+        self._L.mi355_sw_last_counters(self._ctx, c)
+        return dict(requeried=int(c[0]), whole_batch_again=int(c[1]), candidates=int(c[2]))
 
     def last_kernel(self):
         """The sw_score_kernel instance that swept the most cells in the last call (mi355_sw_last_kernel)."""

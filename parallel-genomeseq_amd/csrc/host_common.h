@@ -14,7 +14,7 @@ constexpr size_t kExactLdsMax = 159 * 1024;    // dynamic part; the wide instanc
 #define MI355_SW_BOOL_OPTIONS(X) \
   X(no_f16) X(no_unsat) X(no_sample) X(no_satflag) X(no_solo) X(no_wave) X(no_comb) X(no_twin) X(no_wide) X(no_strip) \
   X(no_quant) X(no_f16_wide) X(no_devlist) X(no_ref_cache) X(no_strip_groups) X(u8_long_twin) X(long_twin) X(no_long) \
-  X(no_requery) X(trace)
+  X(no_requery) X(force_f32) X(trace)
 #define MI355_SW_INT_OPTIONS(X) X(strip_r) X(slot) X(few_r) X(chunk) X(long_pipes) X(long_wgs) X(long_sub) X(long_r)
 struct Options {
 #define X(n) bool n = false;
@@ -250,8 +250,11 @@ struct mi355_sw_ctx {
   QueryBatch one;                 // the single query of such a call
   // scratch
   uint32_t flag_cap = 0;          // entries of `flags` (score_begin)
+  size_t requeried = 0;           // queries of the running call that were swept a second time on the exact instances
+  size_t whole_again = 0;         // ... times the whole batch was (most of it exceeded its candidate cap)
+  size_t candidates = 0;          // candidate sub-chunks the sampled / saturating sweeps of the call flagged
   bool long_launched = false;     // a sw_long_kernel launch since the last score_fetch (its status word is flags[1])
-  DevBuf keys, ranges, stab, ftab, ftab_s, htab, htab8, soloblk, flags, submax, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs, scan;
+  DevBuf qcnt, sel2, keys, ranges, stab, ftab, ftab_s, htab, htab8, soloblk, flags, submax, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs, scan;
   // host sides of small per-call uploads: they must outlive the asynchronous copies, and the tables are only
   // sent again when they change
   std::vector<int64_t> h_ranges;
@@ -526,6 +529,38 @@ bool adhoc_confirm(mi355_sw_ctx *ctx, const char *y, size_t ny, const RefData **
   return false;
 }
 
+// stable order of the batch by length: a counting sort when the batch is large (561 k UniProt sequences: 40 ms -> 3 ms)
+void sort_queries_by_length(QueryBatch &q, size_t mx) {
+  const size_t n = q.nq;
+  q.order.resize(n);
+  if (n >= 4096 && mx <= ((size_t)1 << 22)) {
+    std::vector<uint32_t> start(mx + 2, 0);
+    for (size_t k = 0; k < n; ++k) start[(size_t)q.len[k] + 1]++;
+    for (size_t l = 1; l < start.size(); ++l) start[l] += start[l - 1];
+    for (size_t k = 0; k < n; ++k) q.order[start[(size_t)q.len[k]]++] = (int32_t)k;
+  } else {
+    for (size_t k = 0; k < n; ++k) q.order[k] = (int32_t)k;
+    std::stable_sort(q.order.begin(), q.order.end(), [&](int32_t a, int32_t b) { return q.len[a] < q.len[b]; });
+  }
+  q.cumlen.resize(n + 1);
+  q.cumlen[0] = 0;
+  for (size_t k = 0; k < n; ++k) q.cumlen[k + 1] = q.cumlen[k] + q.len[q.order[k]];
+}
+
+// lengths / offsets / sorted ids / prefix sums to the device (the bytes go separately)
+int upload_query_index(mi355_sw_ctx *ctx, QueryBatch &q, size_t tot) {
+  const size_t n = q.nq;
+  if (q.bytes.ensure(tot + 16) || q.lens.ensure(n * 4 + 16) || q.offs.ensure(n * 8 + 16) || q.sel.ensure(n * 4 + 16) ||
+      q.cum.ensure((n + 1) * 8 + 16))
+    return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(queries) failed");
+  HIPCHK(ctx, hipMemcpyAsync(q.cum.p, q.cumlen.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(q.lens.p, q.len.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(q.offs.p, q.off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(q.sel.p, q.order.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(q.bytes.as<uint8_t>() + tot, 0, 16, ctx->stream));
+  return 0;
+}
+
 int upload_queries(mi355_sw_ctx *ctx, QueryBatch &q, size_t n, const char *const *xs, const size_t *nxs) {
   HostTrace trace_("upload_queries");
   q.nq = n;
@@ -541,17 +576,7 @@ int upload_queries(mi355_sw_ctx *ctx, QueryBatch &q, size_t n, const char *const
     mx = std::max(mx, nxs[k]);
   }
   q.maxlen = (int)mx;
-  // stable order by length: a counting sort when the batch is large (561 k UniProt sequences: 40 ms -> 3 ms)
-  q.order.resize(n);
-  if (n >= 4096 && mx <= ((size_t)1 << 22)) {
-    std::vector<uint32_t> start(mx + 2, 0);
-    for (size_t k = 0; k < n; ++k) start[(size_t)q.len[k] + 1]++;
-    for (size_t l = 1; l < start.size(); ++l) start[l] += start[l - 1];
-    for (size_t k = 0; k < n; ++k) q.order[start[(size_t)q.len[k]]++] = (int32_t)k;
-  } else {
-    for (size_t k = 0; k < n; ++k) q.order[k] = (int32_t)k;
-    std::stable_sort(q.order.begin(), q.order.end(), [&](int32_t a, int32_t b) { return q.len[a] < q.len[b]; });
-  }
+  sort_queries_by_length(q, mx);
   // staging copy (16-byte aligned starts; the padding is never read): helper threads share a large batch
   std::unique_ptr<uint8_t[]> host_buf(new uint8_t[tot + 16]);
   uint8_t *host = host_buf.get();
@@ -565,18 +590,43 @@ int upload_queries(mi355_sw_ctx *ctx, QueryBatch &q, size_t n, const char *const
   } else {
     copy_part(0, n);
   }
-  memset(host + tot, 0, 16);
-  q.cumlen.resize(n + 1);
-  q.cumlen[0] = 0;
-  for (size_t k = 0; k < n; ++k) q.cumlen[k + 1] = q.cumlen[k] + q.len[q.order[k]];
-  if (q.bytes.ensure(tot + 16) || q.lens.ensure(n * 4 + 16) || q.offs.ensure(n * 8 + 16) || q.sel.ensure(n * 4 + 16) ||
-      q.cum.ensure((n + 1) * 8 + 16))
-    return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(queries) failed");
-  HIPCHK(ctx, hipMemcpyAsync(q.cum.p, q.cumlen.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(q.bytes.p, host, tot + 16, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(q.lens.p, q.len.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(q.offs.p, q.off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(q.sel.p, q.order.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  int rc = upload_query_index(ctx, q, tot);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(q.bytes.p, host, tot, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// The batch as ONE contiguous buffer + n + 1 ascending offsets (what a multi-FASTA reader has; the reference concatenates each
+// sequence's lines into one string, src/mpi_sw_solve_uniprot.cpp:97-110): no per-sequence pointers, no staging copy — the
+// caller's bytes go to the device as they are (in a few large pieces, so that the first ones travel while the index is sorted
+// on the host), sequence k = buf[offsets[k], offsets[k + 1]).
+int upload_queries_packed(mi355_sw_ctx *ctx, QueryBatch &q, size_t n, const char *buf, const int64_t *offsets) {
+  HostTrace trace_("upload_queries_packed");
+  if (n && offsets[0] < 0) return fail(ctx, MI355_SW_EINVAL, "negative offset");
+  const size_t base = n ? (size_t)offsets[0] : 0, tot = n ? (size_t)(offsets[n] - offsets[0]) : 0;
+  if (q.bytes.ensure(tot + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(queries) failed");
+  const size_t piece = (size_t)32 << 20;
+  for (size_t at = 0; at < tot; at += piece)                         // asynchronous to the host work below
+    HIPCHK(ctx, hipMemcpyAsync(q.bytes.as<uint8_t>() + at, buf + base + at, std::min(piece, tot - at), hipMemcpyHostToDevice, ctx->stream));
+  q.nq = n;
+  ++q.version;
+  q.len.resize(n);
+  q.off.resize(n);
+  size_t mx = 0;
+  bool bad = false;
+  for (size_t k = 0; k < n; ++k) {
+    const int64_t len = offsets[k + 1] - offsets[k];
+    bad |= len < 0 || len > 0x3fffffff;
+    q.len[k] = (int32_t)len;
+    q.off[k] = offsets[k] - (int64_t)base;
+    mx = std::max(mx, (size_t)std::max<int64_t>(len, 0));
+  }
+  if (bad) { (void)hipStreamSynchronize(ctx->stream); q.nq = 0; return fail(ctx, MI355_SW_EINVAL, "offsets must ascend (sequence longer than 2^30 or negative length)"); }
+  q.maxlen = (int)mx;
+  sort_queries_by_length(q, mx);
+  int rc = upload_query_index(ctx, q, tot);
+  if (rc) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }

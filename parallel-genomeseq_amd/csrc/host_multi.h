@@ -86,18 +86,29 @@ int on_devices(mi355_sw_multi *m, F fn) {
   return 0;
 }
 
-// MAX over the devices' keys with one ncclAllReduce(ncclMax, ncclUint64) per device over xGMI.
-// Called from inside on_devices (every device thread passes its own key and gets the global one).
-int merge_key_rccl(mi355_sw_multi *m, int d, unsigned long long key, unsigned long long *out) {
-  mi355_sw_ctx *c = m->ctx[d];
-  HIPCHK(c, hipSetDevice(c->device));
-  unsigned long long *buf = m->keybuf[d].as<unsigned long long>();
-  HIPCHK(c, hipMemcpyAsync(buf, &key, 8, hipMemcpyHostToDevice, c->stream));
-  const ncclResult_t r = m->rccl.AllReduce(buf, buf + 1, 1, ncclUint64, ncclMax, m->comms[d], c->stream);
-  if (r != ncclSuccess) return fail(c, MI355_SW_ENODEV, std::string("ncclAllReduce: ") + m->rccl.GetErrorString(r));
-  HIPCHK(c, hipMemcpyAsync(out, buf + 1, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return 0;
+// MAX over the devices' keys with one ncclAllReduce(ncclMax, ncclUint64) per device over xGMI, in two on_devices passes:
+// everything that can fail on ONE device alone (hipSetDevice, staging the key) happens in the first; the collective is entered
+// in the second, and only when the first succeeded on every device — a device that failed would otherwise leave the others
+// waiting in the all-reduce forever.
+int merge_keys_rccl(mi355_sw_multi *m, std::vector<unsigned long long> &keys) {
+  int rc = on_devices(m, [&](int d) -> int {
+    mi355_sw_ctx *c = m->ctx[d];
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(m->keybuf[d].as<unsigned long long>(), &keys[d], 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+  });
+  if (rc) return rc;
+  return on_devices(m, [&](int d) -> int {
+    mi355_sw_ctx *c = m->ctx[d];
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long *buf = m->keybuf[d].as<unsigned long long>();
+    const ncclResult_t r = m->rccl.AllReduce(buf, buf + 1, 1, ncclUint64, ncclMax, m->comms[d], c->stream);
+    if (r != ncclSuccess) return fail(c, MI355_SW_ENODEV, std::string("ncclAllReduce: ") + m->rccl.GetErrorString(r));
+    HIPCHK(c, hipMemcpyAsync(&keys[d], buf + 1, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+  });
 }
 
 void multi_timings(mi355_sw_multi *m) {
@@ -190,32 +201,47 @@ int mi355_sw_multi_align_split(mi355_sw_multi *m, const char *x, size_t nx, cons
   if (rc) return mfail(m, rc, "_make_string_range: the reference's asserts would fire for these arguments");
   memset(out, 0, sizeof *out);
   const int ndev = (int)m->ctx.size();
-  // one hash of the caller's reference for all devices (each keeps its copy resident across calls)
+  // Every device holds ONLY its own pieces (piece p -> device p mod ndev; each piece's matrix is built on its own sub-string
+  // only, plocalaligner.cpp:96-102): the pieces are packed back to back into one staging buffer per device, hashed (the
+  // resident copy is reused when a later call passes the same bytes) and uploaded — 1/ndev of the reference plus the overlaps
+  // per device instead of all of it.  One device: the caller's buffer as it is.
   OptScope opt_scope0_(m->ctx[0]);
-  const Hash128 h = adhoc_cache_enabled() ? content_hash(y, ny) : Hash128();
   mi355_sw_params ps = *params;
   ps.semantics = sm_semantics;
   std::vector<float> pmax(npiece, 0.0f);
   std::vector<unsigned long long> gkey(ndev, 0ull);
   std::vector<const RefData *> refs(ndev, nullptr);
+  std::vector<std::vector<Range>> local(ndev);                     // device d's pieces inside ITS resident buffer
+  std::vector<std::vector<int>> ids(ndev);
   rc = on_devices(m, [&](int d) -> int {
     mi355_sw_ctx *c = m->ctx[d];
     OptScope opt_scope_(c);
     HIPCHK(c, hipSetDevice(c->device));
     reset_timings(c);
-    std::vector<Range> mine;
-    std::vector<int> ids;
-    for (int p = d; p < npiece; p += ndev) { mine.push_back(Range{lefts[p], rights[p]}); ids.push_back(p); }   // piece p -> device p mod ndev
+    size_t total = 0;
+    for (int p = d; p < npiece; p += ndev) {                       // piece p -> device p mod ndev
+      ids[d].push_back(p);
+      local[d].push_back(ndev == 1 ? Range{lefts[p], rights[p]} : Range{(int64_t)total, (int64_t)total + (rights[p] - lefts[p])});
+      total += (size_t)(rights[p] - lefts[p]);
+    }
     unsigned long long key = 0;                                    // "no piece": below every real key
-    if (!mine.empty()) {
-      int r = adhoc_reference(c, y, ny, &refs[d], &h);
+    if (!ids[d].empty()) {
+      int r = 0;
+      if (ndev == 1) {
+        r = adhoc_reference(c, y, ny, &refs[d]);
+      } else {
+        std::unique_ptr<char[]> stage(new char[total + 1]);
+        for (size_t k = 0; k < ids[d].size(); ++k)
+          memcpy(stage.get() + local[d][k].lo, y + lefts[ids[d][k]], (size_t)(rights[ids[d][k]] - lefts[ids[d][k]]));
+        r = adhoc_reference(c, stage.get(), total, &refs[d]);
+      }
       if (!r) r = upload_queries(c, c->one, 1, &x, &nx);
-      std::vector<float> mx(mine.size(), 0.0f);
-      if (!r) r = range_maxima(c, *refs[d], c->one, mine, ps, mx.data());
+      std::vector<float> mx(ids[d].size(), 0.0f);
+      if (!r) r = range_maxima(c, *refs[d], c->one, local[d], ps, mx.data());
       if (r) return r;
-      for (size_t k = 0; k < ids.size(); ++k) {
-        pmax[ids[k]] = mx[k];
-        key = std::max(key, pack_best(mx[k], (uint32_t)ids[k]));
+      for (size_t k = 0; k < ids[d].size(); ++k) {
+        pmax[ids[d][k]] = mx[k];
+        key = std::max(key, pack_best(mx[k], (uint32_t)ids[d][k]));
       }
     }
     gkey[d] = key;
@@ -225,7 +251,7 @@ int mi355_sw_multi_align_split(mi355_sw_multi *m, const char *x, size_t nx, cons
   unsigned long long best = 0;
   if (m->flags & MI355_SW_MULTI_RCCL) {
     // second phase, entered only when every device finished its sweep: nobody can be left waiting in the collective
-    rc = on_devices(m, [&](int d) -> int { return merge_key_rccl(m, d, gkey[d], &gkey[d]); });
+    rc = merge_keys_rccl(m, gkey);
     if (rc) return rc;
     best = gkey[0];
     for (int d = 1; d < ndev; ++d)
@@ -243,7 +269,7 @@ int mi355_sw_multi_align_split(mi355_sw_multi *m, const char *x, size_t nx, cons
   mi355_sw_params pd;
   mi355_sw_default_params(&pd);                                    // LAT(x, piece): default scoring (plocalaligner.cpp:135)
   pd.semantics = la_semantics;
-  rc = align_range(c, *refs[owner], c->one, Range{lefts[bp], rights[bp]}, pd, 0, out);
+  rc = align_range(c, *refs[owner], c->one, local[owner][(size_t)(bp / ndev)], pd, 0, out);
   if (rc) return mfail(m, rc, c->err);
   if (out->score > 0) { out->pos += (uint32_t)lefts[bp]; out->end_y += lefts[bp]; }
   else out->pos = (uint32_t)lefts[bp];
@@ -322,7 +348,7 @@ int mi355_sw_multi_align_batch(mi355_sw_multi *m, size_t n, const char *const *x
     return 0;
   });
   if (!rc && (m->flags & MI355_SW_MULTI_RCCL))                     // second phase: every device finished its share
-    rc = on_devices(m, [&](int d) -> int { return merge_key_rccl(m, d, gkey[d], &gkey[d]); });
+    rc = merge_keys_rccl(m, gkey);
   if (rc) {                                                        // nothing half-filled leaves the call
     mi355_sw_free_results(outs, n);
     memset(outs, 0, n * sizeof *outs);

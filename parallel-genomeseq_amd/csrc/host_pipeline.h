@@ -522,19 +522,69 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       const bool trace_on = opt().trace;
       if (trace_on) std::fprintf(stderr, "[mi355_sw] saturating / sampled sweep: %u candidate sub-chunks of %zu queries (budget %.0f)\n", nflag, nsatq,
                                  64.0 * (double)nsatq + 1024.0);
-      if (nflag > ctx->flag_cap || (double)nflag > 64.0 * (double)nsatq + 1024.0) {
-        // saturated nearly everywhere (a background that reaches the cap): the exact packed int16 sweep instead
+      auto whole_batch_again = [&]() {
+        // saturated nearly everywhere (a background that reaches the cap): the exact sweep instead, for every query
         allow_sat = false;
         allow_sample = false;
         ctx->last_kernel.cells = 0;                                  // the sweep that counts is the one that follows
-        continue;
-      }
+        ctx->timings[4] = 0; ctx->timings[5] = 0;                    // launches / cells: only the sweep that produced the result
+                                                                     // (its device time stays in timings[0]: honest extra cost)
+        ctx->whole_again += 1;
+      };
+      if (nflag > ctx->flag_cap) { whole_batch_again(); continue; }  // (only the unfiltered saturating sweep can overflow the list)
       std::vector<uint32_t> raw(2 * (size_t)nflag);
       if (nflag) HIPCHK(ctx, hipMemcpy(raw.data(), ctx->flags.as<unsigned int>() + 2, (size_t)nflag * 8, hipMemcpyDeviceToHost));
       std::vector<std::pair<uint32_t, uint32_t>> flagged(nflag);
       for (size_t f = 0; f < nflag; ++f) flagged[f] = {raw[2 * f], raw[2 * f + 1]};
       std::sort(flagged.begin(), flagged.end());
       flagged.erase(std::unique(flagged.begin(), flagged.end()), flagged.end());
+      ctx->candidates += flagged.size();
+      // Per QUERY, not per call: a query with more candidates than its cap (a poly-A or microsatellite read against a repeat-rich
+      // reference flags thousands of near-equal sub-chunks) is swept again on the exact instances, alone with the other
+      // offenders; everybody else keeps the candidates of the first sweep.  Only when most of the batch offends (a background
+      // that reaches the cap everywhere) is the whole batch swept again.
+      const uint32_t qcap = query_flag_cap(nq);
+      std::vector<uint32_t> qcount(nq, 0);
+      for (const auto &f : flagged) if (f.first < nq) qcount[f.first]++;
+      std::vector<int> offenders;
+      for (size_t k = 0; k < nq; ++k) if (qsat[k] && qcount[k] > qcap) offenders.push_back((int)k);
+      if (trace_on) std::fprintf(stderr, "[mi355_sw] %zu of %zu queries exceed %u candidates\n", offenders.size(), nsatq, qcap);
+      if (!offenders.empty() && (opt().no_requery || 2 * offenders.size() > nsatq)) { whole_batch_again(); continue; }
+      if (!offenders.empty()) {
+        flagged.erase(std::remove_if(flagged.begin(), flagged.end(), [&](const std::pair<uint32_t, uint32_t> &f) { return qcount[f.first] > qcap; }),
+                      flagged.end());
+        // a view of the batch that lists only the offenders (same device bytes / offsets / lengths, own sorted id list)
+        QueryBatch qo;
+        qo.bytes.alias(q.bytes.p); qo.lens.alias(q.lens.p); qo.offs.alias(q.offs.p); qo.cum.alias(q.cum.p);
+        qo.len = q.len; qo.off = q.off;
+        qo.order.assign(offenders.begin(), offenders.end());
+        std::stable_sort(qo.order.begin(), qo.order.end(), [&](int32_t a, int32_t b2) { return q.len[a] < q.len[b2]; });
+        qo.nq = offenders.size();
+        qo.maxlen = 0;
+        for (int id : offenders) qo.maxlen = std::max(qo.maxlen, (int)q.len[id]);
+        if (ctx->sel2.ensure(qo.nq * 4 + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
+        HIPCHK(ctx, hipMemcpy(ctx->sel2.p, qo.order.data(), qo.nq * 4, hipMemcpyHostToDevice));
+        qo.sel.alias(ctx->sel2.p);
+        std::vector<Bucket> again = make_buckets(ref, qo, table, p, n, false, false);
+        rc = score_begin(ctx, q, ranges, table);                     // (clears every key: the first sweep's are on the host)
+        if (rc) return rc;
+        for (Bucket &b : again) {
+          b.fast = bucket_fast_ok(ref, table, b, n, p);
+          if (!b.fast) return fail(ctx, MI355_SW_ENODEV, "internal: an exact instance refuses a query the sampled one took");
+          rc = score_launch(ctx, ref, qo, ranges, p, table, b);
+          if (rc) return rc;
+          for (int k = 0; k < b.count; ++k) {
+            const int id = qo.order[b.first + k];
+            qchunk[id] = b.sub_len; qwarm[id] = b.warm; qsat[id] = 0;
+            qfloat[id] = b.sem == kSemF16 ? 2 : (b.sem == kSemU8H ? 3 : (b.sem == kSemF32 ? 4 : (sem_is_float(b.sem) ? 1 : 0)));
+          }
+        }
+        std::vector<unsigned long long> keys2;
+        rc = score_fetch(ctx, nq, keys2);
+        if (rc) return rc;
+        for (int id : offenders) keys[id] = keys2[id];
+        ctx->requeried += offenders.size();
+      }
       HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
       std::vector<float> qlower(nq, 0.0f);                          // the sweep's key: a lower bound of the query's maximum
       for (size_t k = 0; k < nq; ++k) {
@@ -759,6 +809,7 @@ void reset_timings(mi355_sw_ctx *ctx) {
   for (double &t : ctx->timings) t = 0;
   ctx->score_ev_used = 0; ctx->arenas.clear(); ctx->cons_used = 0;
   ctx->last_kernel = mi355_sw_kernel_info{};
+  ctx->requeried = 0; ctx->whole_again = 0; ctx->candidates = 0;
 }
 
 }  // namespace

@@ -242,7 +242,8 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       }
     } else {
       // packed 16-bit cells when scores are small integers and the score bound fits; float32 cells otherwise
-      const bool fits = t.integral && (int64_t)t.smax * std::min<int64_t>(b.maxlen, std::max<int64_t>(n, 1)) + t.smax <= 32000;
+      // (option force_f32: the float32 instance for everything — what bench.py's parity_check runs the resident batch on again)
+      const bool fits = !opt().force_f32 && t.integral && (int64_t)t.smax * std::min<int64_t>(b.maxlen, std::max<int64_t>(n, 1)) + t.smax <= 32000;
       b.sem = fits ? kSemI16 : kSemF32;
       // small scores on short reads: packed float16 cells (clamped add + three-input maximum: 3.5 instead of 4.5 ops per cell)
       const bool f16_wide = !opt().no_f16_wide;                                                 // A/B switch
@@ -608,6 +609,8 @@ int score_tables(mi355_sw_ctx *ctx, int maxlen, int64_t maxrange, const ScoreTab
 }
 
 constexpr uint32_t kFlagCap = 1u << 20;   // (query, sub-chunk) pairs a saturating float16 sweep may flag before it is abandoned
+// candidates one query may have before IT is swept again exactly (sampled sweeps): 64, plus a share of 1024 (a lone query: 1088)
+inline uint32_t query_flag_cap(size_t nq) { return 64u + (uint32_t)(1024 / std::max<size_t>(1, nq)); }
 
 // Uploads what every score launch of a call shares and clears the keys.
 int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range> &ranges, const ScoreTable &t) {
@@ -625,9 +628,12 @@ int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range>
   if (rc) return rc;
   HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, nq * nr * 8, ctx->stream));
   // room for the flagged (query, sub-chunk) pairs: a few per query (sampled / saturating sweeps), at least kFlagCap
-  ctx->flag_cap = (uint32_t)std::min<size_t>(0x7FFFFFFFu, std::max<size_t>(kFlagCap, 4 * q.nq + 4096));
-  if (ctx->flags.ensure(8 + (size_t)ctx->flag_cap * 8)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
+  // (the filter of the sampled sweeps appends at most query_flag_cap + 1 entries per query: its list cannot overflow)
+  ctx->flag_cap = (uint32_t)std::min<size_t>(0x7FFFFFFFu, std::max<size_t>(kFlagCap, (size_t)(query_flag_cap(q.nq) + 2) * q.nq + 4096));
+  if (ctx->flags.ensure(8 + (size_t)ctx->flag_cap * 8) || ctx->qcnt.ensure(q.nq * 4 + 16))
+    return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
   HIPCHK(ctx, hipMemsetAsync(ctx->flags.p, 0, 8, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->qcnt.p, 0, q.nq * 4, ctx->stream));
   return 0;
 }
 
@@ -720,7 +726,8 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     hipLaunchKernelGGL(sw_sample_filter<true>, fgrid, dim3(256), 0, ctx->stream, (const void *)a.submax_out, nsub, nsub,
                        q.sel.as<int32_t>(), b.first, 1, (const unsigned long long *)a.keys,
                        std::ldexp(3.0f * t.gapf, -ctx->fshift),
-                       ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), ctx->flag_cap);
+                       ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), ctx->flag_cap,
+                       ctx->qcnt.as<unsigned int>(), query_flag_cap(q.nq));
     HIPCHK(ctx, hipGetLastError());
   }
   HIPCHK(ctx, hipEventRecord(ctx->score_ev[ctx->score_ev_used + 1], ctx->stream));
@@ -873,11 +880,13 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
         hipLaunchKernelGGL(sw_sample_filter<true>, fgrid, dim3(256), 0, ctx->stream, rows, nsub, nsub,
                            (const int32_t *)a.qsel, a.qfirst + f0, fc, (const unsigned long long *)a.keys,
                            std::ldexp(3.0f * t.gapf + (t.integral ? 0.0f : std::ldexp(t.smaxf * (float)(b.maxlen + 1), -20)), -ctx->fshift),
-                           ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), ctx->flag_cap);
+                           ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), ctx->flag_cap,
+                           ctx->qcnt.as<unsigned int>(), query_flag_cap(q.nq));
       else
         hipLaunchKernelGGL(sw_sample_filter<false>, fgrid, dim3(256), 0, ctx->stream, rows, nsub, nsub,
                            (const int32_t *)a.qsel, a.qfirst + f0, fc, (const unsigned long long *)a.keys, 3.0f * (float)t.gap,
-                           ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), ctx->flag_cap);
+                           ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), ctx->flag_cap,
+                           ctx->qcnt.as<unsigned int>(), query_flag_cap(q.nq));
       HIPCHK(ctx, hipGetLastError());
     }
   }

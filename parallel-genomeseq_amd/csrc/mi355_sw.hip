@@ -83,7 +83,7 @@ int mi355_sw_create(mi355_sw_ctx **out, int device) {
 void mi355_sw_destroy(mi355_sw_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  DevBuf *bufs[] = {&c->ref.bytes, &c->ref.codes, &c->batch.bytes, &c->batch.lens, &c->keys, &c->ranges, &c->stab,
+  DevBuf *bufs[] = {&c->qcnt, &c->sel2, &c->ref.bytes, &c->ref.codes, &c->batch.bytes, &c->batch.lens, &c->keys, &c->ranges, &c->stab,
                     &c->batch.offs, &c->batch.sel, &c->ftab, &c->ftab_s, &c->htab, &c->htab8, &c->soloblk, &c->flags, &c->submax, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow, &c->wprobs, &c->scan, &c->batch.cum};
   for (DevBuf *b : bufs) b->release();
   c->adhoc.release(); c->one.release();
@@ -117,6 +117,13 @@ int mi355_sw_batch_upload(mi355_sw_ctx *ctx, size_t n, const char *const *xs, co
   if (!ctx || !xs || !nxs) return MI355_SW_EINVAL;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   return upload_queries(ctx, ctx->batch, n, xs, nxs);
+}
+
+int mi355_sw_batch_upload_packed(mi355_sw_ctx *ctx, size_t n, const char *buf, const int64_t *offsets) {
+  OptScope opt_scope_(ctx);
+  if (!ctx || (n && (!buf || !offsets))) return MI355_SW_EINVAL;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return upload_queries_packed(ctx, ctx->batch, n, buf, offsets);
 }
 
 int mi355_sw_batch_run(mi355_sw_ctx *ctx, const mi355_sw_params *params, int flags, mi355_sw_result *outs) {
@@ -406,6 +413,12 @@ void mi355_sw_raw2true(size_t nx, size_t ny, size_t ri, size_t rj, size_t *ti, s
 int mi355_sw_last_timings(const mi355_sw_ctx *ctx, double out[6]) {
   if (!ctx || !out) return MI355_SW_EINVAL;
   for (int k = 0; k < 6; ++k) out[k] = ctx->timings[k];
+  return 0;
+}
+
+int mi355_sw_last_counters(const mi355_sw_ctx *ctx, uint64_t out[4]) {
+  if (!ctx || !out) return MI355_SW_EINVAL;
+  out[0] = ctx->requeried; out[1] = ctx->whole_again; out[2] = ctx->candidates; out[3] = 0;
   return 0;
 }
 

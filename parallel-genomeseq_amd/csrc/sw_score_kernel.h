@@ -671,10 +671,14 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const ScoreArgs a) {
 // Sampled sweep (MK > 1): every sub-chunk whose value lies within `slack` (in H units) of its query's final key may hold
 // the true maximum — append it to the flag list.  grid.y = launch-local query position, threads stride over sub-chunks.
 // F32V: float32 cells (values and key are float bit patterns in the sweep's scaled units, and so is `slack`).
+// qcnt / per_query_cap: candidates are also counted per query, and a query appends at most per_query_cap + 1 of them — one
+// low-complexity read with a hundred thousand near-equal hits cannot crowd the list; the host re-sweeps exactly the
+// queries whose count exceeds the cap (host_pipeline.h) and keeps everybody else's candidates.
 template <bool F32V>
 __global__ __launch_bounds__(256) void sw_sample_filter(const void *submax, int64_t stride, int64_t nsub, const int32_t *qsel,
                                                         int qfirst, int qcount, const unsigned long long *keys, float slack,
-                                                        unsigned int *flag_count, uint2 *flag_list, uint32_t flag_cap) {
+                                                        unsigned int *flag_count, uint2 *flag_list, uint32_t flag_cap,
+                                                        unsigned int *qcnt = nullptr, uint32_t per_query_cap = 0) {
   const int pos = blockIdx.y;
   if (pos >= qcount) return;
   const int q = qsel[qfirst + pos];
@@ -687,6 +691,7 @@ __global__ __launch_bounds__(256) void sw_sample_filter(const void *submax, int6
     const float v = F32V ? __uint_as_float(static_cast<const uint32_t *>(submax)[at])
                          : (float)__builtin_bit_cast(_Float16, static_cast<const uint16_t *>(submax)[at]) * 2048.0f;
     if (v > 0.0f && v >= thr) {
+      if (qcnt != nullptr && atomicAdd(&qcnt[q], 1u) > per_query_cap) continue;
       const unsigned int at = atomicAdd(flag_count, 1u);
       if (at < flag_cap) flag_list[at] = make_uint2((unsigned int)q, (unsigned int)s);
     }

@@ -60,6 +60,9 @@ def pack_key(score, index):
     return (int(s.view(np.uint32)) << 32) | (0xFFFFFFFF - int(index))
 
 
+BAD_KEY = (0x7FC00000 << 32) | 0xFFFFFFFF      # above every valid key (float32 NaN pattern): "some rank saw a bad score"
+
+
 def unpack_key(key):
     return float(np.uint32(key >> 32).view(np.float32)), 0xFFFFFFFF - (key & 0xFFFFFFFF)
 
@@ -116,12 +119,16 @@ def align_split_sharded(ranges, piece_maxima_fn, final_align_fn):
     maxima = piece_maxima_fn(mine) if mine else []
     key = 0                                                   # "no piece": below every packed key (index < 2^32 - 1)
     # serial rule (plocalaligner.cpp:122-129): max_score_l starts at -1, strict '>' -> first piece with the max
+    # a negative / NaN maximum on ONE rank must not leave the others waiting in the collective: it travels as a sentinel key
+    # above every valid one, and every rank raises after the all-reduce
     for p, v in zip(mine, maxima):
-        key = max(key, pack_key(v, p))
+        key = max(key, pack_key(v, p) if np.float32(v) >= 0 else BAD_KEY)
     if size > 1:
         t = torch.tensor([key], dtype=torch.int64, device=_dev())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         key = int(t.item())
+    if key == BAD_KEY:
+        raise ValueError("a rank reported a negative or NaN piece maximum (scores are maxima of cells >= 0)")
     _, piece = unpack_key(key)
     owner = piece % size
     res = None
@@ -132,6 +139,8 @@ def align_split_sharded(ranges, piece_maxima_fn, final_align_fn):
         if res.get("end_y", 0) > 0:
             res["end_y"] = res["end_y"] + left
         res["piece"] = piece
+        # every rank returns the same keys: what travels in the broadcast (the owner's device timings stay with the owner)
+        res = {k: res.get(k, 0) for k in ("score", "pos", "end_x", "end_y", "cons_x", "cons_y", "piece")}
     if size > 1:
         res = _broadcast_result(res, owner)
     return res, piece

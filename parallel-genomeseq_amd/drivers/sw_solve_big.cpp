@@ -15,57 +15,62 @@
 #include "parseq/smithwaterman.h"
 
 template <class SMT>
-int run(int npiece, int nrepeat, const std::string &fa_string, const std::string &in_path) {
-  std::ifstream align_input(in_path);
-  if (!align_input) { std::cerr << "cannot open " << in_path << std::endl; return 2; }
-  std::string input_line;
-  double time_avg = 0.0, time_iter_avg = 0.0;
-  unsigned long long num_cells = 0;
-  int i = 0;
-  std::vector<double> GCUPS_vec;
-  const double overlaprate = 2.0;
-  while (std::getline(align_input, input_line)) {
-    if (i > 0) {
-      const std::vector<std::string> row = drv::split_row(input_line);
-      const auto matsize = row.at(2).size() * fa_string.size();
-      if (i == 1) {
-        std::cout << "[INFO] Estimated Memory consumption of the reference's matrix " << (double)matsize * 1e-9
-                  << "GB (not allocated here)" << std::endl;
+int run(int npiece, int nrepeat, const std::string &reference, const std::string &reads_path) {
+  std::ifstream reads(reads_path);
+  if (!reads) { std::cerr << "cannot open " << reads_path << std::endl; return 2; }
+  std::string line;
+  double sum_best_us = 0.0, sum_best_pieces_us = 0.0;   // per read: the fastest repeat's getTimings()[0] / [1]
+  unsigned long long cells_total = 0;
+  int lineno = 0;
+  std::vector<double> gcups_per_read;
+  const double overlap = 2.0;                           // sw_solve_big.cpp:53
+  while (std::getline(reads, line)) {
+    if (lineno > 0) {                                   // line 0 is the CSV header
+      const std::vector<std::string> row = drv::split_row(line);
+      const std::string &read = row.at(2);
+      const auto cells = read.size() * reference.size();
+      if (lineno == 1) {
+        // the reference prints the size of ITS matrix here (sw_solve_big.cpp:71); this engine never materialises one, the
+        // line is kept verbatim so that scripts that parse the driver's output keep working
+        std::cout << "[INFO] Estimated Memory consumption " << (double)(cells * sizeof(uint8_t)) * 1e-9 << "GB" << std::endl;
+        if (npiece > 0)                                 // the reference's USEOMP build (sw_solve_big.cpp:72-74)
+          std::cout << "[INFO] Theoretical GCUPS on Leonhard: "
+                    << npiece * 4.6 / (reference.size() + 2 * (npiece - 1) * overlap * read.size()) * reference.size() << std::endl;
       }
-      double time_min = 9e20, time_iter_min = 9e20;
+      double best_us = 9e20, best_pieces_us = 9e20;
       if (npiece > 0) {
-        auto la = std::make_unique<OMPParallelLocalAligner<SMT, SWAligner<SMT>>>(row[2], fa_string, npiece * 2, overlaprate);
-        for (int j = 0; j < nrepeat; j++) {
-          la->calculateScore();
-          time_min = std::min(time_min, (double)la->getTimings()[0]);
-          time_iter_min = std::min(time_iter_min, (double)la->getTimings()[1]);
+        auto aligner = std::make_unique<OMPParallelLocalAligner<SMT, SWAligner<SMT>>>(read, reference, npiece * 2, overlap);
+        for (int rep = 0; rep < nrepeat; rep++) {
+          aligner->calculateScore();
+          best_us = std::min(best_us, (double)aligner->getTimings()[0]);
+          best_pieces_us = std::min(best_pieces_us, (double)aligner->getTimings()[1]);
         }
       } else {
-        auto la = std::make_unique<SWAligner<SMT>>(row[2], fa_string);
-        for (int j = 0; j < nrepeat; j++) {
-          la->calculateScore();
-          time_min = std::min(time_min, (double)la->getTimings()[0]);
-          time_iter_min = time_min;
+        auto aligner = std::make_unique<SWAligner<SMT>>(read, reference);
+        for (int rep = 0; rep < nrepeat; rep++) {
+          aligner->calculateScore();
+          best_us = std::min(best_us, (double)aligner->getTimings()[0]);
+          best_pieces_us = best_us;
         }
       }
-      time_avg += time_min;
-      time_iter_avg += time_iter_min;
-      GCUPS_vec.emplace_back(matsize / time_min * 1e-3);
-      num_cells += matsize;
+      sum_best_us += best_us;
+      sum_best_pieces_us += best_pieces_us;
+      gcups_per_read.emplace_back(cells / best_us * 1e-3);
+      cells_total += cells;
     }
-    i++;
+    lineno++;
   }
-  if (GCUPS_vec.empty()) { std::cerr << "no reads" << std::endl; return 2; }
-  const double GCUPS = num_cells / time_avg * 1e-3, GCUPS_iter = num_cells / time_iter_avg * 1e-3;
-  time_avg /= (i - 1);
+  if (gcups_per_read.empty()) { std::cerr << "no reads" << std::endl; return 2; }
+  const double overall = cells_total / sum_best_us * 1e-3, overall_pieces = cells_total / sum_best_pieces_us * 1e-3;
+  const double mean_us = sum_best_us / (lineno - 1);
   double mean = 0, var = 0;
-  for (double g : GCUPS_vec) mean += g;
-  mean /= GCUPS_vec.size();
-  for (double g : GCUPS_vec) var += (g - mean) * (g - mean);
-  std::cout << "[INFO] Average SW iter_ad_read times: " << time_avg * 1e-6 << "s, GCUPS:" << GCUPS
-            << ", GCPUS per iteration: " << GCUPS_iter << std::endl;
-  std::cout << "[INFO] GCUPS avg:" << mean << ", GCUPS std:" << std::sqrt(var / GCUPS_vec.size()) << std::endl;
-  for (double g : GCUPS_vec) std::cout << g << " ";
+  for (double g : gcups_per_read) mean += g;
+  mean /= gcups_per_read.size();
+  for (double g : gcups_per_read) var += (g - mean) * (g - mean);
+  std::cout << "[INFO] Average SW iter_ad_read times: " << mean_us * 1e-6 << "s, GCUPS:" << overall
+            << ", GCPUS per iteration: " << overall_pieces << std::endl;
+  std::cout << "[INFO] GCUPS avg:" << mean << ", GCUPS std:" << std::sqrt(var / gcups_per_read.size()) << std::endl;
+  for (double g : gcups_per_read) std::cout << g << " ";
   std::cout << std::endl;
   return 0;
 }

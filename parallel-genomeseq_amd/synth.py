@@ -140,3 +140,61 @@ def lognormal_lengths(seed, count, median=290.0, sigma=0.66, lo=2, hi=35000):
     u2 = (r[count:] >> np.uint64(11)).astype(np.float64) / float(1 << 53)
     z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
     return np.clip(np.rint(median * np.exp(sigma * z)), lo, hi).astype(np.int64)
+
+
+def dna_repeats(seed, length, families=4, family_len=300, copies=2000, divergence=0.03, tandem_runs=200, tandem_len=400,
+                polya_runs=200, polya_len=300):
+    """A repeat-rich reference (what genomes look like and uniform ACGT does not): a uniform background with planted
+    * interspersed repeat families: `families` consensus sequences of `family_len` bp, `copies` copies each at PRNG
+      positions, every copy with `divergence` substitutions (Alu-like: thousands of near-identical 300 bp elements);
+    * tandem repeats: `tandem_runs` microsatellite runs of `tandem_len` bp with a 2-6 bp unit;
+    * poly-A runs: `polya_runs` runs of `polya_len` bp.
+    Returns (reference uint8 array, dict with the planted intervals per class: 'family' [(start, family id)],
+    'tandem' [start], 'polya' [start]).  Deterministic in `seed`."""
+    ref = dna(seed, length)
+    r = splitmix64(seed ^ 0xA5A5A5A5, 4 * (families * copies + tandem_runs + polya_runs) + 64)
+    k = 0
+    planted = {"family": [], "tandem": [], "polya": []}
+    cons = [dna(seed + 1000 + f, family_len) for f in range(families)]
+    for f in range(families):
+        for _ in range(copies):
+            at = int(r[k] % np.uint64(max(1, length - family_len))); k += 1
+            copy = cons[f].copy()
+            rr = splitmix64(int(r[k] & np.uint64(0x7FFFFFFF)), 2 * family_len); k += 1
+            sub = (rr[:family_len] >> np.uint64(11)).astype(np.float64) / float(1 << 53) < divergence
+            copy[sub] = _DNA[(rr[family_len:][sub] >> np.uint64(62)).astype(np.intp)]
+            ref[at:at + family_len] = copy
+            planted["family"].append((at, f))
+    for _ in range(tandem_runs):
+        at = int(r[k] % np.uint64(max(1, length - tandem_len))); k += 1
+        ulen = 2 + int(r[k] % np.uint64(5)); k += 1
+        unit = _DNA[(splitmix64(int(r[k] & np.uint64(0x7FFFFFFF)), ulen) >> np.uint64(62)).astype(np.intp)]; k += 1
+        ref[at:at + tandem_len] = np.tile(unit, tandem_len // ulen + 1)[:tandem_len]
+        planted["tandem"].append(at)
+    for _ in range(polya_runs):
+        at = int(r[k] % np.uint64(max(1, length - polya_len))); k += 1
+        ref[at:at + polya_len] = ord("A")
+        planted["polya"].append(at)
+    return ref, planted
+
+
+def reads_with_repeats(ref, planted, seed, count, length, repeat_fraction=0.01, sub_rate=0.01):
+    """`count` reads of `length` bp: fast_reads_from_ref of the reference, with round(repeat_fraction * count) of them cut
+    from inside planted repeats instead (family copies, tandem runs and poly-A runs in turn).  Returns (reads, offsets,
+    indices of the repeat-derived reads)."""
+    reads, offs = fast_reads_from_ref(ref, seed, count, length, sub_rate)
+    nrep = int(round(repeat_fraction * count))
+    if nrep == 0:
+        return reads, offs, np.zeros(0, dtype=np.int64)
+    r = splitmix64(seed ^ 0x0F0F0F0F, 3 * nrep + 8)
+    which = (r[:nrep] % np.uint64(count)).astype(np.int64)
+    which = np.unique(which)
+    classes = [c for c in ("family", "tandem", "polya") if planted[c]]
+    for j, idx in enumerate(which):
+        cls = classes[j % len(classes)]
+        item = planted[cls][int(r[nrep + j] % np.uint64(len(planted[cls])))]
+        at = int(item[0] if cls == "family" else item)
+        at = max(0, min(len(ref) - length, at + int(r[2 * nrep + j] % np.uint64(32))))
+        reads[idx] = ref[at:at + length]
+        offs[idx] = at
+    return reads, offs, which

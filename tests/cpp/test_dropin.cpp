@@ -33,6 +33,17 @@ int main() {
     EXPECT(ix == 7 && iy == 6 && mx == 13);
     EXPECT(la->getSimilarity_matrix()(7, 6) == 13);
     EXPECT(la->getTimings()[0] > 0);
+    // repeated calculateScore() (sw_solve_big.cpp:84-88): pos / score unchanged; the consensus is replaced — or, with
+    // PARSEQ_APPEND_CONSENSUS in the environment, appended to as the reference does (smithwaterman.cpp:40-78 never clears)
+    la->calculateScore();
+    EXPECT(la->getScore() == 13 && la->getPos() == 2);
+    if (std::getenv("PARSEQ_APPEND_CONSENSUS")) {
+      EXPECT(la->getConsensus_x() == std::string_view("CAGTTGCAGTTG"));
+      EXPECT(la->getConsensus_y() == std::string_view("CA-TTGCA-TTG"));
+      std::printf("consensus appended on repeat\n");
+    } else {
+      EXPECT(la->getConsensus_x() == std::string_view("CAGTTG") && la->getConsensus_y() == std::string_view("CA-TTG"));
+    }
   }
   {  // SimilarityMatrix.SkewedMatrixDP
     std::string sequence_x = "GGTTGACTA";

@@ -126,6 +126,7 @@ int main() {
   for (auto &r : split_ref) mi355_sw_free_result(&r);
   mi355_sw_free_results(batch_ref.data(), batch_ref.size());
   mi355_sw_destroy(ctx);
+  std::printf("device sets run: %zu (devices visible: %d)%s\n", sets.size(), visible, visible >= 2 ? "" : "; SKIPPED two-device sets: one device visible");
   std::printf("ALL OK\n");
   return 0;
 }

@@ -148,41 +148,69 @@ def test_full_size_planted_reads(ctx, pgs):
                 assert r["score"] == 255 and r["end_x"] == 85 and r["end_y"] == o + 85
 
 
+def _cpp_test_binary(name):
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", name)
+    if not os.path.exists(exe) and name != "test_dropin_eigen.bin":
+        import __graft_entry__ as g
+        g.build()
+    return exe
+
+
 def test_cpp_dropin_binary():
     """The reference's gtest cases compiled against include/parseq/*.h run on the GPU."""
     import os
     import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "tests", "cpp", "test_dropin.bin")
-    if not os.path.exists(exe):
-        import __graft_entry__ as g
-        g.build()
+    exe = _cpp_test_binary("test_dropin.bin")
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert p.returncode == 0 and b"ALL OK" in p.stdout, p.stdout.decode()
     # OMPParallelLocalAligner over a device set (MI355_SW_DEVICES -> mi355_sw_multi_align_split): same answers
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120,
                        env=dict(os.environ, MI355_SW_DEVICES="0,0"))
     assert p.returncode == 0 and b"ALL OK" in p.stdout, p.stdout.decode()
-    # the same source compiled against the reference's vendored Eigen (tests/cpp/build_dropin.sh): Eigen::VectorXf
-    # getTimings(), const Eigen::MatrixXf &get_matrix(), MatrixX8u raw storage — prebuilt where the reference exists
-    exe2 = os.path.join(root, "tests", "cpp", "test_dropin_eigen.bin")
-    if os.path.exists(exe2):
-        p = subprocess.run([exe2], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
-        assert p.returncode == 0 and b"ALL OK" in p.stdout and b"Eigen signatures: ok" in p.stdout, p.stdout.decode()
+    # the reference's append-on-repeat behaviour of the consensus strings, opt-in (smithwaterman.cpp:40-78, :80-108)
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120,
+                       env=dict(os.environ, PARSEQ_APPEND_CONSENSUS="1"))
+    assert p.returncode == 0 and b"ALL OK" in p.stdout and b"consensus appended on repeat" in p.stdout, p.stdout.decode()
+
+
+def test_cpp_dropin_binary_with_eigen():
+    """The same source compiled against the reference's vendored Eigen (tests/cpp/build_dropin.sh): Eigen::VectorXf
+    getTimings(), const Eigen::MatrixXf &get_matrix(), MatrixX8u raw storage.  The binary is prebuilt where the reference
+    exists (it travels to the GPU box); where it did not travel this leg is SKIPPED, not passed."""
+    import os
+    import subprocess
+    exe2 = _cpp_test_binary("test_dropin_eigen.bin")
+    if not os.path.exists(exe2):
+        pytest.skip("tests/cpp/test_dropin_eigen.bin was not built (needs the reference's vendored Eigen zip at build time)")
+    p = subprocess.run([exe2], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert p.returncode == 0 and b"ALL OK" in p.stdout and b"Eigen signatures: ok" in p.stdout, p.stdout.decode()
 
 
 def test_cpp_multi_device_binary():
     """mi355_sw_multi_* (one handle, several devices: pieces / alignments dealt to devices, packed-key merge on the
     host and through RCCL) == the single-device calls; on a one-GPU box with device sets {0}, {0,0}, {0,0,0}."""
-    import os
     import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "tests", "cpp", "test_multi.bin")
-    if not os.path.exists(exe):
-        import __graft_entry__ as g
-        g.build()
+    exe = _cpp_test_binary("test_multi.bin")
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert p.returncode == 0 and b"ALL OK" in p.stdout, p.stdout.decode()
+    for name in (b"{0} ok", b"{0,0} ok", b"{0,0,0} ok", b"{0} rccl ok"):
+        assert name in p.stdout, p.stdout.decode()
+
+
+def test_cpp_multi_device_binary_two_devices():
+    """The {0,1}, {0,1}+RCCL, {1,0,1} and all-devices+RCCL sets of tests/cpp/test_multi.cpp: only where the box has a second
+    GPU — SKIPPED (not passed) on a one-GPU box."""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the two-device sets of tests/cpp/test_multi.cpp did not run")
+    exe = _cpp_test_binary("test_multi.bin")
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0 and b"ALL OK" in p.stdout, p.stdout.decode()
+    for name in (b"{0,1} ok", b"{0,1} rccl ok", b"{1,0,1} ok", b"all rccl ok"):
+        assert name in p.stdout, p.stdout.decode()
 
 
 def test_multi_context_vs_oracle(oracle, pgs):

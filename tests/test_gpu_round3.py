@@ -191,3 +191,116 @@ def test_align_scored_range_is_the_pieces_alignment(pgs, oracle):
             c.align_scored_range(0, semantics=0)
     finally:
         c.close()
+
+
+def _drivers_dir():
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "parallel-genomeseq_amd", "drivers")
+    if not os.path.exists(os.path.join(d, "sw_solve_small.bin")):
+        subprocess.check_call(["make", "-C", d])
+    return d
+
+
+def _eval_pos():
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("eval_pos", os.path.join(root, "tools", "eval_pos.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_eval_report_on_data_small_matches_the_reference(data_small, tmp_path):
+    """the reference's own evaluation (py/eval.py:102-121, `--option sw_solve_small`: rows whose
+    pos_pred differs from the SAM POS) on the output of the sw_solve_small driver over the reference's data_small inputs:
+    188 of 1170 positions differ with the float engine, 222 of 1170 with the uint8 engine (measured on the unmodified
+    reference) — the greedy traceback overshoots, nothing is 'fixed' here."""
+    import os
+    import subprocess
+    d = _drivers_dir()
+    ev = _eval_pos()
+    fa = tmp_path / "genome.fa"
+    ref = data_small["ref"]
+    fa.write_text(">22_5K\n" + "\n".join(ref[i:i + 60] for i in range(0, len(ref), 60)) + "\n")
+    csv = tmp_path / "truth.csv"
+    csv.write_text("index,QNAME,SEQ,POS\n" + "".join("%d,22_5K-1170,%s,%d\n" % (k, r, p) for k, (r, p) in
+                                                       enumerate(zip(data_small["reads"], data_small["sam_pos"]))))
+    for engine, want in (("f32", 188), ("u8", 222)):
+        out = tmp_path / ("out_%s.csv" % engine)
+        p = subprocess.run([os.path.join(d, "sw_solve_small.bin"), str(fa), str(csv), str(out), "--engine=" + engine],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 0, p.stdout.decode()
+        n, bad = ev.count_mismatches(str(out))
+        assert (n, bad) == (1170, want), (engine, n, bad)
+
+
+def test_generator_driver_eval_chain(pgs, oracle, tmp_path):
+    """tools/make_dataset.py (the reference's file shapes, py/ompfg_data_prep.py:92-116) -> drivers/sw_solve_small and
+    drivers/sw_solve_big -> tools/eval_pos.py: every pos_pred / score of the output equals the oracle's, and the mismatch
+    count of the report equals the one computed from the oracle's positions."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = _drivers_dir()
+    ev = _eval_pos()
+    data = tmp_path / "data"
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "make_dataset.py"), str(data), "--ref-len", "120000",
+                           "--reads", "60", "--read-len", "150"])
+    ref = (data / "custom_ref_1.fa").read_text().strip()
+    rows = (data / "custom_reads_1.csv").read_text().splitlines()
+    assert rows[0] == "index,QNAME,SEQ,POS" and len(rows) == 61
+    reads = [r.split(",")[2] for r in rows[1:]]
+    truth = [int(r.split(",")[3]) for r in rows[1:]]
+    for engine, sem in (("f32", 0), ("u8", 1)):
+        out = tmp_path / ("chain_%s.csv" % engine)
+        p = subprocess.run([os.path.join(d, "sw_solve_small.bin"), str(data / "genome.fa"), str(data / "custom_reads_1.csv"), str(out),
+                            "--engine=" + engine], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 0, p.stdout.decode()
+        got = out.read_text().splitlines()[1:]
+        exp = [oracle.align(q.encode(), ref.encode(), sem) for q in reads]
+        for line, e in zip(got, exp):
+            assert int(line.split(", ")[1]) == e["pos"] and float(line.split(", ")[2]) == e["score"], line[:40]
+        n, bad = ev.count_mismatches(str(out))
+        assert n == 60 and bad == sum(1 for e, t in zip(exp, truth) if e["pos"] != t), (engine, bad)
+    # the benchmark driver on the same files: the reference's report lines, verbatim (sw_solve_big.cpp:71-74, :99-106)
+    p = subprocess.run([os.path.join(d, "sw_solve_big.bin"), "2", "1", str(data / "custom_ref_1.fa"), str(data / "custom_reads_1.csv")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    text = p.stdout.decode()
+    assert p.returncode == 0, text
+    for want in ("[INFO] npiece: 2, nrepeat:1", "[INFO] Estimated Memory consumption 0.018GB", "[INFO] Theoretical GCUPS on Leonhard: ",
+                 "[INFO] Average SW iter_ad_read times: ", ", GCPUS per iteration: ", "[INFO] GCUPS avg:", ", GCUPS std:"):
+        assert want in text, (want, text)
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+def test_per_query_fallback_on_repeat_rich_reference(pgs, oracle, sem):
+    """Reads cut from poly-A runs, microsatellites and interspersed repeat families flag more candidate sub-chunks than their
+    cap: THEY are swept again on the exact instances, the other reads of the batch keep the sampled sweep's candidates (no
+    whole-batch second sweep).  Every result bit-exact against the oracle, with the per-query path, and with the whole-batch
+    path it replaces (option no_requery)."""
+    ref, planted = pgs.synth.dna_repeats(9001, 400_000, families=3, family_len=300, copies=150, tandem_runs=60, tandem_len=400,
+                                         polya_runs=120, polya_len=300)
+    reads, offs, which = pgs.synth.reads_with_repeats(ref, planted, 9002, 48, 150, repeat_fraction=0.2)
+    assert len(which) >= 6
+    refb = ref.tobytes()
+    qs = [r.tobytes() for r in reads]
+    exp = [oracle.align(q, refb, sem) for q in qs]
+    c = pgs.Context(0)
+    try:
+        got = c.align_batch(qs, refb, semantics=sem)
+        cnt = c.last_counters()
+        for k, (g, e) in enumerate(zip(got, exp)):
+            _cmp(g, e, "repeat-rich sem=%d read %d%s" % (sem, k, " (repeat)" if k in which else ""))
+        assert 1 <= cnt["requeried"] <= len(which) and cnt["whole_batch_again"] == 0, cnt
+        c.set_option("no_requery")
+        got = c.align_batch(qs, refb, semantics=sem)
+        cnt = c.last_counters()
+        for k, (g, e) in enumerate(zip(got, exp)):
+            _cmp(g, e, "repeat-rich, whole batch again, sem=%d read %d" % (sem, k))
+        assert cnt["whole_batch_again"] == 1 and cnt["requeried"] == 0, cnt
+    finally:
+        c.close()

@@ -153,3 +153,14 @@ def test_trace_from_equals_reference_traceback(oracle, golden):
         assert (w["score"], w["cons_x"], w["cons_y"], w["pos"]) == (e["score"], e["cons_x"], e["cons_y"], e["pos"]), c
         n += 1
     assert n > 400
+
+
+def test_eval_mismatch_counts_of_data_small(data_small):
+    """SURVEY.md §0.5 / py/eval.py:102-121 on the committed golden positions: the reference's float engine differs from the
+    SAM POS column on 188 of 1170 reads, its uint8 engine on 222 (the oracle reproduces every position, so its count is
+    the reference's)."""
+    from oracle import binding as ob
+    ref = data_small["ref"].encode()
+    for sem, want in ((ob.F32, 188), (ob.U8SAT, 222)):
+        bad = sum(1 for q, p in zip(data_small["reads"], data_small["sam_pos"]) if ob.align(q.encode(), ref, sem)["pos"] != p)
+        assert bad == want, (sem, bad)
