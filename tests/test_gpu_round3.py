@@ -304,3 +304,43 @@ def test_per_query_fallback_on_repeat_rich_reference(pgs, oracle, sem):
         assert cnt["whole_batch_again"] == 1 and cnt["requeried"] == 0, cnt
     finally:
         c.close()
+
+
+def test_packed_upload_equals_pointer_upload(pgs, oracle):
+    """mi355_sw_batch_upload_packed (one contiguous buffer + n + 1 offsets, the multi-FASTA shape of
+    src/mpi_sw_solve_uniprot.cpp:97-110) == mi355_sw_batch_upload of the same sequences: UniProt-shaped batch against the
+    144-aa query (every result vs the oracle), empty sequences, a buffer that does not start at offset 0, bad offsets."""
+    n = 3000
+    lens = pgs.synth.lognormal_lengths(15, n)
+    lens[7] = 0
+    lens[n - 1] = 0
+    allres = pgs.synth.protein(15, int(lens.sum()) + 5)
+    offs = np.concatenate([[5], 5 + np.cumsum(lens)]).astype(np.int64)      # the batch starts 5 bytes into the buffer
+    seqs = [allres[offs[k]:offs[k + 1]].tobytes() for k in range(n)]
+    query = pgs.synth.P02232
+    c = pgs.Context(0)
+    try:
+        c.set_reference(query)
+        c.batch_upload_packed(allres, offs)
+        a = c.batch_run(semantics=0, raw=True)
+        cons = [c.consensus(k) for k in range(0, n, 97)]
+        c.batch_upload(seqs)
+        b = c.batch_run(semantics=0, raw=True)
+        for f in ("score", "pos", "end_x", "end_y", "cons_len"):
+            assert np.array_equal(a[f], b[f]), f
+        assert cons == [c.consensus(k) for k in range(0, n, 97)]
+        for k in range(0, n, 131):
+            e = oracle.align(seqs[k], query.encode(), 0)
+            assert (a["score"][k], a["pos"][k], a["end_x"][k], a["end_y"][k]) == (e["score"], e["pos"], e["end_x"], e["end_y"]), k
+        # reads against a long reference through the packed upload (score-kernel path)
+        ref = pgs.synth.dna(16, 200_000)
+        reads, _ = pgs.synth.fast_reads_from_ref(ref, 17, 33, 150)
+        c.set_reference(ref)
+        c.batch_upload_packed(reads.reshape(-1), np.arange(0, 34 * 150, 150, dtype=np.int64))
+        got = c.batch_run(semantics=1)
+        for r, g in zip(reads, got):
+            _cmp(g, oracle.align(r.tobytes(), ref.tobytes(), 1), "packed reads")
+        with pytest.raises(pgs.MI355Error):
+            c.batch_upload_packed(allres, np.array([0, 10, 5], dtype=np.int64))
+    finally:
+        c.close()
