@@ -1,7 +1,8 @@
 #!/usr/bin/env bash
-# PMC counters of one kernel: tools/pmc_run.sh TAG KERNEL_SUBSTRING PROGRAM ARGS...   (PROGRAM = python3 or a binary: rocprofv3
-# gets it after `--`, never a shell).  Separate passes per counter set, kernel-trace-free; summary -> gpurun_out/pmc/TAG.json
-TAG=$1; KSUB=$2; shift 2
+# PMC counters of one command, summarised per kernel: tools/pmc_run.sh TAG 'KSUB1|KSUB2|...' PROGRAM ARGS...
+# (PROGRAM = python3 or a binary: rocprofv3 gets it after `--`, never a shell).  Separate passes per counter set, no trace flags;
+# one summary per kernel-name substring -> gpurun_out/pmc/TAG.<n>.json (n = position of the substring)
+TAG=$1; KSUBS=$2; shift 2
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc/$TAG
 mkdir -p $OUT
@@ -12,5 +13,14 @@ for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT
   rocprofv3 --pmc $set -d $OUT/p$n --output-format csv -- "$@" > $OUT/p$n.log 2>&1 || echo "pass $n failed"
 done
 cd $R
-python tools/pmc_summary.py --kernel "$KSUB" $OUT/p1 $OUT/p2 > gpurun_out/pmc/$TAG.json
-cat gpurun_out/pmc/$TAG.json
+k=0
+IFS='|' read -ra SUBS <<< "$KSUBS"
+for sub in "${SUBS[@]}"; do
+  k=$((k+1))
+  python tools/pmc_summary.py --kernel "$sub" $OUT/p1 $OUT/p2 > gpurun_out/pmc/$TAG.$k.json
+  echo "== $TAG.$k: $sub"; python - "$R/gpurun_out/pmc/$TAG.$k.json" <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1])); print(d["kernel"]); print(json.dumps(d["derived"]))
+PY
+done
+rm -rf $OUT/p1 $OUT/p2
