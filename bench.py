@@ -449,10 +449,10 @@ def extra_config5(pgs, device, ref_len, qlen):
                          "locate_ms": tm["locate_us"] * 1e-3, "traceback_ms": tm["trace_us"] * 1e-3,
                          "kernel": ctx.last_kernel()["name"], "score": r["score"], "pos": r["pos"]}
         out["rank_share"] = rank_share_config5(pgs, ctx, q, ref_len, qlen)
-        # in-run verification at full size: the 16-piece split (score_ranges + the winner finished from its keys) against the
+        # in-run verification at full size: the 16-piece split (best_range + the winner finished from its keys) against the
         # whole-reference alignment — where the serial reference logic says they agree (SURVEY.md §8d cfg 5)
         rs = out["rank_share"]["worlds"]["8"]
-        out["parity_check"] = {"vs": "16-piece split on the resident reference (score_ranges + align_scored_range)",
+        out["parity_check"] = {"vs": "16-piece split on the resident reference (best_range + align_scored_range)",
                                "fields": ["score", "pos"],
                                "mismatches": int(rs["pos"] != out["f32"]["pos"]) + int(rs["score"] != out["f32"]["score"])}
         return out
@@ -464,8 +464,9 @@ def rank_share_config5(pgs, ctx, q, ref_len, qlen):
     """One rank's share of configs[4] at world = 1 / 2 / 4 / 8, measured on ONE GPU (the 8-GPU node is the driver's):
     npiece = 2 * world pieces of _make_string_range(npiece, |q|, |ref|, 2.0) (plocalaligner.cpp:44-67) dealt round-robin
     (piece p -> rank p mod world, plocalaligner.cpp:110-129).  Timed: the share of the rank on the job's critical path — the
-    owner of the winning piece: it sweeps its pieces on the resident reference (score_ranges: what every rank does, all shares
-    are the same size) and then finishes the winner (argmax + traceback from the sweep's keys, align_scored_range).
+    owner of the winning piece: it sweeps its pieces on the resident reference (mi355_sw_best_range: what every rank does, all
+    shares are the same size; score_ms includes the exact re-evaluation of the winner's candidate sub-chunks, i.e. its argmax)
+    and then finishes the winner (traceback, align_scored_range).
     predicted_speedup = T(world = 1) / T(share): what the sharded job reaches when every rank is as fast as this GPU and the
     8-byte all-reduce is free; predicted_speedup_score_pass: the same for the sweep alone."""
     out = {"note": "the pieces of the rank that owns the winning piece, swept on one GPU against the resident %d bp reference; "
@@ -474,23 +475,23 @@ def rank_share_config5(pgs, ctx, q, ref_len, qlen):
     for world in (1, 2, 4, 8):
         npiece = 2 * world
         ranges = pgs.capi.make_string_range(npiece, qlen, ref_len, 2.0)
-        full = ctx.score_ranges(ranges, semantics=pgs.F32)[:, 0]
-        winner = int(full.argmax())                                          # first piece with the greatest maximum
+        fbest, fwhich, _ = ctx.best_range(ranges, semantics=pgs.F32)
+        winner = int(fwhich[0])                                              # first piece with the greatest maximum
         owner = winner % world
         mine = ranges[owner::world]
         best = None
         for _ in range(2):
             t0 = time.perf_counter()
-            mx = ctx.score_ranges(mine, semantics=pgs.F32)[:, 0]
+            bst, wh, _ = ctx.best_range(mine, semantics=pgs.F32)
             t1 = time.perf_counter()
             tm_score = ctx.last_timings()["score_us"]
-            k = int(mx.argmax())
+            k = int(wh[0])
             r = ctx.align_scored_range(k, semantics=pgs.F32)
             t2 = time.perf_counter()
             tm = ctx.last_timings()
             if best is None or (t2 - t0) < best[0]:
                 best = (t2 - t0, t1 - t0, t2 - t1, tm_score, tm["locate_us"], tm["trace_us"], r)
-        assert mine[k] == ranges[winner] and best[6]["score"] == float(full[winner])
+        assert mine[k] == ranges[winner] and best[6]["score"] == float(fbest[0])
         rec = {"pieces": len(mine), "columns": int(sum(b - a for a, b in mine)), "share_ms": best[0] * 1e3,
                "score_ms": best[1] * 1e3, "score_kernel_ms": best[3] * 1e-3, "finish_ms": best[2] * 1e3,
                "finish_locate_ms": best[4] * 1e-3, "finish_traceback_ms": best[5] * 1e-3,
@@ -500,7 +501,7 @@ def rank_share_config5(pgs, ctx, q, ref_len, qlen):
         rec["predicted_speedup"] = base["share_ms"] / rec["share_ms"]
         rec["predicted_speedup_score_pass"] = base["score_ms"] / rec["score_ms"]
         out["worlds"][str(world)] = rec
-    ctx.score_ranges(ranges[:1], semantics=pgs.F32)
+    ctx.best_range(ranges[:1], semantics=pgs.F32)
     out["kernel"] = ctx.last_kernel()["name"]
     return out
 
@@ -578,14 +579,14 @@ def strong_config5(pgs, D, args, device):
         if mine:
             ctx.set_reference(np.concatenate(parts))
             ctx.batch_upload([q])
-            ctx.score_ranges(local[:1], semantics=pgs.F32)                 # warm-up: scratch buffers, code objects
+            ctx.best_range(local[:1], semantics=pgs.F32)                   # warm-up: scratch buffers, code objects
 
         def step():
             key = 0
             if mine:
-                mx = ctx.score_ranges(local, semantics=pgs.F32)[:, 0]
-                for p, v in zip(mine, mx):
-                    key = max(key, int(np.float32(v).view(np.uint32)) << 32 | (0xFFFFFFFF - p))
+                # winner-only sweep of this rank's pieces (mi355_sw_best_range): all the reduction needs is the rank's best piece
+                best, which, _ = ctx.best_range(local, semantics=pgs.F32)
+                key = int(np.float32(best[0]).view(np.uint32)) << 32 | (0xFFFFFFFF - mine[int(which[0])])
             key = D.max_key(key)
             piece = 0xFFFFFFFF - (key & 0xFFFFFFFF)
             res = None

@@ -152,7 +152,16 @@ int mi355_sw_align_split(mi355_sw_ctx *ctx, const char *x, size_t nx, const char
 int mi355_sw_score_ranges(mi355_sw_ctx *ctx, size_t nranges, const int64_t *lefts, const int64_t *rights,
                           const mi355_sw_params *params, float *maxima);
 
-/* Finishes range `range_index` of the LAST mi355_sw_score_ranges call on this context as a stand-alone problem: argmax
+/* mi355_sw_score_ranges for callers that only need the WINNER: per resident query the first range with the strictly
+ * greatest maximum (best[q], best_range[q]; -1 / -1 without ranges) — all OMPParallelLocalAligner does with the per-piece
+ * maxima (plocalaligner.cpp:106,122-129).  That freedom lets a lone long query take the cheaper sampled sweep: ranges that
+ * cannot hold the greatest maximum are not re-evaluated, so their entries of `maxima` (optional, may be NULL) are lower
+ * bounds within three gap penalties; best / best_range and the winner's entry are exact.  For multi-GPU reference
+ * sharding: every rank calls it on its own pieces, the packed (best, ~piece) keys are merged by one 8-byte all-reduce(MAX). */
+int mi355_sw_best_range(mi355_sw_ctx *ctx, size_t nranges, const int64_t *lefts, const int64_t *rights,
+                        const mi355_sw_params *params, float *maxima, float *best, int64_t *best_range);
+
+/* Finishes range `range_index` of the LAST mi355_sw_score_ranges / mi355_sw_best_range call on this context as a stand-alone problem: argmax
  * cell and traceback of every resident query within [lefts[k], rights[k]) — what LAT(sequence_x, winning piece) computes
  * (plocalaligner.cpp:132-137); pos / end_y are relative to the range start (the caller adds `left`, :137).  When `params`
  * equals the scoring and engine of that sweep, its per-range keys are used and only the argmax window and the traceback

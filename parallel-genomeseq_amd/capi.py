@@ -20,7 +20,7 @@ EXPORTS = [
     "mi355_sw_multi_create", "mi355_sw_multi_destroy", "mi355_sw_multi_last_error", "mi355_sw_multi_device_count",
     "mi355_sw_multi_rccl_version", "mi355_sw_multi_align_split", "mi355_sw_multi_set_reference",
     "mi355_sw_multi_align_batch", "mi355_sw_multi_last_timings",
-    "mi355_sw_set_option", "mi355_sw_option_names", "mi355_sw_multi_set_option", "mi355_sw_last_counters", "mi355_sw_batch_upload_packed",
+    "mi355_sw_set_option", "mi355_sw_option_names", "mi355_sw_multi_set_option", "mi355_sw_last_counters", "mi355_sw_batch_upload_packed", "mi355_sw_best_range",
 ]
 MULTI_RCCL = 1
 
@@ -258,6 +258,21 @@ class Context:
         self._chk(self._L.mi355_sw_score_ranges(self._ctx, C.c_size_t(n), lefts, rights, C.byref(p),
                                                 out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
+
+    def best_range(self, ranges, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None):
+        """Per resident query the first range with the greatest maximum (mi355_sw_best_range): (best[nq], best_range[nq],
+        maxima[len(ranges), nq] — exact for the winners, lower bounds for ranges that cannot win)."""
+        p, keep = make_params(semantics, match, mismatch, gap, lut)
+        n = len(ranges)
+        lefts = (C.c_int64 * max(1, n))(*[r[0] for r in ranges])
+        rights = (C.c_int64 * max(1, n))(*[r[1] for r in ranges])
+        mx = np.zeros((n, self._nbatch), dtype=np.float32)
+        best = np.zeros(self._nbatch, dtype=np.float32)
+        which = np.zeros(self._nbatch, dtype=np.int64)
+        self._chk(self._L.mi355_sw_best_range(self._ctx, C.c_size_t(n), lefts, rights, C.byref(p),
+                                              mx.ctypes.data_as(C.POINTER(C.c_float)), best.ctypes.data_as(C.POINTER(C.c_float)),
+                                              which.ctypes.data_as(C.POINTER(C.c_int64))))
+        return best, which, mx
 
     def align_scored_range(self, k, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None, flags=0, query=0):
         """Range k of the last score_ranges call finished as a stand-alone problem (argmax + traceback from the sweep's

@@ -227,6 +227,11 @@ struct ScoredRanges {
   std::vector<char> qfast, qfloat;        // per query: swept by the score kernel; cell type of its key
   std::vector<int64_t> qchunk, qwarm;     // per query: sub-chunk length and warm-up margin of its bucket
   int fshift = 0;
+  // winner-only sweeps (mi355_sw_best_range) on the sampled maximum: keys are lower bounds; the ranges that could hold the
+  // greatest maximum were re-evaluated exactly and carry their first-maximum cell (one query per batch)
+  bool sampled = false;
+  std::vector<char> has_located;          // [nranges]
+  std::vector<Located> located;           // [nranges]
 };
 
 // results of mi355_sw_batch_run_view: arrays the context owns until its next call
@@ -253,6 +258,7 @@ struct mi355_sw_ctx {
   size_t requeried = 0;           // queries of the running call that were swept a second time on the exact instances
   size_t whole_again = 0;         // ... times the whole batch was (most of it exceeded its candidate cap)
   size_t candidates = 0;          // candidate sub-chunks the sampled / saturating sweeps of the call flagged
+  int64_t long_nsub = 0;          // sub-chunks per range of the last sampled sw_long_kernel launch (decodes its flag entries)
   bool long_launched = false;     // a sw_long_kernel launch since the last score_fetch (its status word is flags[1])
   DevBuf qcnt, sel2, keys, ranges, stab, ftab, ftab_s, htab, htab8, soloblk, flags, submax, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs, scan;
   // host sides of small per-call uploads: they must outlive the asynchronous copies, and the tables are only

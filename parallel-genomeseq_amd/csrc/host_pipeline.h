@@ -489,6 +489,7 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       keys.assign(pre->keys.begin() + pre_range * nq, pre->keys.begin() + (pre_range + 1) * nq);
       ctx->fshift = pre->fshift;
       for (size_t k = 0; k < nq; ++k) any_fast |= qfast[k] != 0;
+      if (pre->sampled && nq == 1 && pre->has_located[pre_range]) { loc[0] = pre->located[pre_range]; qdone[0] = 1; }
     }
     for (int attempt = 0; attempt < 2 && !pre; ++attempt) {
       buckets.clear();
@@ -723,8 +724,13 @@ int align_range_view(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
 }
 
 // Per-range maxima of every query (value half of find_index_of_maximum per piece).
+// winner_only (mi355_sw_best_range): the caller only needs, per query, the first range with the greatest maximum — what
+// OMPParallelLocalAligner does with the per-piece maxima (plocalaligner.cpp:122-129).  A lone long query is then swept with the
+// sampled maximum (every 4th step: keys are lower bounds within three gaps), and only the ranges whose key lies within that
+// slack of the best key — the only ones that can hold the greatest maximum — have their candidate sub-chunks re-evaluated
+// exactly; the maxima of the other ranges stay lower bounds.
 int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const std::vector<Range> &ranges,
-                 const mi355_sw_params &p, float *maxima /* [nranges][nq] */) {
+                 const mi355_sw_params &p, float *maxima /* [nranges][nq] */, bool winner_only = false) {
   const size_t nq = q.nq, nr = ranges.size();
   ctx->scored.valid = false;
   if (nq == 0 || nr == 0) return 0;
@@ -737,11 +743,15 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   }
   int64_t maxn = 0;
   for (auto &r : ranges) maxn = std::max(maxn, r.hi - r.lo);
-  std::vector<Bucket> buckets = make_buckets(ref, q, table, p, maxn);
+  const bool try_sample = winner_only && nq == 1 && nr <= 4096 && strip_scoring_ok(ref, p) && !opt().no_sample;
+  std::vector<Bucket> buckets = make_buckets(ref, q, table, p, maxn, false, try_sample);
   std::vector<char> qfast(nq, 0), qfloat(nq, 0);
+  bool sampled = false;
   for (Bucket &b : buckets) {
     b.fast = true;
     for (auto &r : ranges) b.fast = b.fast && bucket_fast_ok(ref, table, b, r.hi - r.lo, p);
+    if (!b.longp) b.sampled = false;                               // only sw_long_kernel lays out one value row per range
+    sampled |= b.fast && b.sampled;
   }
   // what a following mi355_sw_align_scored_range needs (one launch group only: the geometry is per launch)
   ScoredRanges &sc = ctx->scored;
@@ -750,6 +760,7 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   if (keep) {
     sc.ref_version = ref.version; sc.batch_version = q.version; sc.params = p; sc.ranges = ranges;
     sc.keys.assign(nr * nq, 0ull); sc.qfast.assign(nq, 0); sc.qfloat.assign(nq, 0); sc.qchunk.assign(nq, 0); sc.qwarm.assign(nq, 0);
+    sc.sampled = false; sc.has_located.assign(nr, 0); sc.located.assign(nr, Located());
   }
   for (size_t lo = 0; lo < nr; lo += 32768) {
     const size_t hi = std::min(nr, lo + 32768);
@@ -784,6 +795,51 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
           else if (qfloat[k]) memcpy(&v, &hi32, 4); else v = (float)hi32;
           maxima[(lo + r) * nq + k] = v;
         }
+    if (sampled) {
+      // (nq == 1, one launch group.)  The keys above are lower bounds within 3 gaps: re-evaluate the contenders exactly.
+      unsigned int nflag = 0;
+      HIPCHK(ctx, hipMemcpy(&nflag, ctx->flags.p, 4, hipMemcpyDeviceToHost));
+      const uint32_t qcap = query_flag_cap(nq);
+      float top = 0.0f;
+      for (size_t r = 0; r < nr; ++r) top = std::max(top, maxima[r]);
+      const float slack = 3.0f * table.gapf;
+      bool ok = nflag <= ctx->flag_cap && nflag <= qcap;            // (the filter stops appending beyond the cap)
+      std::vector<std::vector<std::pair<uint32_t, uint32_t>>> per_range(nr);
+      if (ok && nflag) {
+        std::vector<uint32_t> raw(2 * (size_t)nflag);
+        HIPCHK(ctx, hipMemcpy(raw.data(), ctx->flags.as<unsigned int>() + 2, (size_t)nflag * 8, hipMemcpyDeviceToHost));
+        for (size_t f = 0; f < nflag; ++f) {
+          const size_t r = (size_t)(raw[2 * f + 1] / (uint64_t)ctx->long_nsub);
+          if (r < nr) per_range[r].push_back({raw[2 * f], (uint32_t)(raw[2 * f + 1] % (uint64_t)ctx->long_nsub)});
+        }
+      }
+      HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+      for (size_t r = 0; r < nr && ok; ++r) {
+        if (!(maxima[r] > 0.0f) || maxima[r] < top - slack) continue;                     // cannot hold the greatest maximum
+        auto &fl = per_range[r];
+        std::sort(fl.begin(), fl.end());
+        fl.erase(std::unique(fl.begin(), fl.end()), fl.end());
+        std::vector<Located> loc(1);
+        std::vector<char> done(1, 0);
+        const std::vector<float> qlower(1, maxima[r]);
+        std::vector<int64_t> qchunk(1, 0), qwarm(1, 0);
+        for (Bucket &b : buckets) if (b.fast) { qchunk[0] = b.sub_len; qwarm[0] = b.warm; }
+        rc = locate_saturated(ctx, ref, q, ranges[r], p, qchunk, qwarm, qlower, table, fl, loc, done);
+        if (rc) return rc;
+        if (!done[0]) { ok = false; break; }
+        maxima[r] = loc[0].score;
+        if (keep) { sc.has_located[r] = 1; sc.located[r] = loc[0]; }
+        ctx->candidates += fl.size();
+      }
+      HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+      ctx->timings[1] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
+      if (!ok) {                                                     // too many near-equal candidates: the exact sweep instead
+        ctx->whole_again += 1;
+        ctx->timings[4] = 0; ctx->timings[5] = 0; ctx->last_kernel.cells = 0;
+        return range_maxima(ctx, ref, q, ranges, p, maxima, false);
+      }
+      if (keep) sc.sampled = true;
+    }
   }
   std::vector<int> slow;
   for (size_t k = 0; k < nq; ++k) if (!qfast[k]) slow.push_back((int)k);

@@ -679,7 +679,7 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   b.sub_len = sub_len;
   const int64_t cpr = (maxlen + chunk - 1) / chunk;
   const int subs_per_tile = (int)(chunk / sub_len);
-  if (b.sampled && nr != 1) b.sampled = false;                        // (per-range value rows are not laid out)
+  if (b.sampled && (nr > 4096 || (double)nr * (double)(cpr * subs_per_tile) > 4.0e9)) b.sampled = false;
 
   LongArgs a;
   a.refcodes = ref.codes.as<uint8_t>();
@@ -699,10 +699,13 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   a.submax_out = nullptr;
   a.nstrips = b.nstrips; a.pipes = pipes; a.subs_per_tile = subs_per_tile;
   a.status = reinterpret_cast<int32_t *>(ctx->flags.as<unsigned int>() + 1);      // zeroed by score_begin, read by score_fetch
-  const int64_t nsub = cpr * subs_per_tile;
+  const int64_t nsub = cpr * subs_per_tile;                           // sub-chunks of one range (value rows: one per range)
+  a.submax_range_stride = nsub;
   if (b.sampled) {
-    if (ctx->submax.ensure((size_t)nsub * 4 + 64)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(sub-chunk values) failed");
+    if (ctx->submax.ensure((size_t)nr * (size_t)nsub * 4 + 64)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(sub-chunk values) failed");
     a.submax_out = ctx->submax.as<uint32_t>();
+    // (tiles beyond a short range's end never run: their values must read as "nothing")
+    if (nr > 1) HIPCHK(ctx, hipMemsetAsync(ctx->submax.p, 0, (size_t)nr * (size_t)nsub * 4, ctx->stream));
   }
   const size_t shmem = long_lds_bytes(ref.ncodes, b.nstrips, pipes, b.R, subs_per_tile);
   const dim3 grid((unsigned)((cpr + pipes - 1) / pipes), (unsigned)nr);
@@ -722,13 +725,16 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   HIPCHK(ctx, hipGetLastError());
   ctx->long_launched = true;
   if (b.sampled) {
+    // one filter launch per range: its value row against ITS key; entries carry the range in the sub-chunk index (r * nsub + s)
     const dim3 fgrid((unsigned)std::min<int64_t>(64, (nsub + 255) / 256), 1u);
-    hipLaunchKernelGGL(sw_sample_filter<true>, fgrid, dim3(256), 0, ctx->stream, (const void *)a.submax_out, nsub, nsub,
-                       q.sel.as<int32_t>(), b.first, 1, (const unsigned long long *)a.keys,
-                       std::ldexp(3.0f * t.gapf, -ctx->fshift),
-                       ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), ctx->flag_cap,
-                       ctx->qcnt.as<unsigned int>(), query_flag_cap(q.nq));
+    for (size_t r = 0; r < nr; ++r)
+      hipLaunchKernelGGL(sw_sample_filter<true>, fgrid, dim3(256), 0, ctx->stream, (const void *)(a.submax_out + r * (size_t)nsub), nsub, nsub,
+                         q.sel.as<int32_t>(), b.first, 1, (const unsigned long long *)(a.keys + r * (size_t)q.nq),
+                         std::ldexp(3.0f * t.gapf, -ctx->fshift),
+                         ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), ctx->flag_cap,
+                         ctx->qcnt.as<unsigned int>(), query_flag_cap(q.nq), (uint32_t)(r * (size_t)nsub));
     HIPCHK(ctx, hipGetLastError());
+    ctx->long_nsub = nsub;
   }
   HIPCHK(ctx, hipEventRecord(ctx->score_ev[ctx->score_ev_used + 1], ctx->stream));
   ctx->score_ev_used += 2;

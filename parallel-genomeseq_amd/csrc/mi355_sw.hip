@@ -340,6 +340,33 @@ int mi355_sw_score_ranges(mi355_sw_ctx *ctx, size_t nranges, const int64_t *left
   return range_maxima(ctx, ctx->ref, q, ranges, *params, maxima);
 }
 
+int mi355_sw_best_range(mi355_sw_ctx *ctx, size_t nranges, const int64_t *lefts, const int64_t *rights,
+                        const mi355_sw_params *params, float *maxima, float *best, int64_t *best_range) {
+  OptScope opt_scope_(ctx);
+  int rc = check_params(ctx, params);
+  if (rc) return rc;
+  if (!lefts || !rights || !best || !best_range) return fail(ctx, MI355_SW_EINVAL, "null argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  reset_timings(ctx);
+  const QueryBatch &q = ctx->batch;
+  if (q.nq == 0) return 0;
+  for (size_t k = 0; k < q.nq; ++k) { best[k] = -1.0f; best_range[k] = -1; }
+  if (nranges == 0) return 0;
+  std::vector<Range> ranges(nranges);
+  for (size_t k = 0; k < nranges; ++k) {
+    if (lefts[k] < 0 || rights[k] < lefts[k] || rights[k] > (int64_t)ctx->ref.n) return fail(ctx, MI355_SW_EINVAL, "range outside the resident reference");
+    ranges[k] = Range{lefts[k], rights[k]};
+  }
+  std::vector<float> own;
+  if (!maxima) { own.resize(nranges * q.nq); maxima = own.data(); }
+  rc = range_maxima(ctx, ctx->ref, q, ranges, *params, maxima, true);
+  if (rc) return rc;
+  for (size_t k = 0; k < q.nq; ++k)                               // plocalaligner.cpp:106,122-129: starts at -1, strict '>'
+    for (size_t r = 0; r < nranges; ++r)
+      if (maxima[r * q.nq + k] > best[k]) { best[k] = maxima[r * q.nq + k]; best_range[k] = (int64_t)r; }
+  return 0;
+}
+
 int mi355_sw_align_scored_range(mi355_sw_ctx *ctx, size_t range_index, const mi355_sw_params *params, int flags,
                                 mi355_sw_result *outs) {
   OptScope opt_scope_(ctx);
@@ -354,8 +381,10 @@ int mi355_sw_align_scored_range(mi355_sw_ctx *ctx, size_t range_index, const mi3
   if (ctx->batch.nq == 0) return 0;
   const Range rg = sc.ranges[range_index];
   // the sweep's keys serve when it ran under the same engine and scoring; otherwise the range is swept again
+  // ... and, after a winner-only sweep (mi355_sw_best_range), for the ranges that were re-evaluated exactly
   const bool same = params->lut == nullptr && params->semantics == sc.params.semantics && params->match == sc.params.match &&
-                    params->mismatch == sc.params.mismatch && params->gap == sc.params.gap;
+                    params->mismatch == sc.params.mismatch && params->gap == sc.params.gap &&
+                    (!sc.sampled || sc.has_located[range_index]);
   return align_range(ctx, ctx->ref, ctx->batch, rg, *params, flags, outs, same ? &sc : nullptr, range_index);
 }
 

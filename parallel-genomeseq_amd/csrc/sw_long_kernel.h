@@ -51,7 +51,8 @@ struct LongArgs {
   float scale;                 // 2048 * 2^-k
   uint32_t pubmax;             // != 0: published maxima are clamped to this float bit pattern (uint8 engine swept unsaturated)
   unsigned long long *keys;    // [nranges][nq]
-  uint32_t *submax_out;        // MK > 1: value of every sub-chunk of range 0 (float bits), else null
+  uint32_t *submax_out;        // MK > 1: value of every sub-chunk (float bits), range r at submax_out + r * submax_range_stride; else null
+  int64_t submax_range_stride;
   int32_t nstrips;             // strips = wavefronts per pipeline
   int32_t pipes;               // pipelines (tiles) per workgroup
   int32_t subs_per_tile;       // chunk_len / sub_len
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
     uint32_t bv = 0u, bs = 0xFFFFFFFFu;                                    // best value, first sub-chunk that holds it
     for (int s = l; s < a.subs_per_tile; s += 64) {
       uint32_t v = submax[s];
-      if (MK > 1 && a.submax_out != nullptr) a.submax_out[(size_t)tile * a.subs_per_tile + s] = v;
+      if (MK > 1 && a.submax_out != nullptr) a.submax_out[(size_t)range * (size_t)a.submax_range_stride + (size_t)tile * a.subs_per_tile + s] = v;
       if (a.pubmax != 0u && v > a.pubmax) v = a.pubmax;
       if (v > bv) { bv = v; bs = (uint32_t)s; }
     }

