@@ -159,8 +159,15 @@ bool long_shape(int ncodes, int len, int &R, int &nstrips) {
   for (int r : {20, 24, 32}) {
     if ((forced == 20 || forced == 24 || forced == 32) && r != forced) continue;
     const int ns = (len + 64 * r - 1) / (64 * r);
-    if (ns < 1 || ns > long_max_waves(r)) continue;
-    if (long_lds_bytes(ncodes, ns, 1, r, kLongSubsMax) > kLongLdsMax) continue;
+    if (ns < 1) continue;
+    // one workgroup with the float16 profile, or up to eight with a float32 profile each (long_score_launch decides)
+    const bool one_wg = ns <= long_max_waves(r) && long_lds_bytes(ncodes, ns, 1, r, kLongSubsMax) <= kLongLdsMax;
+    bool many_wg = false;
+    for (int g = 1; g <= 8 && !many_wg; g *= 2) {
+      const int spg = (ns + g - 1) / g;
+      many_wg = spg <= long_max_waves(r) && long_lds_bytes(ncodes, spg, 1, r, kLongSubsMax, true) <= kLongLdsMax;
+    }
+    if (!one_wg && (!many_wg || opt().no_long_p32)) continue;
     const int64_t rows = (int64_t)ns * 64 * r;
     if (best < 0 || rows < best) { best = rows; R = r; nstrips = ns; }    // ties: fewer rows per lane = more wavefronts (measured,
                                                                           // 10 kbp x 250 Mbp: 8 x R=20 strips 244 ms, 5 x R=32 strips 306 ms)
@@ -654,27 +661,43 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   double total_cols = 0;
   int64_t maxlen = 0;
   for (auto &r : ranges) { total_cols += (double)(r.hi - r.lo); maxlen = std::max(maxlen, r.hi - r.lo); }
+  // float32 profile where the strips can be dealt to at most eight workgroups per tile (the cell's add then issues at the
+  // double rate, sw_long_kernel.h); else the float16 profile of the whole query in one workgroup
+  bool p32 = !opt().no_long_p32;
+  int groups = 1, spg = b.nstrips;
+  if (p32) {
+    p32 = false;
+    for (int g = opt().long_groups > 0 ? (int)opt().long_groups : 1; g <= 8; g *= 2) {
+      const int s1 = (b.nstrips + g - 1) / g;
+      if (s1 <= long_max_waves(b.R) && long_lds_bytes(ref.ncodes, s1, 1, b.R, kLongSubsMax, true) <= kLongLdsMax) { p32 = true; groups = g; spg = s1; break; }
+    }
+  }
+  if (!p32 && (b.nstrips > long_max_waves(b.R) || long_lds_bytes(ref.ncodes, b.nstrips, 1, b.R, kLongSubsMax) > kLongLdsMax))
+    return fail(ctx, MI355_SW_ENOTSUP, "internal: no sw_long_kernel layout for this query");
+  groups = (b.nstrips + spg - 1) / spg;                                 // (no workgroup without strips)
   int pipes = (int)opt().long_pipes;
-  if (pipes < 1) pipes = long_max_waves(b.R) / b.nstrips;                             // as many wavefronts per CU as fit: the sweep
-                                                                                      // is bound by issue slots that only other wavefronts fill
-  pipes = std::max(1, std::min(pipes, long_max_waves(b.R) / b.nstrips));
-  while (pipes > 1 && long_lds_bytes(ref.ncodes, b.nstrips, pipes, b.R, kLongSubsMax) > kLongLdsMax) --pipes;
+  if (pipes < 1) pipes = long_max_waves(b.R) / spg;                     // as many wavefronts per CU as fit: the sweep
+                                                                        // is bound by issue slots that only other wavefronts fill
+  pipes = std::max(1, std::min(pipes, long_max_waves(b.R) / spg));
+  while (pipes > 1 && long_lds_bytes(ref.ncodes, spg, pipes, b.R, kLongSubsMax, p32) > kLongLdsMax) --pipes;
   int64_t sub_len = opt().long_sub >= 64 ? opt().long_sub / 64 * 64 : 2048;
   // uint8 engine: a power of two >= |x|, so that the skewed storage order stays within two neighbouring sub-chunks (locate_fast)
   if (p.semantics == MI355_SW_U8SAT) sub_len = std::max<int64_t>(sub_len, score_sub_len(p.semantics, b));
   int64_t chunk = 0;
   int wg_per_cu = 1;
   for (;;) {
-    const size_t lds = long_lds_bytes(ref.ncodes, b.nstrips, pipes, b.R, kLongSubsMax);
-    wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(long_max_waves(b.R) / (b.nstrips * pipes))));
-    const int64_t G = opt().long_wgs > 0 ? opt().long_wgs : (int64_t)256 * wg_per_cu;
-    chunk = std::max<int64_t>(sub_len, (int64_t)std::ceil(total_cols / (double)(G * pipes) / (double)sub_len) * sub_len);
-    auto wgs = [&](int64_t c) { int64_t n = 0; for (auto &r : ranges) n += (((r.hi - r.lo) + c - 1) / c + pipes - 1) / pipes; return n; };
+    const size_t lds = long_lds_bytes(ref.ncodes, spg, pipes, b.R, kLongSubsMax, p32);
+    wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(long_max_waves(b.R) / (spg * pipes))));
+    // never more workgroups than the chip holds at once: with several workgroups per tile they WAIT for each other
+    const int64_t G = std::max<int64_t>(groups, opt().long_wgs > 0 ? opt().long_wgs : (int64_t)256 * wg_per_cu);
+    chunk = std::max<int64_t>(sub_len, (int64_t)std::ceil(total_cols / (double)((G / groups) * pipes) / (double)sub_len) * sub_len);
+    auto wgs = [&](int64_t c) { int64_t n = 0; for (auto &r : ranges) n += ((((r.hi - r.lo) + c - 1) / c + pipes - 1) / pipes) * groups; return n; };
     while (wgs(chunk) > G) chunk += sub_len;
     if (chunk / sub_len <= kLongSubsMax) break;
     sub_len *= 2;
   }
-  { const long v = opt().chunk; if (v >= sub_len) chunk = v / sub_len * sub_len; }   // tuning aid
+  if (groups == 1) { const long v = opt().chunk; if (v >= sub_len) chunk = v / sub_len * sub_len; }   // tuning aid (one workgroup per tile only:
+                                                                                                     // waiting workgroups must all be resident)
   b.chunk_len = chunk;
   b.sub_len = sub_len;
   const int64_t cpr = (maxlen + chunk - 1) / chunk;
@@ -690,6 +713,7 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   a.qbytes = q.bytes.as<uint8_t>() + q.off[qid];
   a.qlen = q.len[qid]; a.qid = qid; a.nq = (int)q.nq;
   a.htab = ctx->htab.as<uint16_t>();
+  a.ftab = ctx->ftab_s.as<float>();
   a.ncodes = ref.ncodes;
   a.gap_s = std::ldexp(t.gapf, -ctx->fshift);
   a.scale = std::ldexp(kF16Scale, -ctx->fshift);
@@ -697,19 +721,31 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   if (b.unsat) { const float v = std::ldexp(255.0f, -ctx->fshift); memcpy(&a.pubmax, &v, 4); }
   a.keys = ctx->keys.as<unsigned long long>();
   a.submax_out = nullptr;
-  a.nstrips = b.nstrips; a.pipes = pipes; a.subs_per_tile = subs_per_tile;
+  a.nstrips = b.nstrips; a.groups = groups; a.spg = spg; a.pipes = pipes; a.subs_per_tile = subs_per_tile;
+  const int64_t tgroups = (cpr + pipes - 1) / pipes;                    // workgroup sets per range
+  a.tiles_stride = tgroups * pipes;
+  a.gbound = nullptr; a.gstride = 0; a.gcount = nullptr;
+  if (groups > 1) {
+    a.gstride = a.warm + chunk + 192;
+    const size_t slots = nr * (size_t)a.tiles_stride * (size_t)(groups - 1);
+    if (ctx->brow.ensure(slots * (size_t)a.gstride * 4) || ctx->gcnt.ensure(slots * 8 + 64))
+      return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(boundary rows between the workgroups of a tile) failed");
+    HIPCHK(ctx, hipMemsetAsync(ctx->gcnt.p, 0, slots * 8, ctx->stream));
+    a.gbound = ctx->brow.as<float>();
+    a.gcount = ctx->gcnt.as<long long>();
+  }
   a.status = reinterpret_cast<int32_t *>(ctx->flags.as<unsigned int>() + 1);      // zeroed by score_begin, read by score_fetch
   const int64_t nsub = cpr * subs_per_tile;                           // sub-chunks of one range (value rows: one per range)
   a.submax_range_stride = nsub;
   if (b.sampled) {
     if (ctx->submax.ensure((size_t)nr * (size_t)nsub * 4 + 64)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(sub-chunk values) failed");
     a.submax_out = ctx->submax.as<uint32_t>();
-    // (tiles beyond a short range's end never run: their values must read as "nothing")
-    if (nr > 1) HIPCHK(ctx, hipMemsetAsync(ctx->submax.p, 0, (size_t)nr * (size_t)nsub * 4, ctx->stream));
+    // (the workgroups of a tile merge their values by atomic maximum; tiles beyond a short range's end never run)
+    HIPCHK(ctx, hipMemsetAsync(ctx->submax.p, 0, (size_t)nr * (size_t)nsub * 4, ctx->stream));
   }
-  const size_t shmem = long_lds_bytes(ref.ncodes, b.nstrips, pipes, b.R, subs_per_tile);
-  const dim3 grid((unsigned)((cpr + pipes - 1) / pipes), (unsigned)nr);
-  const dim3 block((unsigned)(64 * b.nstrips * pipes));
+  const size_t shmem = long_lds_bytes(ref.ncodes, spg, pipes, b.R, subs_per_tile, p32);
+  const dim3 grid((unsigned)(tgroups * groups), (unsigned)nr);
+  const dim3 block((unsigned)(64 * spg * pipes));
   if (ctx->score_ev.size() < ctx->score_ev_used + 2) {
     for (int e = 0; e < 2; ++e) { hipEvent_t ev; HIPCHK(ctx, hipEventCreate(&ev)); ctx->score_ev.push_back(ev); }
   }
@@ -718,10 +754,14 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     hipLaunchKernelGGL(kernel, grid, block, shmem, ctx->stream, a);
   };
-  if (b.R == 20) { if (b.sampled) launch(sw_long_kernel<20, 4>); else launch(sw_long_kernel<20, 1>); }
-  else if (b.R == 24) { if (b.sampled) launch(sw_long_kernel<24, 4>); else launch(sw_long_kernel<24, 1>); }
-  else if (b.R == 32) { if (b.sampled) launch(sw_long_kernel<32, 4>); else launch(sw_long_kernel<32, 1>); }
-  else return fail(ctx, MI355_SW_ENOTSUP, "no sw_long_kernel instance for this R");
+#define LONG_CASE(r) \
+  if (b.R == r) { \
+    if (p32) { if (b.sampled) launch(sw_long_kernel<r, 4, true>); else launch(sw_long_kernel<r, 1, true>); } \
+    else { if (b.sampled) launch(sw_long_kernel<r, 4, false>); else launch(sw_long_kernel<r, 1, false>); } \
+  } else
+  LONG_CASE(20) LONG_CASE(24) LONG_CASE(32)
+    return fail(ctx, MI355_SW_ENOTSUP, "no sw_long_kernel instance for this R");
+#undef LONG_CASE
   HIPCHK(ctx, hipGetLastError());
   ctx->long_launched = true;
   if (b.sampled) {
@@ -747,8 +787,8 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     ki.cell = b.sem; ki.lanes = 64; ki.rows_per_lane = b.R; ki.strips = b.nstrips; ki.twin = 0;
     ki.chunk_len = chunk; ki.sub_len = sub_len; ki.warm = a.warm; ki.cells = cells;
     ki.valu_ops_per_cell = valu_ops_per_cell(b);
-    std::snprintf(ki.name, sizeof ki.name, "sw_long_kernel<R=%d, f32 cells, f16 profile; %d strips pipelined over a workgroup, %d tile(s) per workgroup>%s%s",
-                  b.R, b.nstrips, pipes, b.unsat ? " uint8 engine swept unsaturated, maxima clamped at 255" : "",
+    std::snprintf(ki.name, sizeof ki.name, "sw_long_kernel<R=%d, f32 cells, %s profile; %d strips pipelined over %d workgroup(s), %d tile(s) per workgroup>%s%s",
+                  b.R, p32 ? "f32" : "f16", b.nstrips, groups, pipes, b.unsat ? " uint8 engine swept unsaturated, maxima clamped at 255" : "",
                   b.sampled ? "; maximum folded every 4th step (candidates re-evaluated)" : "");
   }
   return 0;

@@ -19,6 +19,15 @@
 // Cells, scaling and results are those of Cell<kSemF32> (sw_score_kernel.h): keys (max << 32 | ~sub-chunk) by atomicMax,
 // per-sub-chunk values for the sampled maximum (MK = 4).
 //
+// Float32 profile, several workgroups per tile (P32 = true): the float16 profile costs a v_fma_mix_f32 (4 cycles per wave64
+// instruction) where the float32 one takes a v_add_f32 clamp (2: it issues at the double rate), 12 % of the cell.  A float32
+// profile of the whole query does not fit one CU (10 kbp x 5 codes x 4 B = 205 KB), so the strips of a tile are dealt to
+// `groups` workgroups — on as many CUs — of `spg` strips each (10 kbp: 2 x 4 strips of 1280 rows, 102 KB per CU); the bottom
+// row of a workgroup's last strip reaches the next workgroup's first strip through a global row (one float per column, written
+// once, read once: 8 B per column and tile against 10^4 cell updates) with an agent-scope progress counter per (tile, group).
+// The chain of waits is acyclic (group g only waits for group g - 1) and every workgroup of the launch is resident (the host
+// never launches more workgroups than the chip holds at once), so the waits terminate; they are bounded all the same.
+//
 // Flow control between the wavefronts of a pipeline: sw_strip_kernel.h's (produced / consumed counters per wavefront,
 // release stores once per segment, acquire polls with s_sleep, every wait bounded; on expiry the workgroup raises
 // *status and drains, the host reports an error).  `pipes` pipelines (tiles) may share one workgroup and its profile.
@@ -46,6 +55,7 @@ struct LongArgs {
   int32_t qid;                 // its id (column of keys)
   int32_t nq;                  // row length of keys
   const uint16_t *htab;        // [256][ncodes] float16 bits of score / 2048; column ncodes-1 = padding
+  const float *ftab;           // P32: [256][ncodes] score * 2^-k
   int32_t ncodes;
   float gap_s;                 // gap * 2^-k
   float scale;                 // 2048 * 2^-k
@@ -53,8 +63,14 @@ struct LongArgs {
   unsigned long long *keys;    // [nranges][nq]
   uint32_t *submax_out;        // MK > 1: value of every sub-chunk (float bits), range r at submax_out + r * submax_range_stride; else null
   int64_t submax_range_stride;
-  int32_t nstrips;             // strips = wavefronts per pipeline
+  int32_t nstrips;             // strips of the query
+  int32_t groups;              // workgroups a tile's strips are dealt to (1: the whole pipeline in one workgroup)
+  int32_t spg;                 // strips per workgroup = wavefronts per pipeline and workgroup (ceil(nstrips / groups))
   int32_t pipes;               // pipelines (tiles) per workgroup
+  int64_t tiles_stride;        // tiles per range, rounded up to whole workgroups (indexes gbound / gcount)
+  float *gbound;               // groups > 1: [(range * tiles_stride + tile) * (groups - 1) + g][gstride] bottom rows of group g
+  int64_t gstride;
+  long long *gcount;           // ... and the positions of it that are complete (zero at launch)
   int32_t subs_per_tile;       // chunk_len / sub_len
   int32_t *status;             // set to 1 when a pipeline wait expired
 };
@@ -67,10 +83,10 @@ struct LongArgs {
 __host__ __device__ constexpr bool long_wide(int R) { return R == 24; }
 __host__ __device__ constexpr int long_lane_stride(int R) { return long_wide(R) ? lane_stride(R / 2) : ((R / 2) % 8 == 0 ? R / 2 + 2 : R / 2); }
 
-// bytes of dynamic LDS
-__host__ __device__ inline size_t long_lds_bytes(int ncodes, int nstrips, int pipes, int R, int subs_per_tile) {
-  const size_t prof = (size_t)ncodes * nstrips * 64 * long_lane_stride(R) * 4;
-  const size_t waves = (size_t)nstrips * pipes;
+// bytes of dynamic LDS of a workgroup that holds `spg` strips of `pipes` tiles (p32: float32 profile entries)
+__host__ __device__ inline size_t long_lds_bytes(int ncodes, int spg, int pipes, int R, int subs_per_tile, bool p32 = false) {
+  const size_t prof = (size_t)ncodes * spg * 64 * (p32 ? lane_stride(R) : long_lane_stride(R)) * 4;
+  const size_t waves = (size_t)spg * pipes;
   return prof + waves * kLongRing * 4 + (size_t)pipes * subs_per_tile * 4;
 }
 
@@ -78,34 +94,41 @@ __host__ __device__ inline size_t long_lds_bytes(int ncodes, int nstrips, int pi
 // (R = 20 / 24), three at <= 168 (R = 32: 2048-row strips, a third less per-step overhead per cell)
 __host__ __device__ constexpr int long_max_waves(int R) { return R >= 32 ? 12 : kLongMaxWaves; }
 
-template <int R, int MK>
+template <int R, int MK, bool P32 = false>
 __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const LongArgs a) {
   static_assert(R % 4 == 0, "two float16 profile entries per dword, whole 8-byte reads");
   static_assert(MK == 1 || MK == 4, "running maximum every step or every 4th");
-  constexpr int LSH = long_lane_stride(R);     // dwords between the profile rows of adjacent lanes
-  constexpr bool WIDE = long_wide(R);          // ds_read_b128 (else ds_read_b64)
+  constexpr int LSH = P32 ? lane_stride(R) : long_lane_stride(R);   // dwords between the profile rows of adjacent lanes
+  constexpr bool WIDE = P32 || long_wide(R);   // ds_read_b128 (else ds_read_b64)
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   __shared__ long long produced[kLongMaxWaves], consumed[kLongMaxWaves + 1];
   __shared__ int dead;
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;   // (w in an SGPR: everything derived from it branches uniformly)
-  const int nwaves = a.nstrips * a.pipes;
-  uint32_t *prof = smem;                                                   // [ncodes][nstrips][64][LSH]
-  float *ring_all = reinterpret_cast<float *>(prof + (size_t)a.ncodes * a.nstrips * 64 * LSH);
+  const int nwaves = a.spg * a.pipes;
+  const int grp = (int)(blockIdx.x % (unsigned)a.groups);                  // which part of the tile's strips this workgroup holds
+  const int64_t tgroup = blockIdx.x / (unsigned)a.groups;
+  uint32_t *prof = smem;                                                   // [ncodes][spg][64][LSH]
+  float *ring_all = reinterpret_cast<float *>(prof + (size_t)a.ncodes * a.spg * 64 * LSH);
   uint32_t *submax_all = reinterpret_cast<uint32_t *>(ring_all + (size_t)nwaves * kLongRing);
 
-  // ---- the whole query's profile, float16 ------------------------------------------------------
+  // ---- the profile of this workgroup's strips (rows grp*spg*64*R ...) ----------------------------
   {
-    const int per_code = a.nstrips * 64 * R;
+    const int per_code = a.spg * 64 * R;
+    const int row0 = grp * a.spg * 64 * R;
     uint16_t *p16 = reinterpret_cast<uint16_t *>(prof);
     for (int e = tid; e < a.ncodes * per_code; e += blockDim.x) {
       const int c = e / per_code;
       const int rem = e - c * per_code;
-      const int sl = rem / R, r = rem - sl * R;                            // sl = strip * 64 + lane
-      const int i = sl * R + r;
-      const uint16_t v = (i < a.qlen) ? a.htab[(int)a.qbytes[i] * a.ncodes + c] : (uint16_t)0xC800;   // padding rows: -8 = -16384 / 2048
-      p16[((size_t)(c * a.nstrips * 64 + sl) * LSH) * 2 + r] = v;
+      const int sl = rem / R, r = rem - sl * R;                            // sl = local strip * 64 + lane
+      const int i = row0 + sl * R + r;
+      if (P32) {
+        prof[(size_t)(c * a.spg * 64 + sl) * LSH + r] = __float_as_uint((i < a.qlen) ? a.ftab[(int)a.qbytes[i] * a.ncodes + c] : kPadScoreF);
+      } else {
+        const uint16_t v = (i < a.qlen) ? a.htab[(int)a.qbytes[i] * a.ncodes + c] : (uint16_t)0xC800;   // padding rows: -8 = -16384 / 2048
+        p16[((size_t)(c * a.spg * 64 + sl) * LSH) * 2 + r] = v;
+      }
     }
   }
   if (tid < kLongMaxWaves) produced[tid] = 0;
@@ -114,12 +137,13 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
   for (int e = tid; e < a.pipes * a.subs_per_tile; e += blockDim.x) submax_all[e] = 0u;
   __syncthreads();
 
-  const int pipe = w / a.nstrips, strip = w - pipe * a.nstrips;
+  const int pipe = w / a.spg, ls = w - pipe * a.spg;                       // pipeline, strip within this workgroup
+  const int strip = grp * a.spg + ls;                                      // strip of the query
   const int range = blockIdx.y;
   const int64_t rlo = a.range_lo[range], rhi = a.range_hi[range];
   const int64_t ntiles = (rhi - rlo + a.chunk_len - 1) / a.chunk_len;
-  const int64_t tile = (int64_t)blockIdx.x * a.pipes + pipe;
-  const bool active = w < nwaves && tile < ntiles;
+  const int64_t tile = tgroup * a.pipes + pipe;
+  const bool active = w < nwaves && tile < ntiles && strip < a.nstrips;
   const int64_t own_lo = rlo + tile * a.chunk_len;
   const int64_t own_hi = (own_lo + a.chunk_len < rhi) ? own_lo + a.chunk_len : rhi;
   const int64_t s0 = own_lo - a.warm;                                      // reference index of stream position 0
@@ -141,15 +165,32 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
         __builtin_amdgcn_s_sleep(2);
       }
     };
+    auto wait_global = [&](long long *counter, long long need) {          // progress of the workgroup above (device scope)
+      int spins = 0;
+      while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        if (__hip_atomic_load(&dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 || ++spins > kLongSpinLimit) {
+          __hip_atomic_store(&dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          ok = false;
+          return;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    };
     const bool has_in = strip > 0, has_out = strip + 1 < a.nstrips;
-    const float *rin = ring_all + (size_t)(has_in ? w - 1 : w) * kLongRing;
+    const bool in_global = has_in && ls == 0, out_global = has_out && ls == a.spg - 1;
+    const float *rin = ring_all + (size_t)((has_in && !in_global) ? w - 1 : w) * kLongRing;
     float *rout = ring_all + (size_t)w * kLongRing;
+    const size_t gslot = ((size_t)range * (size_t)a.tiles_stride + (size_t)tile) * (size_t)(a.groups > 1 ? a.groups - 1 : 1);
+    const float *gin = in_global ? a.gbound + (gslot + (size_t)(grp - 1)) * (size_t)a.gstride : nullptr;
+    float *gout = out_global ? a.gbound + (gslot + (size_t)grp) * (size_t)a.gstride : nullptr;
+    long long *gin_count = in_global ? a.gcount + gslot + (size_t)(grp - 1) : nullptr;
+    long long *gout_count = out_global ? a.gcount + gslot + (size_t)grp : nullptr;
     auto stage_load = [&](int seg) -> uint32_t {                           // code of stream position seg*64 + l
       const int64_t col = s0 + (int64_t)seg * 64 + l;
       return (col >= rlo && col < own_hi) ? (uint32_t)a.refcodes[col] : pad;
     };
-    const char *prof_lane = reinterpret_cast<const char *>(prof + (size_t)(strip * 64 + l) * LSH);
-    const uint32_t code_stride = (uint32_t)a.nstrips * 64 * LSH * 4;       // bytes per reference code (a multiple of 64 dwords:
+    const char *prof_lane = reinterpret_cast<const char *>(prof + (size_t)(ls * 64 + l) * LSH);
+    const uint32_t code_stride = (uint32_t)a.spg * 64 * LSH * 4;           // bytes per reference code (a multiple of 64 dwords:
                                                                            // the lane -> bank map is the same for every code)
     float gv = a.gap_s, sv = a.scale;
     asm volatile("" : "+v"(gv), "+v"(sv));                                 // VGPR operands: an SGPR operand halves the issue rate of v_sub_f32
@@ -186,13 +227,19 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
 
     for (int seg = 0; seg < nseg && ok; ++seg) {
       // input: boundary positions seg*64 .. seg*64+63 (the strip above finishes them during ITS segment seg + 1)
-      if (has_in) wait_for(&produced[w - 1], ((int64_t)(seg + 1) * 64 < nb) ? (long long)(seg + 1) * 64 : (long long)nb);
+      const long long need_in = ((int64_t)(seg + 1) * 64 < nb) ? (long long)(seg + 1) * 64 : (long long)nb;
+      if (in_global) wait_global(gin_count, need_in);
+      else if (has_in) wait_for(&produced[w - 1], need_in);
       // ring space: this segment stores positions <= seg*64 over the slots of positions <= seg*64 - kLongRing
-      if (has_out) wait_for(&consumed[w + 1], (long long)seg * 64 - kLongRing + 64);
+      // (the global row holds every position: nothing to wait for)
+      if (has_out && !out_global) wait_for(&consumed[w + 1], (long long)seg * 64 - kLongRing + 64);
       if (!ok) break;
       // positions >= nb (the segment after the last column: nb is a multiple of 64) are only reached by lagging lanes; the
       // strip above has not produced them: zero boundary there (padding columns, lower values only)
-      uint32_t bseg = (has_in && (int64_t)seg * 64 < nb) ? __float_as_uint(rin[(seg * 64 + l) & (kLongRing - 1)]) : 0u;
+      uint32_t bseg = 0u;
+      if (has_in && (int64_t)seg * 64 < nb)
+        bseg = in_global ? __float_as_uint(__hip_atomic_load(gin + (size_t)seg * 64 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                         : __float_as_uint(rin[(seg * 64 + l) & (kLongRing - 1)]);
       uint32_t cseg = curc;
       curc = nextc;
       nextc = stage_load(seg + 2);
@@ -204,8 +251,15 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
           cseg = rot1(cseg);
           code = shr1(head, code);
         }
-        uint32_t p[R / 2];
-        if constexpr (WIDE) {
+        uint32_t p[P32 ? R : R / 2];
+        if constexpr (P32) {
+          const u32x4 *pp = static_cast<const u32x4 *>(__builtin_assume_aligned(prof_lane + __umul24(code, code_stride), 16));
+#pragma unroll
+          for (int q = 0; q < R / 4; ++q) {
+            const u32x4 v = pp[q];
+            p[4 * q + 0] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+          }
+        } else if constexpr (WIDE) {
           const u32x4 *pp = static_cast<const u32x4 *>(__builtin_assume_aligned(prof_lane + __umul24(code, code_stride), 16));
 #pragma unroll
           for (int q = 0; q < R / 8; ++q) {
@@ -234,7 +288,8 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
           const float wv = H[r];
           float x, h;
           // x = clamp(score * scale + NW): the [0, 1] clamp is the zero floor (cells hold H * 2^-k in [0, 1))
-          if (r & 1) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(x) : "v"(p[r >> 1]), "v"(sv), "v"(diag));
+          if constexpr (P32) asm("v_add_f32_e64 %0, %1, %2 clamp" : "=v"(x) : "v"(diag), "v"(p[r]));
+          else if (r & 1) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(x) : "v"(p[r >> 1]), "v"(sv), "v"(diag));
           else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0] clamp" : "=v"(x) : "v"(p[r >> 1]), "v"(sv), "v"(diag));
           asm("v_max3_f32 %0, %1, %2, %3" : "=v"(h) : "v"(x), "v"(Hg[r]), "v"(ng));
           if (MK == 1 || (k & (MK - 1)) == MK - 1) {                       // (compile-time per unrolled step)
@@ -249,12 +304,15 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
         if (has_out) oseg = shl1_insert(__float_as_uint(H[R - 1]), oseg);  // lane 63 inserts, the others pass down
       }
       // lane j of oseg holds lane 63's value of step j: stream position seg*64 + j - 63
-      if (has_out) {
+      // positions <= seg*64 are stored; this wavefront has read positions <= seg*64 + 63
+      if (out_global) {
+        const int64_t t = (int64_t)seg * 64 + l - 63;
+        if (t >= 0) __hip_atomic_store(gout + t, __uint_as_float(oseg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                 // (all lanes' stores before lane 0's counter)
+        if (l == 0) __hip_atomic_store(gout_count, (long long)seg * 64 + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (has_out) {
         const int t = seg * 64 + l - 63;
         if (t >= 0) rout[t & (kLongRing - 1)] = __uint_as_float(oseg);
-      }
-      // positions <= seg*64 are stored; this wavefront has read positions <= seg*64 + 63
-      if (has_out) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");             // (all lanes' ring stores before lane 0's flag)
         if (l == 0) __hip_atomic_store(&produced[w], (long long)seg * 64 + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
@@ -265,6 +323,8 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
       if (done > 0 && done % segs_per_sub == 0 && done / segs_per_sub < a.subs_per_tile) fold_sub(sub++);
     }
     if (ok) fold_sub(a.subs_per_tile - 1);                                 // the tile's last (or only) sub-chunk
+    // whatever happened, the workgroup below must not wait for this one any more
+    if (out_global && l == 0) __hip_atomic_store(gout_count, 0x7FFFFFFFFFFFFFFFll, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (l == 0 && w < kLongMaxWaves) {
     // whatever happened, nobody may wait on this wavefront any more
@@ -275,11 +335,13 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
   __syncthreads();                                                         // every wavefront gets here: all waits are bounded
 
   // ---- publish: wavefront 0 of each pipeline ------------------------------------------------------
-  if (active && strip == 0 && __hip_atomic_load(&dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+  if (active && ls == 0 && __hip_atomic_load(&dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
     uint32_t bv = 0u, bs = 0xFFFFFFFFu;                                    // best value, first sub-chunk that holds it
     for (int s = l; s < a.subs_per_tile; s += 64) {
       uint32_t v = submax[s];
-      if (MK > 1 && a.submax_out != nullptr) a.submax_out[(size_t)range * (size_t)a.submax_range_stride + (size_t)tile * a.subs_per_tile + s] = v;
+      // (several workgroups may hold strips of this tile: the values merge by maximum; the host zeroes the rows)
+      if (MK > 1 && a.submax_out != nullptr && v != 0u)
+        atomicMax(&a.submax_out[(size_t)range * (size_t)a.submax_range_stride + (size_t)tile * a.subs_per_tile + s], v);
       if (a.pubmax != 0u && v > a.pubmax) v = a.pubmax;
       if (v > bv) { bv = v; bs = (uint32_t)s; }
     }

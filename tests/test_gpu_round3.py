@@ -68,7 +68,7 @@ def fuzz_cases(pgs, oracle):
 # every switch that selects another kernel instance / pipeline for the same answer
 SWITCHES = ["no_f16", "no_unsat", "no_sample", "no_satflag", "no_solo", "no_wave", "no_comb", "no_twin", "no_wide",
             "no_strip", "no_quant", "no_f16_wide", "no_devlist", "no_strip_groups", "u8_long_twin", "long_twin", "no_long",
-            "no_requery", "slot=16", "strip_r=24", "few_r=5", "long_pipes=2"]
+            "no_requery", "slot=16", "strip_r=24", "few_r=5", "long_pipes=2", "no_long_p32", "long_groups=2", "force_f32"]
 
 
 def test_option_names_cover_the_switch_list(pgs):
@@ -123,26 +123,30 @@ def test_long_kernel_vs_oracle(pgs, oracle, sem):
     refb = bytes(refb)
     c = pgs.Context(0)
     try:
-        for chunk in (None, 8192):
-            c.set_option("chunk", chunk)
-            for pipes in (None, 2):
-                c.set_option("long_pipes", pipes)
-                for k, m in enumerate((2049, 2560, 2561, 3072, 5000, 7681, 10_000, 12_288)):
-                    if pipes == 2 and m > 64 * 24 * 8:
-                        continue
-                    o = [0, 150_000 - m, 70_000, 3000][k % 4]
-                    q = bytearray(refb[o:o + m])
-                    rng = np.random.default_rng(100 + k)
-                    for i in rng.choice(m, m // 50, replace=False):
-                        q[i] = b"ACGT"[int(rng.integers(0, 4))]
-                    q = bytes(q).replace(b"N", b"A")
-                    exp = oracle.align(q, refb, sem)
-                    got = c.align(q, refb, sem)
-                    _cmp(got, exp, "long kernel sem=%d m=%d chunk=%r pipes=%r" % (sem, m, chunk, pipes))
-                    if m <= 10_240:                                                 # (12 288 rows x 6 codes: profile beyond the LDS)
-                        assert "sw_long_kernel" in c.last_kernel()["name"], c.last_kernel()["name"]
-                q = pgs.synth.dna(7100 + sem, 4000).tobytes()                       # unrelated: background maximum
-                _cmp(c.align(q, refb, sem), oracle.align(q, refb, sem), "long kernel, unrelated query sem=%d" % sem)
+        variants = [{}, {"no_long_p32": 1}, {"no_long_p32": 1, "chunk": 8192}, {"long_pipes": 2}, {"long_groups": 2}, {"long_groups": 4, "long_pipes": 1},
+                    {"long_wgs": 12}]
+        for var in variants:
+            for k, v in var.items():
+                c.set_option(k, v)
+            for k, m in enumerate((2049, 2560, 2561, 3072, 5000, 7681, 10_000, 12_288)):
+                o = [0, 150_000 - m, 70_000, 3000][k % 4]
+                q = bytearray(refb[o:o + m])
+                rng = np.random.default_rng(100 + k)
+                for i in rng.choice(m, m // 50, replace=False):
+                    q[i] = b"ACGT"[int(rng.integers(0, 4))]
+                q = bytes(q).replace(b"N", b"A")
+                exp = oracle.align(q, refb, sem)
+                got = c.align(q, refb, sem)
+                _cmp(got, exp, "long kernel sem=%d m=%d %r" % (sem, m, var))
+                name = c.last_kernel()["name"]
+                if "no_long_p32" not in var or m <= 10_240:                     # (12 288 rows x 6 codes: float16 profile beyond one CU's LDS)
+                    assert "sw_long_kernel" in name, name
+                if "no_long_p32" in var and "sw_long_kernel" in name:
+                    assert "f16 profile" in name, name
+            q = pgs.synth.dna(7100 + sem, 4000).tobytes()                       # unrelated: background maximum
+            _cmp(c.align(q, refb, sem), oracle.align(q, refb, sem), "long kernel, unrelated query sem=%d %r" % (sem, var))
+            for k in var:
+                c.set_option(k, None)
     finally:
         c.close()
 
