@@ -149,23 +149,23 @@ template <int R>
 void launch_strip(bool u8, bool track, dim3 grid, dim3 block, hipStream_t st, const StripProblem *dp, const WaveScoring &sc,
                   const float *gtab, int ncodes, int groups = 1, bool maxmode = false) {
   if (maxmode && u8) {                          // maximum + first cell in the uint8 engine's storage order (sampled sweep)
-    hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripMax>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0, 1);
+    hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripMax>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0, groups);
     return;
   }
   if (maxmode) {                                // float engine (locate_saturated)
-    if (gtab) hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripMax, true>), grid, block, (size_t)257 * ncodes * 4, st, dp, sc, gtab, ncodes, 1);
-    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripMax>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0, 1);
+    if (gtab) hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripMax, true>), grid, block, (size_t)257 * ncodes * 4, st, dp, sc, gtab, ncodes, groups);
+    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripMax>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0, groups);
     return;
   }
   if (gtab) {                                   // table scoring (float engine): tab[257][ncodes] in dynamic LDS
     const size_t lds = (size_t)257 * ncodes * 4;
-    if (track) hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripTrack, true>), grid, block, lds, st, dp, sc, gtab, ncodes, 1);
+    if (track) hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripTrack, true>), grid, block, lds, st, dp, sc, gtab, ncodes, groups);
     else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripDirs, true>), grid, block, lds, st, dp, sc, gtab, ncodes, groups);
     return;
   }
   if (track) {
-    if (u8) hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripTrack>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0, 1);
-    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripTrack>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0, 1);
+    if (u8) hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripTrack>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0, groups);
+    else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripTrack>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0, groups);
   } else {
     if (u8) hipLaunchKernelGGL((sw_strip_kernel<R, true, kStripDirs>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0, groups);
     else hipLaunchKernelGGL((sw_strip_kernel<R, false, kStripDirs>), grid, block, 0, st, dp, sc, (const float *)nullptr, 0, groups);
@@ -200,7 +200,10 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   // SIMD) each, instead of sixteen wavefronts on one CU (config 5: the sweep of the 26 k-column window)
   const bool no_groups = opt().no_strip_groups;
   const int spg = 4;
-  const int groups = (!track && !no_groups && n <= 8 && nsmax > spg) ? (nsmax + spg - 1) / spg : 1;
+  // ... and the locate windows of a few long queries (first-cell / maximum tracking): each workgroup reports the best cell of
+  // its strips, merged below
+  const int groups = (!no_groups && nsmax > spg && n <= (track ? (size_t)32 : (size_t)8)) ? (nsmax + spg - 1) / spg : 1;
+  const size_t og = track ? (size_t)groups : 1;                    // result slots per job
   for (size_t k = 0; k < n; ++k) {
     WaveJob &j = jobs[k];
     const int ns = strip_count(q.len[j.q], R);
@@ -209,7 +212,7 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
     if (groups > 1) { goff[k] = gtotal; gtotal += (((size_t)groups * ((size_t)j.nb + 192) + 1) & ~(size_t)1) + 2 * (size_t)groups; }   // rows (even count) + 64-bit counters
     else if (ns > kStripMaxWaves) { goff[k] = gtotal; gtotal += 2 * ((size_t)j.nb + 192); }
   }
-  if (ctx->wprobs.ensure(n * sizeof(StripProblem)) || ctx->outs_i.ensure(n * 16) || ctx->outs_f.ensure(2 * n * 4) ||
+  if (ctx->wprobs.ensure(n * sizeof(StripProblem)) || ctx->outs_i.ensure(n * og * 16) || ctx->outs_f.ensure((n + n * og) * 4) ||
       (dirs_total && ctx->dirs.ensure(dirs_total)) || (gtotal && ctx->brow.ensure(gtotal * 4)))
     return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(strip scratch) failed");
   std::vector<StripProblem> pr(n);
@@ -234,12 +237,13 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
     s.own_lo = j.own_lo;
     s.col_offset = j.s_lo;
     s.full_n = rg.hi - rg.lo;
-    s.cell = ctx->outs_i.as<int64_t>() + 2 * k;
+    s.cell = ctx->outs_i.as<int64_t>() + 2 * k * og;
     s.status = ctx->outs_f.as<int32_t>() + k;
-    s.best = ctx->outs_f.as<float>() + n + k;
+    s.best = ctx->outs_f.as<float>() + n + k * og;
     s.fault = fault;
   }
-  HIPCHK(ctx, hipMemsetAsync(ctx->outs_f.p, 0, n * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->outs_f.p, 0, (n + n * og) * 4, ctx->stream));
+  if (og > 1) HIPCHK(ctx, hipMemsetAsync(ctx->outs_i.p, 0, n * og * 16, ctx->stream));       // (workgroups without strips report nothing)
   if (groups > 1) HIPCHK(ctx, hipMemsetAsync(ctx->brow.p, 0, gtotal * 4, ctx->stream));      // the progress counters start at 0
   HIPCHK(ctx, hipMemcpyAsync(ctx->wprobs.p, pr.data(), n * sizeof(StripProblem), hipMemcpyHostToDevice, ctx->stream));
   WaveScoring sc;
@@ -266,15 +270,28 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   else launch_strip<16>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups, maxmode);
   HIPCHK(ctx, hipGetLastError());
   std::vector<int32_t> st(n);
-  std::vector<int64_t> ci(2 * n);
-  std::vector<float> bv(maxmode ? n : 0);
-  if (maxmode) HIPCHK(ctx, hipMemcpyAsync(bv.data(), ctx->outs_f.as<float>() + n, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<int64_t> ci(2 * n * og);
+  std::vector<float> bv(maxmode ? n * og : 0);
+  if (maxmode) HIPCHK(ctx, hipMemcpyAsync(bv.data(), ctx->outs_f.as<float>() + n, n * og * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(st.data(), ctx->outs_f.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (track) HIPCHK(ctx, hipMemcpyAsync(ci.data(), ctx->outs_i.p, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  if (track) HIPCHK(ctx, hipMemcpyAsync(ci.data(), ctx->outs_i.p, n * og * 16, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   for (size_t k = 0; k < n; ++k) {
     if (st[k] != 0) return fail(ctx, MI355_SW_ENODEV, "internal: strip pipeline wait expired");
-    if (track) { jobs[k].ci = ci[2 * k]; jobs[k].cj = ci[2 * k + 1]; jobs[k].best = maxmode ? bv[k] : (ci[2 * k] > 0 ? jobs[k].target : -1.0f); }
+    if (!track) continue;
+    // the workgroups of a job: the greatest value (kStripMax), then the smallest storage-order key
+    float best = 0.0f;
+    int64_t bi = 0, bj = 0;
+    unsigned long long bkey = ~0ull;
+    for (size_t g = 0; g < og; ++g) {
+      const int64_t i = ci[2 * (k * og + g)], j = ci[2 * (k * og + g) + 1];
+      if (i <= 0) continue;
+      const float v = maxmode ? bv[k * og + g] : jobs[k].target;
+      const unsigned long long key = host_order_key(p.semantics, i, j, q.len[jobs[k].q], rg.hi - rg.lo);
+      if (v > best || (v == best && key < bkey)) { best = v; bi = i; bj = j; bkey = key; }
+    }
+    jobs[k].ci = bi; jobs[k].cj = bj;
+    jobs[k].best = maxmode ? best : (bi > 0 ? jobs[k].target : -1.0f);
   }
   return 0;
 }

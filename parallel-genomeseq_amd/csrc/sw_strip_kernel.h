@@ -49,8 +49,8 @@ struct StripProblem {
   int32_t own_lo;        // first stream position (0-based) that competes
   int64_t col_offset;    // true column of stream position t = col_offset + t + 1
   int64_t full_n;        // |y| of the full problem (uint8 storage order)
-  int64_t *cell;         // [2] row, true column of the first cell equal to target; row 0 when none
-  float *best;           // kStripMax: the maximum (0 when no positive cell competes)
+  int64_t *cell;         // [2 per workgroup of the problem] row, true column of the first cell equal to target; row 0 when none
+  float *best;           // kStripMax: [per workgroup] the maximum (0 when no positive cell competes)
   int32_t *status;       // 0 = complete, 1 = a pipeline wait expired (result unusable)
   int32_t spg;           // > 0: the strips are dealt to several WORKGROUPS, spg consecutive strips each (one wavefront per
                          // strip, one round); the bottom row of a workgroup's last strip reaches the next workgroup
@@ -68,10 +68,12 @@ constexpr int kStripSpinLimit = 1 << 22; // polls (with s_sleep) before a wait i
 // LUT = true (float engine): scores come from a table tab[257][ncodes] in dynamic LDS (row = query byte, row 256 =
 // padding row; column = reference code, column ncodes-1 = padding) and the stream is the window of reference
 // CODES; LUT = false: identity scoring on raw bytes, no table.
-// groups > 1 (kStripDirs only): the grid holds `groups` workgroups per problem — the traceback decisions of ONE long
-// alignment on several CUs (a workgroup of sixteen wavefronts is bound by its CU's issue rate: 31 ms for config 5's
-// 26 k-column window); all workgroups of a launch are resident at once (the host keeps the grid far below the CU count),
-// the chain of waits is acyclic (strip s only waits for strip s - 1) and every wait is bounded as before.
+// groups > 1: the grid holds `groups` workgroups per problem — the sweep of ONE long alignment's window on several CUs (a
+// workgroup of sixteen wavefronts is bound by its CU's issue rate: 31 ms for the decisions of config 5's 26 k-column window,
+// 8.6 ms for the candidate windows of its locate step); all workgroups of a launch are resident at once (the host keeps the
+// grid far below the CU count), the chain of waits is acyclic (strip s only waits for strip s - 1) and every wait is bounded
+// as before.  kStripMax / kStripTrack: every workgroup reports the best cell of ITS strips (best[grp], cell[2 grp ..]); the
+// host merges them by (value, storage-order key).
 template <int R, bool U8, int MODE, bool LUT = false>
 __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const StripProblem *probs, const WaveScoring sc,
                                                                        const float *gtab = nullptr, int ncodes = 0, int groups = 1) {
@@ -317,9 +319,9 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
     if (tid == 0) {
       for (int k = 1; k < (int)(blockDim.x >> 6); ++k)
         if (wval[k] > bval || (wval[k] == bval && wkey[k] < bkey)) { bval = wval[k]; bkey = wkey[k]; bi = wi[k]; bj = wj[k]; }
-      *P.best = bval;
-      P.cell[0] = bval > 0.0f ? bi : 0;
-      P.cell[1] = bval > 0.0f ? bj : 0;
+      P.best[grp] = bval;
+      P.cell[2 * grp] = bval > 0.0f ? bi : 0;
+      P.cell[2 * grp + 1] = bval > 0.0f ? bj : 0;
     }
   }
   if (MODE == kStripTrack) {
@@ -334,8 +336,8 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
     if (tid == 0) {
       for (int k = 1; k < (int)(blockDim.x >> 6); ++k)
         if (wkey[k] < bkey) { bkey = wkey[k]; bi = wi[k]; bj = wj[k]; }
-      P.cell[0] = bkey != ~0ull ? bi : 0;
-      P.cell[1] = bkey != ~0ull ? bj : 0;
+      P.cell[2 * grp] = bkey != ~0ull ? bi : 0;
+      P.cell[2 * grp + 1] = bkey != ~0ull ? bj : 0;
     }
   }
 }
