@@ -582,12 +582,22 @@ def strong_config5(pgs, D, args, device):
             ctx.best_range(local[:1], semantics=pgs.F32)                   # warm-up: scratch buffers, code objects
 
         def step():
-            key = 0
-            if mine:
-                # winner-only sweep of this rank's pieces (mi355_sw_best_range): all the reduction needs is the rank's best piece
-                best, which, _ = ctx.best_range(local, semantics=pgs.F32)
-                key = int(np.float32(best[0]).view(np.uint32)) << 32 | (0xFFFFFFFF - mine[int(which[0])])
-            key = D.max_key(key)
+            # winner-only sweep of this rank's pieces (mi355_sw_best_range): all the reduction needs is the rank's best piece.
+            # The sweep's warm-up margin is optimistic: exact for maxima above `above` (the same value on every rank); when the
+            # merged best does not exceed it, every rank sweeps again with the margin that best needs (known_best) — one more
+            # 8-byte all-reduce decides, identically on all ranks.
+            known = 0.0
+            for _ in range(3):
+                key, above = 0, -1.0
+                if mine:
+                    best, which, _, above = ctx.best_range(local, semantics=pgs.F32, known_best=known, want_exact_above=True)
+                    key = int(np.float32(best[0]).view(np.uint32)) << 32 | (0xFFFFFFFF - mine[int(which[0])])
+                key = D.max_key(key)
+                above = D.max_float(above)
+                gbest = float(np.uint32(key >> 32).view(np.float32))
+                if gbest > above:
+                    break
+                known = max(gbest, 1.0)
             piece = 0xFFFFFFFF - (key & 0xFFFFFFFF)
             res = None
             if piece in mine:

@@ -156,10 +156,18 @@ int mi355_sw_score_ranges(mi355_sw_ctx *ctx, size_t nranges, const int64_t *left
  * greatest maximum (best[q], best_range[q]; -1 / -1 without ranges) — all OMPParallelLocalAligner does with the per-piece
  * maxima (plocalaligner.cpp:106,122-129).  That freedom lets a lone long query take the cheaper sampled sweep: ranges that
  * cannot hold the greatest maximum are not re-evaluated, so their entries of `maxima` (optional, may be NULL) are lower
- * bounds within three gap penalties; best / best_range and the winner's entry are exact.  For multi-GPU reference
- * sharding: every rank calls it on its own pieces, the packed (best, ~piece) keys are merged by one 8-byte all-reduce(MAX). */
+ * bounds within three gap penalties; best / best_range and the winner's entry are exact.
+ * A lone long query is also swept with an OPTIMISTIC warm-up margin in front of its tiles: enough for maxima above 11/12 of
+ * the best possible score, not for every cell.  exact_above == NULL: the call checks its own best against
+ * what that margin certifies and sweeps again with the margin its best needs when it falls short — results as above.
+ * exact_above != NULL (multi-GPU reference sharding: every rank calls this on its own pieces and the packed (best, ~piece)
+ * keys are merged by one 8-byte all-reduce(MAX)): no second sweep here; *exact_above = the value above which this call was
+ * exact (the same on every rank; -1: everything).  When the MERGED best does not exceed it, every rank calls again with
+ * known_best = the merged best (a lower bound of the true one): the margin is then the one that value needs, and the second
+ * merge is exact.  known_best <= 0: nothing known. */
 int mi355_sw_best_range(mi355_sw_ctx *ctx, size_t nranges, const int64_t *lefts, const int64_t *rights,
-                        const mi355_sw_params *params, float *maxima, float *best, int64_t *best_range);
+                        const mi355_sw_params *params, float known_best, float *maxima, float *best, int64_t *best_range,
+                        float *exact_above);
 
 /* Finishes range `range_index` of the LAST mi355_sw_score_ranges / mi355_sw_best_range call on this context as a stand-alone problem: argmax
  * cell and traceback of every resident query within [lefts[k], rights[k]) — what LAT(sequence_x, winning piece) computes

@@ -259,9 +259,11 @@ class Context:
                                                 out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
-    def best_range(self, ranges, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None):
+    def best_range(self, ranges, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None, known_best=0.0, want_exact_above=False):
         """Per resident query the first range with the greatest maximum (mi355_sw_best_range): (best[nq], best_range[nq],
-        maxima[len(ranges), nq] — exact for the winners, lower bounds for ranges that cannot win)."""
+        maxima[len(ranges), nq] — exact for the winners, lower bounds for ranges that cannot win).  want_exact_above=True (the
+        multi-rank protocol): a fourth value, the maximum above which this call was exact (-1: everything); the caller merges
+        the ranks' bests and calls again with known_best = the merged best when that does not exceed it."""
         p, keep = make_params(semantics, match, mismatch, gap, lut)
         n = len(ranges)
         lefts = (C.c_int64 * max(1, n))(*[r[0] for r in ranges])
@@ -269,9 +271,12 @@ class Context:
         mx = np.zeros((n, self._nbatch), dtype=np.float32)
         best = np.zeros(self._nbatch, dtype=np.float32)
         which = np.zeros(self._nbatch, dtype=np.int64)
-        self._chk(self._L.mi355_sw_best_range(self._ctx, C.c_size_t(n), lefts, rights, C.byref(p),
+        above = C.c_float(-1.0)
+        self._chk(self._L.mi355_sw_best_range(self._ctx, C.c_size_t(n), lefts, rights, C.byref(p), C.c_float(known_best),
                                               mx.ctypes.data_as(C.POINTER(C.c_float)), best.ctypes.data_as(C.POINTER(C.c_float)),
-                                              which.ctypes.data_as(C.POINTER(C.c_int64))))
+                                              which.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(above) if want_exact_above else None))
+        if want_exact_above:
+            return best, which, mx, float(above.value)
         return best, which, mx
 
     def align_scored_range(self, k, semantics=F32, match=3.0, mismatch=-3.0, gap=2.0, lut=None, flags=0, query=0):

@@ -491,12 +491,26 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       for (size_t k = 0; k < nq; ++k) any_fast |= qfast[k] != 0;
       if (pre->sampled && nq == 1 && pre->has_located[pre_range]) { loc[0] = pre->located[pre_range]; qdone[0] = 1; }
     }
-    for (int attempt = 0; attempt < 2 && !pre; ++attempt) {
+    ctx->long_margin = 0;
+    // sw_long_kernel swept with an optimistic warm-up margin (long_score_launch): the lone query's maximum must lie above what
+    // that margin certifies, else the sweep is repeated with the margin this maximum needs (which then certifies it)
+    auto margin_certified = [&](float best) {
+      if (!(ctx->long_cert >= 0.0f) || best > ctx->long_cert) return true;
+      const double m = (double)q.maxlen;
+      ctx->long_margin = (int64_t)(m + std::ceil(((double)table.smax * m - (double)best) / (double)table.gap)) + 2 + 64;
+      ctx->last_kernel.cells = 0; ctx->timings[4] = 0; ctx->timings[5] = 0;
+      ctx->whole_again += 1;
+      return false;
+    };
+    for (int attempt = 0; attempt < 4 && !pre; ++attempt) {
       buckets.clear();
       if (n >= 1024) buckets = make_buckets(ref, q, table, p, n, allow_sat, allow_sample);
       any_fast = false;
       bool any_sat = false;
-      for (Bucket &b : buckets) { b.fast = bucket_fast_ok(ref, table, b, n, p); any_fast |= b.fast; any_sat |= b.fast && (b.satflag || b.sampled); }
+      for (Bucket &b : buckets) {
+        b.fast = bucket_fast_ok(ref, table, b, n, p); any_fast |= b.fast; any_sat |= b.fast && (b.satflag || b.sampled);
+        b.opt_margin = b.longp && !opt().no_opt_margin;
+      }
       if (!any_fast) break;
       const std::vector<Range> ranges{rg};
       int rc = score_begin(ctx, q, ranges, table);
@@ -514,7 +528,13 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       }
       rc = score_fetch(ctx, nq, keys);
       if (rc) return rc;
-      if (!any_sat) break;
+      if (!any_sat) {
+        if (ctx->long_cert >= 0.0f && nq == 1) {                       // exact keys: the lone query's maximum as swept
+          float v; const uint32_t hi32 = (uint32_t)(keys[0] >> 32); memcpy(&v, &hi32, 4);
+          if (!margin_certified(std::ldexp(v, ctx->fshift))) continue;
+        }
+        break;
+      }
       // the flagged (query, sub-chunk) pairs of the saturating sweep
       unsigned int nflag = 0;
       HIPCHK(ctx, hipMemcpy(&nflag, ctx->flags.p, 4, hipMemcpyDeviceToHost));
@@ -602,6 +622,10 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       for (size_t k = 0; k < nq; ++k)
         if (qsat[k] && !qdone[k] && (qsat[k] == 2 ? (keys[k] >> 32) != 0 : half_value((uint16_t)(keys[k] >> 32)) * kF16Scale >= kF16Scale))
           return fail(ctx, MI355_SW_ENODEV, "internal: a saturated or sampled query without a flagged sub-chunk");
+      if (ctx->long_cert >= 0.0f && nq == 1 && !margin_certified(qdone[0] ? loc[0].score : 0.0f)) {
+        loc[0] = Located(); qdone[0] = 0;
+        continue;
+      }
       break;
     }
     if (any_fast) {
@@ -729,10 +753,16 @@ int align_range_view(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
 // sampled maximum (every 4th step: keys are lower bounds within three gaps), and only the ranges whose key lies within that
 // slack of the best key — the only ones that can hold the greatest maximum — have their candidate sub-chunks re-evaluated
 // exactly; the maxima of the other ranges stay lower bounds.
+// known_best / exact_above (winner_only): the sweep of a lone long query uses an optimistic warm-up margin (long_score_launch)
+// and is exact for maxima above *exact_above.  known_best > 0: a lower bound of the greatest maximum the caller already knows
+// (from other ranks, or from a first call) — the margin is then the one THAT value needs, so that every range whose maximum
+// reaches it comes out exact.  exact_above == nullptr: this function certifies its own best by sweeping again when needed.
 int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const std::vector<Range> &ranges,
-                 const mi355_sw_params &p, float *maxima /* [nranges][nq] */, bool winner_only = false) {
+                 const mi355_sw_params &p, float *maxima /* [nranges][nq] */, bool winner_only = false, float known_best = 0.0f,
+                 float *exact_above = nullptr) {
   const size_t nq = q.nq, nr = ranges.size();
   ctx->scored.valid = false;
+  if (exact_above) *exact_above = -1.0f;
   if (nq == 0 || nr == 0) return 0;
   const ScoreTable table = plan_table(ref, p);
   // no positive score possible (see align_range): every maximum is 0
@@ -752,7 +782,11 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     for (auto &r : ranges) b.fast = b.fast && bucket_fast_ok(ref, table, b, r.hi - r.lo, p);
     if (!b.longp) b.sampled = false;                               // only sw_long_kernel lays out one value row per range
     sampled |= b.fast && b.sampled;
+    b.opt_margin = winner_only && b.longp && nq == 1 && !opt().no_opt_margin;
   }
+  ctx->long_margin = 0;
+  if (winner_only && nq == 1 && known_best > 0.0f && table.integral)
+    ctx->long_margin = (int64_t)((double)q.maxlen + std::ceil(((double)table.smax * (double)q.maxlen - (double)known_best) / (double)table.gap)) + 2 + 64;
   // what a following mi355_sw_align_scored_range needs (one launch group only: the geometry is per launch)
   ScoredRanges &sc = ctx->scored;
   sc.valid = false;
@@ -839,6 +873,19 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
         return range_maxima(ctx, ref, q, ranges, p, maxima, false);
       }
       if (keep) sc.sampled = true;
+    }
+    if (winner_only && nq == 1 && ctx->long_cert >= 0.0f) {
+      // optimistic margin: exact above long_cert.  The caller merges several ranks' results and checks the GLOBAL best
+      // against it (exact_above); without a caller's check, this call certifies its own best
+      float top = 0.0f;
+      for (size_t r = 0; r < nr; ++r) top = std::max(top, maxima[r]);
+      if (exact_above) *exact_above = ctx->long_cert;
+      else if (!(top > ctx->long_cert)) {
+        ctx->whole_again += 1;
+        ctx->timings[4] = 0; ctx->timings[5] = 0; ctx->last_kernel.cells = 0;
+        // the margin `top` needs; a second call is exact for every maximum >= top, hence for the true best
+        return range_maxima(ctx, ref, q, ranges, p, maxima, true, std::max(top, 1.0f), nullptr);
+      }
     }
   }
   std::vector<int> slow;

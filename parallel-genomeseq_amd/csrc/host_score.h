@@ -34,6 +34,7 @@ struct Bucket {
   bool unsat = false;         // uint8 engine swept by a float-engine instance WITHOUT saturation, maxima clamped at 255
   bool sampled = false;       // running maximum folded every 4th step (sw_score_kernel MK = 4): sub-chunk values are lower bounds
                               // within 3 gaps of the truth; sub-chunks within that slack of the key are re-evaluated exactly
+  bool opt_margin = false;    // sw_long_kernel: optimistic warm-up margin, certified afterwards (long_score_launch)
   bool longp = false;         // lone long query on sw_long_kernel: the strips of a tile pipelined over the wavefronts of a workgroup
   int nstrips = 0;            // ... strips (= wavefronts) per tile
   bool satflag = false;       // float engine swept on float16 cells BEYOND their exact range (the sweep saturates at 2048):
@@ -622,6 +623,7 @@ inline uint32_t query_flag_cap(size_t nq) { return 64u + (uint32_t)(1024 / std::
 // Uploads what every score launch of a call shares and clears the keys.
 int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range> &ranges, const ScoreTable &t) {
   const size_t nq = q.nq, nr = ranges.size();
+  ctx->long_cert = -1.0f;                                            // (set by a sw_long_kernel launch with an optimistic margin)
   if (nr > 32768) return fail(ctx, MI355_SW_ENOTSUP, "more than 32768 ranges per launch");
   // the previous call's copies out of these host vectors have completed: every call ends synchronised
   std::vector<int64_t> &rl = ctx->h_ranges;
@@ -710,6 +712,22 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   a.range_hi = ctx->ranges.as<int64_t>() + nr;
   a.chunk_len = chunk; a.sub_len = sub_len;
   a.warm = (cpr == 1) ? 0 : b.warm;              // a single tile per range starts at the range's own border
+  // Optimistic warm-up margin.  The full margin m + ceil(smax m / g) makes EVERY cell exact; a cell of value v is already
+  // exact behind m + ceil((smax m - v) / g) + 2 columns (a path that reaches v within m diagonal steps affords that many gap
+  // columns).  The sweep therefore starts with the margin that is enough for maxima above 11/12 of the best possible score —
+  // what a read with a real hit has — and reports the value above which it was exact (long_cert); the callers check their
+  // maximum against it and sweep again with the margin that maximum needs when it falls short (host_pipeline.h).
+  ctx->long_cert = -1.0f;
+  if (b.opt_margin && a.warm > 0 && t.integral) {
+    const int64_t m = b.maxlen;
+    int64_t w1 = m + std::max<int64_t>(256, m / 8);
+    w1 = std::max(w1, ctx->long_margin);
+    w1 = (w1 + 63) / 64 * 64;
+    if (w1 < a.warm) {
+      a.warm = w1;
+      ctx->long_cert = (float)((double)t.smax * (double)m - (double)t.gap * (double)(w1 - m - 2));
+    }
+  }
   a.qbytes = q.bytes.as<uint8_t>() + q.off[qid];
   a.qlen = q.len[qid]; a.qid = qid; a.nq = (int)q.nq;
   a.htab = ctx->htab.as<uint16_t>();

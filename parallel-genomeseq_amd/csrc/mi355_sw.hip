@@ -341,7 +341,8 @@ int mi355_sw_score_ranges(mi355_sw_ctx *ctx, size_t nranges, const int64_t *left
 }
 
 int mi355_sw_best_range(mi355_sw_ctx *ctx, size_t nranges, const int64_t *lefts, const int64_t *rights,
-                        const mi355_sw_params *params, float *maxima, float *best, int64_t *best_range) {
+                        const mi355_sw_params *params, float known_best, float *maxima, float *best, int64_t *best_range,
+                        float *exact_above) {
   OptScope opt_scope_(ctx);
   int rc = check_params(ctx, params);
   if (rc) return rc;
@@ -359,7 +360,7 @@ int mi355_sw_best_range(mi355_sw_ctx *ctx, size_t nranges, const int64_t *lefts,
   }
   std::vector<float> own;
   if (!maxima) { own.resize(nranges * q.nq); maxima = own.data(); }
-  rc = range_maxima(ctx, ctx->ref, q, ranges, *params, maxima, true);
+  rc = range_maxima(ctx, ctx->ref, q, ranges, *params, maxima, true, known_best > 0.0f ? known_best : 0.0f, exact_above);
   if (rc) return rc;
   for (size_t k = 0; k < q.nq; ++k)                               // plocalaligner.cpp:106,122-129: starts at -1, strict '>'
     for (size_t r = 0; r < nranges; ++r)

@@ -146,6 +146,51 @@ def align_split_sharded(ranges, piece_maxima_fn, final_align_fn):
     return res, piece
 
 
+def align_split_sharded_certified(ranges, best_fn, final_align_fn, max_rounds=3):
+    """Reference sharding on winner-only sweeps with an optimistic warm-up margin (mi355_sw_best_range).
+    `best_fn(list_of_piece_indices, known_best) -> (best_score, position_in_that_list, exact_above)` sweeps this rank's pieces:
+    best_score is a lower bound of the rank's true best, exact when it exceeds exact_above (the same value on every rank,
+    -1 = everything exact).  The packed (best, ~piece) keys are merged by one 8-byte all-reduce(MAX); when the merged best does
+    not exceed the merged exact_above, every rank sweeps again with known_best = the merged best, whose margin makes the second
+    merge exact (plocalaligner.cpp:122-129: lowest piece wins ties).  Then as align_split_sharded: the owner finishes its
+    piece and the result is broadcast.  Returns (result dict, winning piece, rounds of sweeping)."""
+    rank, size = world()
+    mine = list(range(rank, len(ranges), size))
+    known = 0.0
+    piece = 0
+    rounds = 0
+    for rounds in range(1, max_rounds + 1):
+        key, above = 0, -1.0
+        if mine:
+            best, at, above = best_fn(mine, known)
+            key = pack_key(best, mine[int(at)]) if np.float32(best) >= 0 else BAD_KEY
+        if size > 1:
+            t = torch.tensor([key, int(np.float32(above).view(np.int32))], dtype=torch.int64, device=_dev())
+            # exact_above is -1 or a non-negative float: as a signed integer its bit pattern orders the same way
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            key = int(t[0].item())
+            above = float(np.int32(int(t[1].item())).view(np.float32))
+        if key == BAD_KEY:
+            raise ValueError("a rank reported a negative or NaN piece maximum (scores are maxima of cells >= 0)")
+        gbest, piece = unpack_key(key)
+        if gbest > above:
+            break
+        known = max(gbest, 1.0)
+    owner = piece % size
+    res = None
+    if rank == owner:
+        res = dict(final_align_fn(piece))
+        left = ranges[piece][0]
+        res["pos"] = res["pos"] + left
+        if res.get("end_y", 0) > 0:
+            res["end_y"] = res["end_y"] + left
+        res["piece"] = piece
+        res = {k: res.get(k, 0) for k in ("score", "pos", "end_x", "end_y", "cons_x", "cons_y", "piece")}
+    if size > 1:
+        res = _broadcast_result(res, owner)
+    return res, piece, rounds
+
+
 def _broadcast_result(res, src):
     """The owner's result to every rank as two tensor broadcasts (a fixed 6-word header, then the consensus bytes) —
     no pickling, and on RCCL the payload goes GPU to GPU."""

@@ -168,3 +168,49 @@ def test_partitions():
     assert pd.unpack_key(max(pd.pack_key(30, 5), pd.pack_key(30, 2), pd.pack_key(29, 0))) == (30.0, 2)
     assert pd.unpack_key(max(pd.pack_key(12.0, 1), pd.pack_key(12.5, 3))) == (12.5, 3)
     assert pd.pack_key(0.0, 0) > 0                                  # a piece whose maximum is 0 still beats "no piece"
+
+
+def _case_ref_sharding_certified(rank, size, pgs, ob):
+    """align_split_sharded_certified with best_fn callables that behave like mi355_sw_best_range under an optimistic margin:
+    a first sweep that UNDER-reports every maximum below a certification threshold (here: halves it), exact above it and in
+    the second sweep (known_best given).  Cases: the true best above the threshold (one round), below it (two rounds), and a
+    tie between pieces of different ranks."""
+    from parallel_genomeseq_amd import dist as pd
+    ref = pgs.synth.dna(6, 30000)
+    q = ref[7000:7100].tobytes()
+    refb = ref.tobytes()
+    refb = refb[:21000] + q + refb[21000 + len(q):]        # the same hit in a later piece (other rank): lowest piece wins
+    out = {}
+    for name, threshold in (("above", 250.0), ("below", 400.0)):
+        ranges = ob.make_string_range(6, len(q), len(refb), 2.0)
+        calls = []
+
+        def best_fn(pieces, known_best):
+            calls.append(known_best)
+            true = [ob.score_only(q, refb[ranges[p][0]:ranges[p][1]], ob.F32) for p in pieces]
+            if known_best > 0:                              # second sweep: exact for everything >= known_best
+                seen, above = true, -1.0
+            else:
+                seen = [t if t > threshold else float(int(t) // 2) for t in true]
+                above = threshold
+            at = int(np.argmax(seen))
+            return seen[at], at, above
+
+        def final_fn(piece):
+            l, r = ranges[piece]
+            return ob.align(q, refb[l:r], ob.F32)
+
+        res, piece, rounds = pd.align_split_sharded_certified(ranges, best_fn, final_fn)
+        out[name] = (res, piece, rounds, list(calls), ob.align_split(q, refb, 6, 2.0, ob.F32, ob.F32))
+    return out
+
+
+def test_ref_sharding_certified_gloo():
+    out = _run("_case_ref_sharding_certified")
+    for rank in (0, 1):
+        for name, (res, piece, rounds, calls, exp) in out[rank].items():
+            assert piece == exp["piece"], (rank, name)
+            for k in ("score", "pos", "cons_x", "cons_y"):
+                assert res[k] == exp[k], (rank, name, k)
+            assert rounds == (1 if name == "above" else 2), (rank, name, rounds, calls)
+            assert calls[0] == 0.0 and (name == "above" or calls[1] > 0)

@@ -68,7 +68,7 @@ def fuzz_cases(pgs, oracle):
 # every switch that selects another kernel instance / pipeline for the same answer
 SWITCHES = ["no_f16", "no_unsat", "no_sample", "no_satflag", "no_solo", "no_wave", "no_comb", "no_twin", "no_wide",
             "no_strip", "no_quant", "no_f16_wide", "no_devlist", "no_strip_groups", "u8_long_twin", "long_twin", "no_long",
-            "no_requery", "slot=16", "strip_r=24", "few_r=5", "long_pipes=2", "no_long_p32", "long_groups=2", "force_f32"]
+            "no_requery", "slot=16", "strip_r=24", "few_r=5", "long_pipes=2", "no_long_p32", "long_groups=2", "force_f32", "no_opt_margin"]
 
 
 def test_option_names_cover_the_switch_list(pgs):
@@ -390,3 +390,60 @@ def test_best_range_winner_only(pgs, oracle):
             assert mx[:, j].tolist() == true and best[j] == max(true) and which[j] == true.index(max(true))
     finally:
         c.close()
+
+
+def test_optimistic_margin_is_certified_or_swept_again(pgs, oracle):
+    """sw_long_kernel's optimistic warm-up margin (exact for maxima above 11/12 of the best possible score): a query with a
+    strong hit is certified by one sweep; a diverged copy (25 % substitutions: its score lies below what the margin certifies)
+    and a hit that crosses tile borders make the library sweep again with the margin that score needs — results bit-exact
+    either way, for the whole-reference call, for best_range on its own, and through the multi-rank protocol (exact_above /
+    known_best) emulated with two contexts holding the even and the odd pieces."""
+    ref = pgs.synth.dna(7501, 400_000)
+    m = 4000
+    rng = np.random.default_rng(7502)
+    strong = bytearray(ref[150_000:150_000 + m].tobytes())
+    for i in rng.choice(m, m // 100, replace=False):
+        strong[i] = b"ACGT"[int(rng.integers(0, 4))]
+    weak = bytearray(ref[300_000:300_000 + m].tobytes())
+    for i in rng.choice(m, m // 4, replace=False):
+        weak[i] = b"ACGT"[int(rng.integers(0, 4))]
+    refb = ref.tobytes()
+    c = pgs.Context(0)
+    c2 = pgs.Context(0)
+    try:
+        for name, q in (("strong", bytes(strong)), ("weak", bytes(weak))):
+            exp = oracle.align(q, refb, 0)
+            got = c.align(q, refb, 0)
+            _cmp(got, exp, "optimistic margin, whole reference, %s hit" % name)
+            again = c.last_counters()["whole_batch_again"]
+            assert again == (0 if name == "strong" else 1), (name, again, exp["score"])
+            # reference sharding: ranges and the oracle's per-piece answers
+            ranges = pgs.capi.make_string_range(6, m, len(refb), 2.0)
+            true = [oracle.score_only(q, refb[lo:hi], 0) for lo, hi in ranges]
+            c.set_reference(refb); c.batch_upload([q])
+            best, which, mx = c.best_range(ranges, semantics=0)
+            assert best[0] == max(true) and which[0] == true.index(max(true)), (name, best, which, true)
+            _cmp(c.align_scored_range(int(which[0]), semantics=0), oracle.align(q, refb[ranges[which[0]][0]:ranges[which[0]][1]], 0), "finish %s" % name)
+            # two "ranks": even / odd pieces, merged as dist.align_split_sharded_certified does
+            c2.set_reference(refb); c2.batch_upload([q])
+            shares = [(c, list(range(0, 6, 2))), (c2, list(range(1, 6, 2)))]
+            known, rounds = 0.0, 0
+            for rounds in (1, 2, 3):
+                keys, above = [], -1.0
+                for cc, pieces in shares:
+                    b, w, _, a = cc.best_range([ranges[p] for p in pieces], semantics=0, known_best=known, want_exact_above=True)
+                    keys.append((float(b[0]), -pieces[int(w[0])]))
+                    above = max(above, a)
+                gbest, negpiece = max(keys)
+                if gbest > above:
+                    break
+                known = max(gbest, 1.0)
+            assert gbest == max(true) and -negpiece == true.index(max(true)), (name, gbest, negpiece, true)
+            assert rounds == (1 if name == "strong" else 2), (name, rounds)
+        # the option that switches the optimistic margin off: one sweep with the full margin
+        c.set_option("no_opt_margin")
+        _cmp(c.align(bytes(weak), refb, 0), oracle.align(bytes(weak), refb, 0), "full margin")
+        assert c.last_counters()["whole_batch_again"] == 0
+    finally:
+        c.close()
+        c2.close()
