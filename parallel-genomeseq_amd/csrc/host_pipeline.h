@@ -509,7 +509,8 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       bool any_sat = false;
       for (Bucket &b : buckets) {
         b.fast = bucket_fast_ok(ref, table, b, n, p); any_fast |= b.fast; any_sat |= b.fast && (b.satflag || b.sampled);
-        b.opt_margin = b.longp && !opt().no_opt_margin;
+        // (not for the uint8 engine's unsaturated sweep: there every cell that reaches 255 must be exact, wherever it lies)
+        b.opt_margin = b.longp && !b.unsat && !opt().no_opt_margin;
       }
       if (!any_fast) break;
       const std::vector<Range> ranges{rg};
@@ -782,7 +783,7 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     for (auto &r : ranges) b.fast = b.fast && bucket_fast_ok(ref, table, b, r.hi - r.lo, p);
     if (!b.longp) b.sampled = false;                               // only sw_long_kernel lays out one value row per range
     sampled |= b.fast && b.sampled;
-    b.opt_margin = winner_only && b.longp && nq == 1 && !opt().no_opt_margin;
+    b.opt_margin = winner_only && b.longp && !b.unsat && nq == 1 && !opt().no_opt_margin;
   }
   ctx->long_margin = 0;
   if (winner_only && nq == 1 && known_best > 0.0f && table.integral)

@@ -78,17 +78,16 @@ template <int R, bool U8, int MODE, bool LUT = false>
 __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const StripProblem *probs, const WaveScoring sc,
                                                                        const float *gtab = nullptr, int ncodes = 0, int groups = 1) {
   extern __shared__ float tab[];
-  __shared__ float ring[kStripMaxWaves + 1][kStripRing];            // [w] = output of wavefront w; [kStripMaxWaves] = round input of wavefront 0
+  __shared__ float ring[kStripMaxWaves][kStripRing];                // [w] = bottom row of wavefront w's strip (the strip below reads it)
   __shared__ long long produced[kStripMaxWaves], consumed[kStripMaxWaves + 1];
   __shared__ int dead;
-  __shared__ __attribute__((aligned(16))) uint8_t win[kStripMaxWaves][128];
   __shared__ unsigned long long wkey[kStripMaxWaves];
   __shared__ long long wi[kStripMaxWaves], wj[kStripMaxWaves];
   const bool multi = groups > 1;
   const StripProblem P = probs[multi ? blockIdx.x / groups : blockIdx.x];
   const int grp = multi ? blockIdx.x % groups : 0;
   const int tid = threadIdx.x;
-  const int w = tid >> 6, l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;   // (w in an SGPR: what derives from it branches uniformly)
   if (tid < kStripMaxWaves) produced[tid] = 0;
   if (tid <= kStripMaxWaves) consumed[tid] = 0;
   if (tid == 0) dead = 0;
@@ -137,12 +136,18 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
     }
   };
 
-  uint8_t *buf = win[w < kStripMaxWaves ? w : 0];
-  const uint8_t *buf_lane = buf + 64 - l;                // + k = byte of stream position seg*64 + k - l
+  // stream byte of position seg*64 + l, flagged where the stream has ended (LUT: the padding code; else bit 8, which no
+  // query byte carries: positions outside the stream compare unequal to everything)
+  const uint32_t off_stream = LUT ? (uint32_t)(ncodes - 1) : 0x100u;
   auto stage_load = [&](int seg) -> uint32_t {
     const int t = seg * 64 + l;
-    return (t < nb) ? (uint32_t)P.b[t] : (LUT ? (uint32_t)(ncodes - 1) : 0u);
+    return (t < nb) ? (uint32_t)P.b[t] : off_stream;
   };
+  // one-lane shifts across the wavefront (as sw_long_kernel.h): shr1 = lanes take the lane above, lane 0 keeps `old`;
+  // rot1 = lanes take the lane below; shl1_insert = lanes take the lane below, lane 63 takes `ins`
+  auto shr1 = [](uint32_t old, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false); };
+  auto rot1 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true); };
+  auto shl1_insert = [](uint32_t ins, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)ins, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false); };
 
   for (int round = 0; round < rounds && ok && w < nw; ++round) {
     const int s = s_first + round * nw + w;              // this wavefront's strip in this round
@@ -151,8 +156,7 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
     const bool has_in = s > 0, has_out = s + 1 < nstrips;
     const bool in_global = has_in && w == 0;             // from the last wavefront of the previous round
     const bool out_global = has_out && w == nw - 1;      // to wavefront 0 of the next round
-    const float *rin = ring[in_global ? kStripMaxWaves : (w > 0 ? w - 1 : 0)];
-    float *rstage = ring[kStripMaxWaves];
+    const float *rin = ring[w > 0 ? w - 1 : 0];
     float *rout = ring[w];
     const float *gin = in_global ? P.gbound + (size_t)(multi ? grp - 1 : ((round + 1) & 1)) * (size_t)P.gstride : nullptr;
     float *gout = out_global ? P.gbound + (size_t)(multi ? grp : (round & 1)) * (size_t)P.gstride : nullptr;
@@ -164,11 +168,14 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
       if (LUT) ca[r] = ((ai < na) ? (uint32_t)P.a[ai] : 256u) * (uint32_t)ncodes;   // row offset into tab
       else ca[r] = (ai < na) ? (uint32_t)P.a[ai] : 0xFFFFu;                          // padding rows never match
     }
-    // stream window of this wavefront: 64 B of history, then the current 64-column segment
-    uint32_t nextc = stage_load(0);
-    buf[l] = LUT ? (uint8_t)(ncodes - 1) : 0;
-    buf[64 + l] = (uint8_t)nextc;
-    nextc = stage_load(1);
+    // The inner loop touches no LDS (LUT: the score table only).  What a step needs from outside the lane travels through
+    // registers: `code` moves one lane up per step and lane 0 takes the next byte of the segment from lane 0 of cseg, which
+    // rotates one lane down per step; bseg holds the segment's 64 boundary values (one ring / global read per lane and
+    // SEGMENT) and rotates the same way, lane 0 of it being the `old` operand of the H shift; oseg collects lane 63's
+    // bottom-row value of every step: one ring / global write per segment.  (With one wavefront per SIMD — a few long
+    // problems dealt to several workgroups — two dependent LDS round trips per step were most of the step.)
+    uint32_t code = off_stream;
+    uint32_t curc = stage_load(0), nextc = stage_load(1);
 
     float H[R];
 #pragma unroll
@@ -182,7 +189,6 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
         if (in_global) {
           if (multi) wait_global(P.gcount + (grp - 1), need);
           else wait_for(&produced[nw - 1], base - NBP + need);
-          if (ok) { const int t = seg * 64 + l; rstage[t & (kStripRing - 1)] = t < nb ? __hip_atomic_load(gin + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f; }
         } else {
           wait_for(&produced[w - 1], base + need);
         }
@@ -190,15 +196,29 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
       // ring space: this segment stores positions <= seg*64, over the slots of positions <= seg*64 - kStripRing
       if (has_out && !out_global) wait_for(&consumed[w + 1], base + seg * 64 - kStripRing + 64);
       if (!ok) break;
+      uint32_t bseg = 0u;
+      {
+        const int tl = seg * 64 + l;
+        if (has_in && tl < nb)
+          bseg = __float_as_uint(in_global ? __hip_atomic_load(gin + tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : rin[tl & (kStripRing - 1)]);
+      }
+      uint32_t cseg = curc;
+      curc = nextc;
+      nextc = stage_load(seg + 2);
+      uint32_t oseg = 0u;
 #pragma unroll 2
       for (int k = 0; k < 64; ++k) {
         const int t0 = seg * 64 + k;                                     // lane 0's stream position
         const int t = t0 - l;
-        const uint32_t cb = LUT ? ((uint32_t)t >= (uint32_t)nb ? (uint32_t)(ncodes - 1) : (uint32_t)buf_lane[k])
-                                : ((uint32_t)buf_lane[k] | ((uint32_t)t >= (uint32_t)nb ? 0x100u : 0u));
-        const float bnd = has_in ? rin[t0 & (kStripRing - 1)] : 0.0f;    // H(first row of the strip - 1, column t0)
-        const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(bnd), (int)__float_as_uint(H[R - 1]),
-                                                                  0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+        {
+          const uint32_t head = cseg;
+          cseg = rot1(cseg);
+          code = shr1(head, code);
+        }
+        const uint32_t cb = code;
+        uint32_t up;                                                     // H(first row of the strip - 1, this column)
+        if (has_in) { const uint32_t head = bseg; bseg = rot1(bseg); up = shr1(head, __float_as_uint(H[R - 1])); }
+        else up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(H[R - 1]), 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
         float diag = __uint_as_float(up_prev);
         float north = __uint_as_float(up);
         up_prev = up;
@@ -266,7 +286,7 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
             }
           }
         }
-        if (has_out && l == 63 && t >= 0) rout[t & (kStripRing - 1)] = H[R - 1];
+        if (has_out) oseg = shl1_insert(__float_as_uint(H[R - 1]), oseg);    // lane 63 inserts, the others pass down
         if (MODE == kStripDirs) {
           if (t >= 0 && t < nb) {
             uint32_t *dst = P.dirs + ((size_t)t * LT + (size_t)(s * 64 + l)) * W;
@@ -275,10 +295,17 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
           }
         }
       }
-      // lane 63 has stored positions <= seg*64; this wavefront has read positions <= seg*64 + 63
-      if (out_global) {
+      // lane j of oseg holds lane 63's value of step j = stream position seg*64 + j - 63: positions <= seg*64 are complete;
+      // this wavefront has read positions <= seg*64 + 63
+      if (has_out) {
         const int t = seg * 64 - 63 + l;
-        if (t >= 0 && t < nb) __hip_atomic_store(gout + t, rout[t & (kStripRing - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (out_global) {
+          if (t >= 0 && t < nb) __hip_atomic_store(gout + t, __uint_as_float(oseg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        } else {
+          if (t >= 0) rout[t & (kStripRing - 1)] = __uint_as_float(oseg);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        }
       }
       if (multi && out_global && l == 0)                               // (the release covers this wavefront's stores above)
         __hip_atomic_store(P.gcount + grp, (long long)seg * 64 + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -286,10 +313,6 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
         if (has_out && !(P.fault && w == 0)) __hip_atomic_store(&produced[w], base + seg * 64 + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(&consumed[w], base + (seg + 1) * 64, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      const uint8_t hist = buf[64 + l];
-      buf[l] = hist;
-      buf[64 + l] = (uint8_t)nextc;
-      nextc = stage_load(seg + 2);
     }
     if (multi && out_global && l == 0 && ok) __hip_atomic_store(P.gcount + grp, NBP, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     if (l == 0 && ok && !(P.fault && w == 0)) {

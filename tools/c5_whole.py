@@ -9,6 +9,9 @@ q, off = bench.config5_inputs(pgs, n, m)
 ref = pgs.synth.dna(6, n)
 ctx = pgs.Context(0)
 ctx.set_reference(ref); ctx.batch_upload([q])
+for kv in sys.argv[1:]:
+    k, _, v = kv.partition("=")
+    ctx.set_option(k, v or True)
 for _ in range(2):
     t0 = time.perf_counter(); r = ctx.batch_run(semantics=0)[0]; dt = time.perf_counter() - t0
     tm = ctx.last_timings()
