@@ -837,7 +837,7 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
       const uint32_t qcap = query_flag_cap(nq);
       float top = 0.0f;
       for (size_t r = 0; r < nr; ++r) top = std::max(top, maxima[r]);
-      const float slack = 3.0f * table.gapf;
+      const float slack = (float)(kLongMK - 1) * table.gapf;
       bool ok = nflag <= ctx->flag_cap && nflag <= qcap;            // (the filter stops appending beyond the cap)
       std::vector<std::vector<std::pair<uint32_t, uint32_t>>> per_range(nr);
       if (ok && nflag) {

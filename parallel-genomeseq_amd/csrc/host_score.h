@@ -154,6 +154,8 @@ bool comb_ok(int ncodes, int R) {
 // the rings and the sub-chunk maxima fit the CU's LDS with at most sixteen wavefronts — the shape with the fewest padded rows.
 constexpr size_t kLongLdsMax = 156 * 1024;
 constexpr int kLongSubsMax = 1024;            // sub-chunk maxima a tile keeps in LDS
+constexpr int kLongMK = 8;                    // sw_long_kernel folds the running maximum every kLongMK-th step when it samples: sub-chunk values
+                                              // are lower bounds within (kLongMK - 1) gaps (a cell holding M passes M - k g along its row)
 bool long_shape(int ncodes, int len, int &R, int &nstrips) {
   int64_t best = -1;
   const long forced = opt().long_r;                                       // tuning aid
@@ -340,7 +342,7 @@ double valu_ops_per_cell(const Bucket &b) {
   double per_step;
   int cells_per_row = 2;
   switch (b.sem) {
-    case kSemF32:   per_step = 3.0 * R + (b.sampled ? 0.25 : 1.0) * ((R + 1) / 2) + 1 + over; cells_per_row = 1; break;   // add clamp, max3, sub; max3 per two cells
+    case kSemF32:   per_step = 3.0 * R + (b.sampled ? (b.longp ? 1.0 / kLongMK : 0.25) : 1.0) * ((R + 1) / 2) + 1 + over; cells_per_row = 1; break;   // add clamp, max3, sub; max3 per two cells
     case kSemF32U8: per_step = 6.0 * R + (R + 1) / 2 + over; cells_per_row = 1; break;          // add, min, max, sub, max, max
     case kSemF16:   per_step = 3.0 * R + (b.sampled ? 0.25 : 1.0) * ((R + 1) / 2) + 1 + over; break;
     case kSemU8H:   { const int odd = R / 2; per_step = 4.0 * R + odd / 2 + odd % 2 + R % 2 + over; break; }
@@ -774,8 +776,8 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   };
 #define LONG_CASE(r) \
   if (b.R == r) { \
-    if (p32) { if (b.sampled) launch(sw_long_kernel<r, 4, true>); else launch(sw_long_kernel<r, 1, true>); } \
-    else { if (b.sampled) launch(sw_long_kernel<r, 4, false>); else launch(sw_long_kernel<r, 1, false>); } \
+    if (p32) { if (b.sampled) launch(sw_long_kernel<r, kLongMK, true>); else launch(sw_long_kernel<r, 1, true>); } \
+    else { if (b.sampled) launch(sw_long_kernel<r, kLongMK, false>); else launch(sw_long_kernel<r, 1, false>); } \
   } else
   LONG_CASE(20) LONG_CASE(24) LONG_CASE(32)
     return fail(ctx, MI355_SW_ENOTSUP, "no sw_long_kernel instance for this R");
@@ -788,7 +790,7 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     for (size_t r = 0; r < nr; ++r)
       hipLaunchKernelGGL(sw_sample_filter<true>, fgrid, dim3(256), 0, ctx->stream, (const void *)(a.submax_out + r * (size_t)nsub), nsub, nsub,
                          q.sel.as<int32_t>(), b.first, 1, (const unsigned long long *)(a.keys + r * (size_t)q.nq),
-                         std::ldexp(3.0f * t.gapf, -ctx->fshift),
+                         std::ldexp((float)(kLongMK - 1) * t.gapf, -ctx->fshift),
                          ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), ctx->flag_cap,
                          ctx->qcnt.as<unsigned int>(), query_flag_cap(q.nq), (uint32_t)(r * (size_t)nsub));
     HIPCHK(ctx, hipGetLastError());
@@ -807,7 +809,7 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     ki.valu_ops_per_cell = valu_ops_per_cell(b);
     std::snprintf(ki.name, sizeof ki.name, "sw_long_kernel<R=%d, f32 cells, %s profile; %d strips pipelined over %d workgroup(s), %d tile(s) per workgroup>%s%s",
                   b.R, p32 ? "f32" : "f16", b.nstrips, groups, pipes, b.unsat ? " uint8 engine swept unsaturated, maxima clamped at 255" : "",
-                  b.sampled ? "; maximum folded every 4th step (candidates re-evaluated)" : "");
+                  b.sampled ? "; maximum folded every 8th step (candidates re-evaluated)" : "");
   }
   return 0;
 }

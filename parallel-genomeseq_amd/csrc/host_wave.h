@@ -136,6 +136,10 @@ int strip_R_few(int na, size_t njobs, bool track) {
   if (njobs > kFewJobs || na <= 512 || na > 64 * kStripMaxWaves * 10) return strip_R(na);
   const long forced = opt().few_r;   // tuning aid
   if (forced == 3 || forced == 5 || forced == 8 || forced == 10 || forced == 16) return (int)forced;
+  // (the strips of a few long problems are dealt to several workgroups, one wavefront per SIMD — run_strip — so their number
+  // is no limit; a lone wavefront's step is a dependent chain R rows long, and at three rows it is shortest: config 5's locate
+  // 5.5 -> 4.4 ms, traceback 9.8 -> 8.3 ms)
+  if (!opt().no_strip_groups && njobs <= (track ? (size_t)32 : (size_t)8)) return 3;      // (run_strip's condition for several workgroups)
   static const int rs[] = {3, 5, 8, 10, 16};
   if (!track) return na <= 2560 ? 3 : 5;
   for (int r : rs) if (strip_count_of(na, r) <= kStripMaxWaves) return r;

@@ -97,7 +97,7 @@ __host__ __device__ constexpr int long_max_waves(int R) { return R >= 32 ? 12 : 
 template <int R, int MK, bool P32 = false>
 __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const LongArgs a) {
   static_assert(R % 4 == 0, "two float16 profile entries per dword, whole 8-byte reads");
-  static_assert(MK == 1 || MK == 4, "running maximum every step or every 4th");
+  static_assert(MK == 1 || MK == 4 || MK == 8, "running maximum every step, every 4th or every 8th");
   constexpr int LSH = P32 ? lane_stride(R) : long_lane_stride(R);   // dwords between the profile rows of adjacent lanes
   constexpr bool WIDE = P32 || long_wide(R);   // ds_read_b128 (else ds_read_b64)
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
       curc = nextc;
       nextc = stage_load(seg + 2);
       uint32_t oseg = 0u;
-#pragma unroll 4
+#pragma unroll(MK > 4 ? MK : 4)
       for (int k = 0; k < 64; ++k) {
         {
           const uint32_t head = cseg;                                      // lane 0: this step's code
