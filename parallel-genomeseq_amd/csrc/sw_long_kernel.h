@@ -100,6 +100,7 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
   static_assert(MK == 1 || MK == 4 || MK == 8, "running maximum every step, every 4th or every 8th");
   constexpr int LSH = P32 ? lane_stride(R) : long_lane_stride(R);   // dwords between the profile rows of adjacent lanes
   constexpr bool WIDE = P32 || long_wide(R);   // ds_read_b128 (else ds_read_b64)
+  constexpr int UNR = MK > 4 ? MK : 4;         // steps per unrolled group: the fold steps are then compile-time
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   __shared__ long long produced[kLongMaxWaves], consumed[kLongMaxWaves + 1];
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
       curc = nextc;
       nextc = stage_load(seg + 2);
       uint32_t oseg = 0u;
-#pragma unroll(MK > 4 ? MK : 4)
+#pragma unroll UNR
       for (int k = 0; k < 64; ++k) {
         {
           const uint32_t head = cseg;                                      // lane 0: this step's code
