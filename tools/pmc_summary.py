@@ -50,6 +50,7 @@ if "SQ_WAVE_CYCLES" in per:
         if c in per:
             d[name] = per[c] / per["SQ_WAVE_CYCLES"]
 if "SQ_WAVES" in per and "SQ_WAVE_CYCLES" in per and "GRBM_GUI_ACTIVE" in per:
-    d["mean_resident_waves_per_simd"] = per["SQ_WAVE_CYCLES"] / (per["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0) / 4.0 * 4.0
+    # SQ_WAVE_CYCLES counts quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs
+    d["mean_resident_waves_per_simd"] = per["SQ_WAVE_CYCLES"] * 4.0 / (per["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
 out["derived"] = d
 print(json.dumps(out, indent=1))
