@@ -500,6 +500,7 @@ def rank_share_config5(pgs, ctx, q, ref_len, qlen):
             base = rec
         rec["predicted_speedup"] = base["share_ms"] / rec["share_ms"]
         rec["predicted_speedup_score_pass"] = base["score_ms"] / rec["score_ms"]
+        rec["predicted_speedup_score_kernel"] = base["score_kernel_ms"] / rec["score_kernel_ms"]
         out["worlds"][str(world)] = rec
     ctx.best_range(ranges[:1], semantics=pgs.F32)
     out["kernel"] = ctx.last_kernel()["name"]
