@@ -70,10 +70,14 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   sc.u8M = sc.u8X = sc.u8G = 0.0f;
   const unsigned blocks = (unsigned)((n + 15) / 16);
   const WaveProblem *dp = ctx->wprobs.as<WaveProblem>();
+  // lanes = columns of the shared second sequence: the profile kernel (three-op cell, first maximum per lane)
+  int prof_rc = orient == 1 ? launch_wave_prof(ctx, ref, p, R, (int)nref, true, want_trace, blocks, dp, (int)n) : 1;
+  if (prof_rc < 0) return prof_rc;
 #define BATCH_WAVE(r)                                                                                                   \
   if (orient == 0) launch_wave_batch<r, 0>(want_trace, blocks, ctx->stream, dp, (int)n, sc);                            \
   else launch_wave_batch<r, 1>(want_trace, blocks, ctx->stream, dp, (int)n, sc);
-  if (R == 10) { BATCH_WAVE(10) } else if (R == 20) { BATCH_WAVE(20) } else { BATCH_WAVE(32) }
+  if (prof_rc == 0) { }
+  else if (R == 10) { BATCH_WAVE(10) } else if (R == 20) { BATCH_WAVE(20) } else { BATCH_WAVE(32) }
 #undef BATCH_WAVE
   HIPCHK(ctx, hipGetLastError());
 

@@ -52,6 +52,47 @@ void launch_wave_R(int orient, bool u8, bool track, bool dirs, unsigned blocks, 
   else { if (u8) launch_wave_flags<R, 1, true>(track, dirs, blocks, st, pr, n, sc); else launch_wave_flags<R, 1, false>(track, dirs, blocks, st, pr, n, sc); }
 }
 
+// sw_wave_prof_kernel for a launch whose lanes hold columns of the reference range (ORIENT 1), float engine, identity scoring:
+// the query profile over the shared lane side + the three-op cell (sw_wave_kernel.h).  Returns 1 when it does not apply
+// (the caller launches sw_wave_kernel), 0 when launched, < 0 on error.
+int launch_wave_prof(mi355_sw_ctx *ctx, const RefData &ref, const mi355_sw_params &p, int R, int na, bool track, bool dirs,
+                     unsigned blocks, const WaveProblem *dp, int n) {
+  if (opt().no_wave_prof || p.semantics != MI355_SW_F32 || !wave_scoring_ok(p) || ref.ncodes < 2 || ref.ncodes > 256) return 1;
+  const size_t lds = (size_t)ref.ncodes * 16 * lane_stride(R) * 4;
+  if (lds > 96 * 1024) return 1;                                   // (alphabets of > 120 letters at R = 10)
+  if (ctx->wlut_ref != (const void *)&ref || ctx->wlut_version != ref.version) {
+    ctx->h_wlut.assign(512, 0);
+    for (int b = 0; b < 256; ++b) ctx->h_wlut[b] = (uint8_t)(ref.code_of[b] >= 0 ? ref.code_of[b] : ref.ncodes - 1);
+    for (int c = 0; c + 1 < ref.ncodes; ++c) ctx->h_wlut[256 + c] = ref.byte_of[c];
+    if (ctx->wlut.ensure(512)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(wave tables) failed");
+    HIPCHK(ctx, hipMemcpyAsync(ctx->wlut.p, ctx->h_wlut.data(), 512, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                // (the staging vector may change with the next reference)
+    ctx->wlut_ref = (const void *)&ref; ctx->wlut_version = ref.version;
+  }
+  WaveProfArgs sa;
+  sa.lut = ctx->wlut.as<uint8_t>();
+  sa.byte_of = ctx->wlut.as<uint8_t>() + 256;
+  sa.ncodes = ref.ncodes;
+  // cells hold H * 2^-k, 2^k above every value of the launch (at most match * min(|x|, |y|), the lane side is <= 512)
+  const int k = std::max(1, std::min(100, std::ilogb((double)p.match * ((double)na + 1.0) + 1.0) + 2));
+  sa.match_s = std::ldexp(p.match, -k); sa.mismatch_s = std::ldexp(p.mismatch, -k); sa.gap_s = std::ldexp(p.gap, -k);
+  sa.unscale = std::ldexp(1.0f, k);
+#define WAVE_PROF(r)                                                                                                                  \
+  {                                                                                                                                   \
+    if (lds > 48 * 1024) {                                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_wave_prof_kernel<r, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_wave_prof_kernel<r, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_wave_prof_kernel<r, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    }                                                                                                                                 \
+    if (track && dirs) hipLaunchKernelGGL((sw_wave_prof_kernel<r, true, true>), dim3(blocks), dim3(256), lds, ctx->stream, dp, n, sa);  \
+    else if (track) hipLaunchKernelGGL((sw_wave_prof_kernel<r, true, false>), dim3(blocks), dim3(256), lds, ctx->stream, dp, n, sa);   \
+    else hipLaunchKernelGGL((sw_wave_prof_kernel<r, false, true>), dim3(blocks), dim3(256), lds, ctx->stream, dp, n, sa);              \
+  }
+  if (R == 10) WAVE_PROF(10) else if (R == 20) WAVE_PROF(20) else WAVE_PROF(32)
+#undef WAVE_PROF
+  return 0;
+}
+
 // One launch: all jobs share orientation and flags; lanes side <= 512.
 int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg, const mi355_sw_params &p,
              std::vector<WaveJob> &jobs) {
@@ -99,7 +140,14 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
   const bool u8 = p.semantics == MI355_SW_U8SAT;
   const unsigned blocks = (unsigned)((n + 15) / 16);
   const WaveProblem *dp = ctx->wprobs.as<WaveProblem>();
-  if (keyed) {
+  int prof_rc = 1;
+  if (!keyed && orient == 1 && !u8) {
+    prof_rc = launch_wave_prof(ctx, ref, p, R, (int)nref, track, dirs, blocks, dp, (int)n);
+    if (prof_rc < 0) return prof_rc;
+  }
+  if (prof_rc == 0) {
+  }
+  else if (keyed) {
     if (R == 10) launch_wave_keyed<10>(u8, blocks, ctx->stream, dp, (int)n, sc);
     else if (R == 20) launch_wave_keyed<20>(u8, blocks, ctx->stream, dp, (int)n, sc);
     else launch_wave_keyed<32>(u8, blocks, ctx->stream, dp, (int)n, sc);

@@ -83,7 +83,7 @@ int mi355_sw_create(mi355_sw_ctx **out, int device) {
 void mi355_sw_destroy(mi355_sw_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  DevBuf *bufs[] = {&c->qcnt, &c->sel2, &c->gcnt, &c->ref.bytes, &c->ref.codes, &c->batch.bytes, &c->batch.lens, &c->keys, &c->ranges, &c->stab,
+  DevBuf *bufs[] = {&c->qcnt, &c->sel2, &c->gcnt, &c->wlut, &c->ref.bytes, &c->ref.codes, &c->batch.bytes, &c->batch.lens, &c->keys, &c->ranges, &c->stab,
                     &c->batch.offs, &c->batch.sel, &c->ftab, &c->ftab_s, &c->htab, &c->htab8, &c->soloblk, &c->flags, &c->submax, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow, &c->wprobs, &c->scan, &c->batch.cum};
   for (DevBuf *b : bufs) b->release();
   c->adhoc.release(); c->one.release();

@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "sw_exact_kernel.h"   // kDir*
+#include "sw_score_kernel.h"   // lane_stride, u32x4, kPadScoreF
 
 namespace mi355sw {
 
@@ -215,6 +216,191 @@ __global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, 
       for (int r = 0; r < R; ++r)                                  // ascending column: strict '>' keeps the first
         if (tbr[r] > bv) { bv = tbr[r]; bj = (long long)l * R + r + 1; bi = P.b_offset + ttr[r] + 1; }
     }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+      const float ov = __shfl_xor(bv, off, 16);
+      const long long oi = __shfl_xor(bi, off, 16);
+      const long long oj = __shfl_xor(bj, off, 16);
+      if (ov > bv || (ov == bv && ov > 0.0f && (oj < bj || (oj == bj && oi < bi)))) { bv = ov; bi = oi; bj = oj; }
+    }
+    if (l == 0 && active) {
+      *P.best = bv;
+      P.cell[0] = bv > 0.0f ? bi : 0;
+      P.cell[1] = bv > 0.0f ? bj : 0;
+    }
+  }
+}
+
+// sw_wave_prof_kernel — ORIENT 1 of sw_wave_kernel (lanes hold columns of the SHARED second sequence y, the stream runs
+// over the rows of a database sequence x: the many-small-alignments batch, src/mpi_sw_solve_uniprot.cpp:95-138) on the cell of
+// the score kernels instead of compare-and-select arithmetic.  sw_wave_kernel spends ~10 VALU instructions per cell there
+// with the first-maximum tracking (compare, select, add, max, sub, max, max; compare + two selects per cell for the
+// tracking) and is VALU-issue-bound (profiles/r03_pmc_config4_*.json); here
+//   * every problem of a workgroup has the same y, so ONE query profile serves all sixteen: prof[code][lane][r] = score of
+//     y's column lane*R + r against the letter `code` (y's distinct letters + "other"), float32 scaled by 2^-k, in LDS;
+//     the stream's bytes are translated to codes as they are staged into the slot's window;
+//   * cell: x = clamp(NW + s) (v_add_f32 clamp: the [0, 1] clamp is the zero floor), H = max3(x, W - g, N - g), keep H - g:
+//     three instructions, two of them at the double issue rate;
+//   * TRACK: the first maximum in storage order (column of y, then row of x) is kept per LANE — (value, column within the
+//     lane, row) under (value desc, column asc, row asc) — behind one max3 per two cells and a compare per step; the
+//     per-cell scan runs only on the steps where a lane's step maximum reaches its best so far.
+// Values, decisions and the winner are those of sw_wave_kernel<R, 1, false, TRACK, DIRS> (a power-of-two scaling commutes
+// with every add, subtract, maximum and comparison).
+struct WaveProfArgs {
+  const uint8_t *lut;        // [256] byte -> code; ncodes - 1 = "other" (a byte that y does not contain)
+  const uint8_t *byte_of;    // [ncodes - 1] code -> byte
+  int32_t ncodes;
+  float match_s, mismatch_s, gap_s;   // scores * 2^-k
+  float unscale;             // 2^k
+};
+
+template <int R, bool TRACK, bool DIRS>
+__global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *probs, int nprob, const WaveProfArgs sa) {
+  constexpr int LS = lane_stride(R);                               // dwords between the profile rows of adjacent lanes
+  constexpr int NQ4 = (R + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) uint32_t wsmem[];
+  __shared__ __attribute__((aligned(16))) uint8_t win[16 * kWaveBuf];
+  __shared__ uint8_t lut_s[256];
+  float *prof = reinterpret_cast<float *>(wsmem);                  // [ncodes][16][LS]
+  const int tid = threadIdx.x;
+  const int l = tid & 15;
+  const int slot = tid >> 4;
+  const int pid = blockIdx.x * 16 + slot;
+  const bool active = pid < nprob;
+  WaveProblem P;
+  if (active) P = probs[pid];
+  else { P.a = nullptr; P.b = nullptr; P.na = 0; P.nb = 0; P.b_offset = 0; P.dirs = nullptr; P.best = nullptr; P.cell = nullptr;
+         P.target = -1.0f; P.own_lo = 0; P.full_n = 0; }
+  const int nb = P.nb;
+  // the lane side is the same for every problem of the launch (the range of the resident reference)
+  const uint8_t *ya = probs[blockIdx.x * 16].a;
+  const int na = probs[blockIdx.x * 16].na;
+  const uint32_t other = (uint32_t)(sa.ncodes - 1);
+  lut_s[tid] = sa.lut[tid];
+  for (int e = tid; e < sa.ncodes * 16 * R; e += 256) {
+    const int c = e / (16 * R);
+    const int rem = e - c * 16 * R;
+    const int ll = rem / R, r = rem - ll * R;
+    const int j = ll * R + r;
+    float v = kPadScoreF;                                          // padding columns: clamp to 0, never a maximum
+    if (j < na) v = ((uint32_t)c < other && ya[j] == sa.byte_of[c]) ? sa.match_s : sa.mismatch_s;
+    prof[(c * 16 + ll) * LS + r] = v;
+  }
+  __syncthreads();
+
+  // stream window of CODES: 16 B history + 64 B segment per slot, refilled every 64 steps
+  uint8_t *buf = win + slot * kWaveBuf;
+  uint32_t *buf32 = reinterpret_cast<uint32_t *>(buf);
+  const uint8_t *buf_lane = buf + 16 - l;
+  auto stage_load = [&](int seg) -> uint32_t {
+    const int c0 = seg * kWaveSeg + 4 * l;
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = c0 + k;
+      const uint32_t ch = (t < nb) ? (uint32_t)lut_s[P.b[t]] : other;     // beyond the stream: matches nothing
+      w |= ch << (8 * k);
+    }
+    return w;
+  };
+  int steps = nb + 16;
+  steps = max(steps, __shfl_xor(steps, 16));
+  steps = max(steps, __shfl_xor(steps, 32));
+  const int nseg = (steps + kWaveSeg - 1) / kWaveSeg;
+
+  uint32_t nextc = stage_load(0);
+  if (l < 4) buf32[l] = other * 0x01010101u;
+  buf32[4 + l] = nextc;
+  nextc = stage_load(1);
+
+  float gv = sa.gap_s;
+  asm volatile("" : "+v"(gv));                                     // (a VGPR operand: v_sub_f32 then issues at the double rate)
+  float H[R], Hg[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { H[r] = 0.0f; Hg[r] = -gv; }
+  uint32_t up_prev = 0;
+  float bl = 0.0f;                                                 // TRACK: this lane's best (value, column within the lane, row)
+  int rl = 0, tl = 0;
+  const float *prof_lane = prof + l * LS;
+
+  for (int seg = 0; seg < nseg; ++seg) {
+#pragma unroll 4
+    for (int k = 0; k < kWaveSeg; ++k) {
+      const int t = seg * kWaveSeg + k - l;                        // this lane's stream position
+      const uint32_t c = (uint32_t)buf_lane[k];
+      const u32x4 *pp = static_cast<const u32x4 *>(__builtin_assume_aligned(prof_lane + c * (16 * LS), 16));
+      uint32_t p[NQ4 * 4];
+#pragma unroll
+      for (int q = 0; q < NQ4; ++q) {
+        const u32x4 v = pp[q];
+        p[4 * q + 0] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+      }
+      const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(H[R - 1]), 0x111, 0xf, 0xf, true);
+      float diag = __uint_as_float(up_prev);
+      float north = __uint_as_float(up);                           // previous lane row, same step
+      up_prev = up;
+      float ng;
+      asm("v_sub_f32 %0, %1, %2" : "=v"(ng) : "v"(north), "v"(gv));
+      constexpr int W = (R + 15) / 16;
+      uint32_t dpack[W];
+      if (DIRS) {
+#pragma unroll
+        for (int d = 0; d < W; ++d) dpack[d] = 0;
+      }
+      float m = 0.0f, tpend = 0.0f;
+      (void)tpend;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float w = H[r];                                      // same lane row, previous step
+        float x, h;
+        asm("v_add_f32_e64 %0, %1, %2 clamp" : "=v"(x) : "v"(diag), "v"(__uint_as_float(p[r])));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(h) : "v"(x), "v"(Hg[r]), "v"(ng));
+        if (DIRS) {
+          // neighbours in the reference's terms (ORIENT 1): n1 = NW = diag, n2 = W = north (previous column of y), n3 = N = w
+          const float tmx = fmaxf(w, north);
+          const float lowest = fminf(fminf(diag, north), w);
+          const uint32_t c_go = lowest != 0.0f ? 1u : 0u, c_nw = diag >= tmx ? 1u : 0u, c_w = north >= w ? 1u : 0u;
+          const uint32_t dir = c_go * (3u - c_w - c_nw * (2u - c_w));   // 0 stop, 1 NW, 2 W, 3 N
+          dpack[r >> 4] |= (uint32_t)dir << (2 * (r & 15));
+        }
+        if (TRACK) {
+          if (r & 1) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(tpend), "v"(h));
+          else if (r + 1 < R) tpend = h;
+          else m = fmaxf(m, h);
+        }
+        diag = w;
+        H[r] = h;
+        north = h;
+        asm("v_sub_f32 %0, %1, %2" : "=v"(ng) : "v"(h), "v"(gv));
+        Hg[r] = ng;
+      }
+      if (TRACK) {
+        // seldom after the first rows: some cell of this step reaches the lane's best so far
+        if (m >= bl && m > 0.0f && (uint32_t)t < (uint32_t)nb) {
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            if (l * R + r < na && (H[r] > bl || (H[r] == bl && r < rl))) { bl = H[r]; rl = r; tl = t; }
+        }
+      }
+      if (DIRS) {
+        if (P.dirs != nullptr && t >= 0 && t < nb) {
+          uint32_t *dst = P.dirs + ((size_t)t * 16 + (size_t)l) * W;
+#pragma unroll
+          for (int d = 0; d < W; ++d) dst[d] = dpack[d];
+        }
+      }
+    }
+    const uint32_t hist = buf32[kWaveSeg / 4 + (l & 3)];
+    if (l < 4) buf32[l] = hist;
+    buf32[4 + l] = nextc;
+    nextc = stage_load(seg + 2);
+  }
+
+  if (TRACK) {
+    // the lane's winner -> across the 16 lanes: value, then column of y, then row of x
+    float bv = bl * sa.unscale;
+    long long bj = (long long)l * R + rl + 1, bi = P.b_offset + tl + 1;
+    if (!(bv > 0.0f)) { bv = 0.0f; bi = 0; bj = 0; }
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) {
       const float ov = __shfl_xor(bv, off, 16);
