@@ -15,7 +15,7 @@ bool wave_scoring_ok(const mi355_sw_params &p) {
 
 // rows per lane of the wave kernel instance that covers `na` cells on the lane side, and its decision bytes
 int wave_R(int na) { return na <= 160 ? 10 : (na <= 320 ? 20 : 32); }
-size_t wave_dirs_bytes(int64_t nb, int R) { return (size_t)nb * 16 * (size_t)((R + 15) / 16) * 4 + 64; }
+size_t wave_dirs_bytes(int64_t nb, int R) { return (size_t)(nb + 16) * 16 * (size_t)((R + 15) / 16) * 4; }   // (+ the skew's rows)
 
 struct WaveJob {
   int q;                  // query index
@@ -60,6 +60,16 @@ int launch_wave_prof(mi355_sw_ctx *ctx, const RefData &ref, const mi355_sw_param
   if (opt().no_wave_prof || p.semantics != MI355_SW_F32 || !wave_scoring_ok(p) || ref.ncodes < 2 || ref.ncodes > 256) return 1;
   const size_t lds = (size_t)ref.ncodes * 16 * lane_stride(R) * 4;
   if (lds > 96 * 1024) return 1;                                   // (alphabets of > 120 letters at R = 10)
+  // The tracking key borrows the five lowest mantissa bits of a cell (sw_wave_kernel.h): every reachable value must be a
+  // multiple of q = 2^e below 2^18 q — scores that are multiples of q, and match * (lane side + 1) < 2^18 q.
+  if (track) {
+    float q = 0.0f;
+    for (int e = 10; e >= -10 && q == 0.0f; --e) {
+      const float c = std::ldexp(1.0f, e);
+      if (std::floor(p.match / c) == p.match / c && std::floor(p.mismatch / c) == p.mismatch / c && std::floor(p.gap / c) == p.gap / c) q = c;
+    }
+    if (q == 0.0f || (double)p.match * ((double)na + 1.0) >= 262144.0 * (double)q) return 1;
+  }
   if (ctx->wlut_ref != (const void *)&ref || ctx->wlut_version != ref.version) {
     ctx->h_wlut.assign(512, 0);
     for (int b = 0; b < 256; ++b) ctx->h_wlut[b] = (uint8_t)(ref.code_of[b] >= 0 ? ref.code_of[b] : ref.ncodes - 1);
@@ -438,6 +448,7 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         w.orient = orient;
         w.R = groupR;
         w.lanes = strips ? 64 * strip_count(na, groupR) : 16;
+        w.skew = strips ? 0 : 1;
         w.need_slope = slope;
         w.b_offset = j.s_lo;
         w.start_i = loc[k].ix; w.start_j = loc[k].iy;

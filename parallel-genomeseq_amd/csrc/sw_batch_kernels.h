@@ -35,10 +35,10 @@ struct BatchWaveArgs {
   int64_t *cell;             // [2 * count]
 };
 
-// decision bytes in front of problem k of the launch (k = 0 .. count): stream positions so far * 16 lanes * W dwords,
-// plus 64 bytes of slack per problem (as wave_dirs_bytes on the host)
+// decision bytes in front of problem k of the launch (k = 0 .. count): (stream positions so far + 16 rows of skew per
+// problem) * 16 lanes * W dwords (as wave_dirs_bytes on the host)
 __device__ __host__ inline int64_t batch_dirs_offset(int64_t stream_positions_before, int64_t k, int W) {
-  return stream_positions_before * 16 * (int64_t)W * 4 + 64 * k;
+  return (stream_positions_before + 16 * k) * 16 * (int64_t)W * 4;
 }
 
 __global__ void batch_wave_setup(const BatchWaveArgs a) {
@@ -82,7 +82,7 @@ __global__ void batch_walk_setup(const BatchWalkArgs a) {
   w.y = a.ref;
   w.dirs = P.dirs;
   w.na = P.na; w.nb = P.nb; w.orient = a.orient;
-  w.R = a.R; w.lanes = 16;
+  w.R = a.R; w.lanes = 16; w.skew = 1;
   w.need_slope = 0.0f;
   w.b_offset = 0;
   const bool hit = a.best[k] > 0.0f;

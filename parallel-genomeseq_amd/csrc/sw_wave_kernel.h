@@ -28,7 +28,8 @@ struct WaveProblem {
   const uint8_t *b;      // streamed sequence: window of y (ORIENT 0) or window of x (ORIENT 1)
   int32_t na, nb;
   int64_t b_offset;      // true (1-based) stream index = b_offset + t + 1 for stream position t
-  uint32_t *dirs;        // DIRS: [nb][16][W] packed decisions (2 bits per cell, cell r of a lane at bit 2*(r%16)), or null
+  uint32_t *dirs;        // DIRS: [nb + 15][16][W] packed decisions (2 bits per cell, cell r of a lane at bit 2*(r%16)); lane l's
+                         // decisions for stream position t are in row t + l (the step they were made at); or null
   float *best;           // TRACK: maximum (0 when no positive cell)
   int64_t *cell;         // TRACK: [2] = row (into x), column (into y), 1-based, of the first maximum
   // KEYED tracking (ORIENT 0): the first cell in the engine's storage order (order_key<>, sw_exact_kernel.h) among
@@ -179,8 +180,9 @@ __global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, 
         }
       }
       if (DIRS) {
+        // row = the STEP (t + l): the sixteen lanes of a slot write one contiguous 64 W-byte row per step
         if (P.dirs != nullptr && t >= 0 && t < nb) {
-          uint32_t *dst = P.dirs + ((size_t)t * 16 + (size_t)l) * W;
+          uint32_t *dst = P.dirs + ((size_t)(seg * kWaveSeg + k) * 16 + (size_t)l) * W;
 #pragma unroll
           for (int d = 0; d < W; ++d) dst[d] = dpack[d];
         }
@@ -241,9 +243,12 @@ __global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, 
 //     the stream's bytes are translated to codes as they are staged into the slot's window;
 //   * cell: x = clamp(NW + s) (v_add_f32 clamp: the [0, 1] clamp is the zero floor), H = max3(x, W - g, N - g), keep H - g:
 //     three instructions, two of them at the double issue rate;
-//   * TRACK: the first maximum in storage order (column of y, then row of x) is kept per LANE — (value, column within the
-//     lane, row) under (value desc, column asc, row asc) — behind one max3 per two cells and a compare per step; the
-//     per-cell scan runs only on the steps where a lane's step maximum reaches its best so far.
+//   * TRACK: the first maximum in storage order (column of y, then row of x) is kept per LANE as ONE orderable key and the
+//     row it was first seen at.  The host takes this kernel only when every reachable cell value has its five lowest
+//     mantissa bits clear (scores that are multiples of a power of two, small against 2^18 of it): the key of a cell is its
+//     float bits OR (31 - column within the lane) — still a positive float, ordered by (value, then smaller column) — so one
+//     v_or per cell, one max3 per two cells and, per STEP, a compare, a max and a select (strict '>' keeps the first row)
+//     replace the per-cell compare + two selects; nothing branches.
 // Values, decisions and the winner are those of sw_wave_kernel<R, 1, false, TRACK, DIRS> (a power-of-two scaling commutes
 // with every add, subtract, maximum and comparison).
 struct WaveProfArgs {
@@ -319,8 +324,8 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
 #pragma unroll
   for (int r = 0; r < R; ++r) { H[r] = 0.0f; Hg[r] = -gv; }
   uint32_t up_prev = 0;
-  float bl = 0.0f;                                                 // TRACK: this lane's best (value, column within the lane, row)
-  int rl = 0, tl = 0;
+  float blk = 0.0f;                                                // TRACK: this lane's best key (value | 31 - column in the lane) ...
+  int tl = 0;                                                      // ... and the stream position it was first seen at
   const float *prof_lane = prof + l * LS;
 
   for (int seg = 0; seg < nseg; ++seg) {
@@ -356,17 +361,26 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
         asm("v_add_f32_e64 %0, %1, %2 clamp" : "=v"(x) : "v"(diag), "v"(__uint_as_float(p[r])));
         asm("v_max3_f32 %0, %1, %2, %3" : "=v"(h) : "v"(x), "v"(Hg[r]), "v"(ng));
         if (DIRS) {
-          // neighbours in the reference's terms (ORIENT 1): n1 = NW = diag, n2 = W = north (previous column of y), n3 = N = w
-          const float tmx = fmaxf(w, north);
-          const float lowest = fminf(fminf(diag, north), w);
-          const uint32_t c_go = lowest != 0.0f ? 1u : 0u, c_nw = diag >= tmx ? 1u : 0u, c_w = north >= w ? 1u : 0u;
-          const uint32_t dir = c_go * (3u - c_w - c_nw * (2u - c_w));   // 0 stop, 1 NW, 2 W, 3 N
-          dpack[r >> 4] |= (uint32_t)dir << (2 * (r & 15));
+          // neighbours in the reference's terms (ORIENT 1): n1 = NW = diag, n2 = W = north (previous column of y), n3 = N = w.
+          // Stop when a neighbour is 0 (all are >= 0), else NW if it is >= both others, else W if it is >= N, else N:
+          // 0 stop, 1 NW, 2 W, 3 N.  The three comparisons land in wavefront masks, their combination is scalar work, and
+          // each of the two bits is shifted into the lane's word by one add-with-carry (word = 2 * word + bit).
+          float tmx, lowest;                                       // (asm: fmaxf / fminf would first canonicalise the asm-made inputs)
+          asm("v_max_f32 %0, %1, %2" : "=v"(tmx) : "v"(w), "v"(north));
+          asm("v_min3_f32 %0, %1, %2, %3" : "=v"(lowest) : "v"(diag), "v"(north), "v"(w));
+          const uint64_t c_go = __builtin_amdgcn_ballot_w64(lowest != 0.0f), c_nw = __builtin_amdgcn_ballot_w64(diag >= tmx),
+                         c_w = __builtin_amdgcn_ballot_w64(north >= w);
+          const uint64_t b_hi = c_go & ~c_nw, b_lo = c_go & (c_nw | ~c_w);
+          uint64_t carry_out;
+          asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(dpack[r >> 4]), "=s"(carry_out) : "v"(dpack[r >> 4]), "s"(b_lo));
+          asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(dpack[r >> 4]), "=s"(carry_out) : "v"(dpack[r >> 4]), "s"(b_hi));
+          (void)carry_out;
         }
         if (TRACK) {
-          if (r & 1) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(tpend), "v"(h));
-          else if (r + 1 < R) tpend = h;
-          else m = fmaxf(m, h);
+          const float hk = __uint_as_float(__float_as_uint(h) | (uint32_t)(31 - r));     // (value, smaller column first)
+          if (r & 1) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(tpend), "v"(hk));
+          else if (r + 1 < R) tpend = hk;
+          else m = fmaxf(m, hk);
         }
         diag = w;
         H[r] = h;
@@ -375,18 +389,23 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
         Hg[r] = ng;
       }
       if (TRACK) {
-        // seldom after the first rows: some cell of this step reaches the lane's best so far
-        if (m >= bl && m > 0.0f && (uint32_t)t < (uint32_t)nb) {
-#pragma unroll
-          for (int r = 0; r < R; ++r)
-            if (l * R + r < na && (H[r] > bl || (H[r] == bl && r < rl))) { bl = H[r]; rl = r; tl = t; }
-        }
+        // strict '>': an equal key (same value, same column) at a later row does not replace the first.  Cells beyond the
+        // stream's end and padding columns hold values strictly below some real cell: they can lead a lane for a while, never
+        // the slot.
+        tl = m > blk ? t : tl;
+        blk = fmaxf(blk, m);
       }
       if (DIRS) {
+        // row = the STEP (t + l): the sixteen lanes of a slot write one contiguous 64 W-byte row per step
         if (P.dirs != nullptr && t >= 0 && t < nb) {
-          uint32_t *dst = P.dirs + ((size_t)t * 16 + (size_t)l) * W;
+          uint32_t *dst = P.dirs + ((size_t)(seg * kWaveSeg + k) * 16 + (size_t)l) * W;
 #pragma unroll
-          for (int d = 0; d < W; ++d) dst[d] = dpack[d];
+          for (int d = 0; d < W; ++d) {
+            // the first cell's bits were shifted in first: reversed and moved down, cell r of the word sits at bit 2 * (r % 16)
+            constexpr int full = 16;
+            const int cells = (d + 1) * full <= R ? full : R - d * full;
+            dst[d] = __builtin_bitreverse32(dpack[d]) >> (32 - 2 * cells);
+          }
         }
       }
     }
@@ -398,8 +417,9 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
 
   if (TRACK) {
     // the lane's winner -> across the 16 lanes: value, then column of y, then row of x
-    float bv = bl * sa.unscale;
-    long long bj = (long long)l * R + rl + 1, bi = P.b_offset + tl + 1;
+    const uint32_t kb = __float_as_uint(blk);
+    float bv = __uint_as_float(kb & ~31u) * sa.unscale;
+    long long bj = (long long)l * R + (31 - (int)(kb & 31u)) + 1, bi = P.b_offset + tl + 1;
     if (!(bv > 0.0f)) { bv = 0.0f; bi = 0; bj = 0; }
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) {
@@ -424,6 +444,7 @@ struct WaveWalk {
   int32_t na, nb, orient;
   int32_t R;               // rows per lane of the instance that wrote dirs
   int32_t lanes;           // lanes that share one stream position in dirs
+  int32_t skew;            // 1: the decisions of (stream position t, lane) are in row t + lane (sw_wave_kernel); 0: in row t
   float need_slope;        // > 0: a cell with lane-side index a is already exact a + ceil(a * need_slope) + 2 stream
                            // positions into the window (DESIGN.md §3.3 for a path confined to a rows/columns)
   int64_t b_offset;        // as WaveProblem
@@ -475,7 +496,7 @@ __global__ void sw_wave_walk_kernel(const WaveWalk *probs, int n, char *cons, co
     if (len >= W.cap) { status = 2; break; }
     const int lane = (int)((aidx - 1) / W.R), r = (int)((aidx - 1) % W.R);
     const int wd = (W.R + 15) / 16;
-    const int dir = (int)((W.dirs[((size_t)t * (size_t)W.lanes + (size_t)lane) * wd + (r >> 4)] >> (2 * (r & 15))) & 3u);
+    const int dir = (int)((W.dirs[((size_t)(t + W.skew * lane) * (size_t)W.lanes + (size_t)lane) * wd + (r >> 4)] >> (2 * (r & 15))) & 3u);
     if (dir == kDirStop) {
       if (WRITE) { cons_x[len] = (char)W.x[ix - 1]; cons_y[len] = (char)W.y[iy - 1]; }
       ++len;
@@ -531,7 +552,7 @@ __global__ __launch_bounds__(64) void sw_wave_walk_long_kernel(const WaveWalk *p
       else if (len + p >= W.cap) code = 5;
       else {
         const int lane = (int)((cx - 1) / W.R), r = (int)((cx - 1) % W.R);
-        code = (int)((W.dirs[((size_t)t * (size_t)W.lanes + (size_t)lane) * wd + (r >> 4)] >> (2 * (r & 15))) & 3u);
+        code = (int)((W.dirs[((size_t)(t + W.skew * lane) * (size_t)W.lanes + (size_t)lane) * wd + (r >> 4)] >> (2 * (r & 15))) & 3u);
       }
     }
     const unsigned long long other = __ballot(code != kDirNW);
