@@ -462,8 +462,9 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
   const size_t nq = q.nq;
   const int64_t n = rg.hi - rg.lo;
   HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  // (half a million small alignments per call: the per-query host arrays are sized only where a path reads them)
   loc.assign(nq, Located());
-  tout.assign(nq, TraceOut());
+  tout.assign(want_trace ? nq : 0, TraceOut());
   // No score can be positive (uint8 engine whose match score saturates to 0; float engine whose best substitution
   // score is <= 0 with a positive gap): every cell of the matrix is 0 and the defined no-match result stands.
   bool all_zero = false;
@@ -480,8 +481,9 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
     bool allow_sat = p.semantics == MI355_SW_F32 && strip_scoring_ok(ref, p);
     // ... and so does the sampled running maximum (sw_score_kernel MK), for the sub-chunks within its slack of the key
     bool allow_sample = strip_scoring_ok(ref, p);
-    std::vector<char> qfast(nq, 0), qfloat(nq, 0), qsat(nq, 0), qdone(nq, 0);
-    std::vector<int64_t> qchunk(nq, 0), qwarm(nq, 0);
+    const size_t nsweep = (n >= 1024 || pre) ? nq : 0;             // only the score-kernel paths (below) index these
+    std::vector<char> qfast(nq, 0), qfloat(nsweep, 0), qsat(nsweep, 0), qdone(nsweep, 0);
+    std::vector<int64_t> qchunk(nsweep, 0), qwarm(nsweep, 0);
     std::vector<unsigned long long> keys;
     bool any_fast = false;
     if (pre) {
@@ -684,7 +686,7 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       }
       HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
       ctx->timings[2] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
-      for (size_t t = 0; t < slow.size(); ++t) { loc[slow[t]] = sl[t]; tout[slow[t]] = std::move(st[t]); }
+      for (size_t t = 0; t < slow.size(); ++t) { loc[slow[t]] = sl[t]; if (want_trace) tout[slow[t]] = std::move(st[t]); }
     }
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));

@@ -125,17 +125,22 @@ def test_long_kernel_vs_oracle(pgs, oracle, sem):
     try:
         variants = [{}, {"no_long_p32": 1}, {"no_long_p32": 1, "chunk": 8192}, {"long_pipes": 2}, {"long_groups": 2}, {"long_groups": 4, "long_pipes": 1},
                     {"long_wgs": 12}]
+        cases = []                                                              # (query, expected): the oracle runs once per query
+        for k, m in enumerate((2049, 2560, 2561, 3072, 5000, 7681, 10_000, 12_288)):
+            o = [0, 150_000 - m, 70_000, 3000][k % 4]
+            q = bytearray(refb[o:o + m])
+            rng = np.random.default_rng(100 + k)
+            for i in rng.choice(m, m // 50, replace=False):
+                q[i] = b"ACGT"[int(rng.integers(0, 4))]
+            q = bytes(q).replace(b"N", b"A")
+            cases.append((q, oracle.align(q, refb, sem)))
+        unrelated = pgs.synth.dna(7100 + sem, 4000).tobytes()                   # background maximum
+        unrelated_exp = oracle.align(unrelated, refb, sem)
         for var in variants:
             for k, v in var.items():
                 c.set_option(k, v)
-            for k, m in enumerate((2049, 2560, 2561, 3072, 5000, 7681, 10_000, 12_288)):
-                o = [0, 150_000 - m, 70_000, 3000][k % 4]
-                q = bytearray(refb[o:o + m])
-                rng = np.random.default_rng(100 + k)
-                for i in rng.choice(m, m // 50, replace=False):
-                    q[i] = b"ACGT"[int(rng.integers(0, 4))]
-                q = bytes(q).replace(b"N", b"A")
-                exp = oracle.align(q, refb, sem)
+            for q, exp in cases:
+                m = len(q)
                 got = c.align(q, refb, sem)
                 _cmp(got, exp, "long kernel sem=%d m=%d %r" % (sem, m, var))
                 name = c.last_kernel()["name"]
@@ -143,8 +148,7 @@ def test_long_kernel_vs_oracle(pgs, oracle, sem):
                     assert "sw_long_kernel" in name, name
                 if "no_long_p32" in var and "sw_long_kernel" in name:
                     assert "f16 profile" in name, name
-            q = pgs.synth.dna(7100 + sem, 4000).tobytes()                       # unrelated: background maximum
-            _cmp(c.align(q, refb, sem), oracle.align(q, refb, sem), "long kernel, unrelated query sem=%d %r" % (sem, var))
+            _cmp(c.align(unrelated, refb, sem), unrelated_exp, "long kernel, unrelated query sem=%d %r" % (sem, var))
             for k in var:
                 c.set_option(k, None)
     finally:

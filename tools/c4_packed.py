@@ -11,6 +11,7 @@ lens = pgs.synth.lognormal_lengths(5, n)
 allres = pgs.synth.protein(5, int(lens.sum()))
 offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
 ctx = pgs.Context(0)
+if os.environ.get("C4_TRACE"): ctx.set_option("trace", 1)
 ctx.set_reference(pgs.synth.P02232)
 t0 = time.perf_counter(); ctx.batch_upload_packed(allres, offs); print("upload %.1f ms" % ((time.perf_counter() - t0) * 1e3), file=sys.stderr)
 for flags in (pgs.capi.SCORE_ONLY, 0):

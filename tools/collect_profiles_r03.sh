@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/kt_config5 --output-format csv -- pytho
 rocprofv3 --kernel-trace --stats -d $OUT/kt_one_by_one --output-format csv -- python3 $R/tools/lat_probe.py 50000000 0 > $OUT/one_by_one.log 2>&1
 cd $R
 tools/pmc_run.sh bench 'sw_score_kernel' python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-strong --no-traffic --no-parity > $OUT/pmc_bench.log 2>&1
-tools/pmc_run.sh config4 'sw_wave_kernel<10, 1, false, true, true|sw_wave_kernel<10, 1, false, true, false|sw_wave_walk_kernel' python3 $R/tools/c4_packed.py > $OUT/pmc_config4.log 2>&1
+tools/pmc_run.sh config4 'sw_wave_prof_kernel<10, true, true>|sw_wave_prof_kernel<10, true, false>|sw_wave_walk_kernel' python3 $R/tools/c4_packed.py > $OUT/pmc_config4.log 2>&1
 tools/pmc_run.sh config5 'sw_long_kernel|sw_strip_kernel<3, false, 2|sw_strip_kernel<3, false, 0|sw_wave_walk_long_kernel' python3 $R/tools/c5_whole.py > $OUT/pmc_config5.log 2>&1
 tools/pmc_run.sh one_by_one 'sw_solo_kernel|sw_score_kernel' python3 $R/tools/lat_probe.py 50000000 0 > $OUT/pmc_one_by_one.log 2>&1
 cp gpurun_out/pmc/*.json $OUT/ 2>/dev/null
