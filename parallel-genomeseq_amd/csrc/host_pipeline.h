@@ -663,7 +663,10 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
         return lo;
       };
       const size_t z = first_above(0);                             // empty queries: score 0, nothing to run
-      const size_t e0 = first_above(std::min<int64_t>(kWaveMaxLanesSide, n));   // lanes = rows of x (|x| <= 512, |x| <= |y|)
+      // lanes = rows of x (|x| <= 512, |x| <= |y|) — unless the range fits the lanes and the profile kernel takes it: then
+      // every x streams past the shared profile (|x| + 16 steps instead of |y| + 16, on the cheaper cell)
+      const bool all_stream = n <= kWaveMaxLanesSide && wave_prof_ok(ref, p, wave_R((int)n), (int)n, true);
+      const size_t e0 = all_stream ? z : first_above(std::min<int64_t>(kWaveMaxLanesSide, n));
       const size_t e1 = n <= kWaveMaxLanesSide ? nq : e0;          // lanes = columns of y (|y| <= 512), x streams
       for (size_t pos = 0; pos < z; ++pos) handled[q.order[pos]] = 1;
       HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));

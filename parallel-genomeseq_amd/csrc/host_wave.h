@@ -55,11 +55,9 @@ void launch_wave_R(int orient, bool u8, bool track, bool dirs, unsigned blocks, 
 // sw_wave_prof_kernel for a launch whose lanes hold columns of the reference range (ORIENT 1), float engine, identity scoring:
 // the query profile over the shared lane side + the three-op cell (sw_wave_kernel.h).  Returns 1 when it does not apply
 // (the caller launches sw_wave_kernel), 0 when launched, < 0 on error.
-int launch_wave_prof(mi355_sw_ctx *ctx, const RefData &ref, const mi355_sw_params &p, int R, int na, bool track, bool dirs,
-                     unsigned blocks, const WaveProblem *dp, int n) {
-  if (opt().no_wave_prof || p.semantics != MI355_SW_F32 || !wave_scoring_ok(p) || ref.ncodes < 2 || ref.ncodes > 256) return 1;
-  const size_t lds = (size_t)ref.ncodes * 16 * lane_stride(R) * 4;
-  if (lds > 96 * 1024) return 1;                                   // (alphabets of > 120 letters at R = 10)
+bool wave_prof_ok(const RefData &ref, const mi355_sw_params &p, int R, int na, bool track) {
+  if (opt().no_wave_prof || p.semantics != MI355_SW_F32 || !wave_scoring_ok(p) || ref.ncodes < 2 || ref.ncodes > 256) return false;
+  if ((size_t)ref.ncodes * 16 * lane_stride(R) * 4 > 96 * 1024) return false;   // (alphabets of > 120 letters at R = 10)
   // The tracking key borrows the five lowest mantissa bits of a cell (sw_wave_kernel.h): every reachable value must be a
   // multiple of q = 2^e below 2^18 q — scores that are multiples of q, and match * (lane side + 1) < 2^18 q.
   if (track) {
@@ -68,8 +66,15 @@ int launch_wave_prof(mi355_sw_ctx *ctx, const RefData &ref, const mi355_sw_param
       const float c = std::ldexp(1.0f, e);
       if (std::floor(p.match / c) == p.match / c && std::floor(p.mismatch / c) == p.mismatch / c && std::floor(p.gap / c) == p.gap / c) q = c;
     }
-    if (q == 0.0f || (double)p.match * ((double)na + 1.0) >= 262144.0 * (double)q) return 1;
+    if (q == 0.0f || (double)p.match * ((double)na + 1.0) >= 262144.0 * (double)q) return false;
   }
+  return true;
+}
+
+int launch_wave_prof(mi355_sw_ctx *ctx, const RefData &ref, const mi355_sw_params &p, int R, int na, bool track, bool dirs,
+                     unsigned blocks, const WaveProblem *dp, int n) {
+  if (!wave_prof_ok(ref, p, R, na, track)) return 1;
+  const size_t lds = (size_t)ref.ncodes * 16 * lane_stride(R) * 4;
   if (ctx->wlut_ref != (const void *)&ref || ctx->wlut_version != ref.version) {
     ctx->h_wlut.assign(512, 0);
     for (int b = 0; b < 256; ++b) ctx->h_wlut[b] = (uint8_t)(ref.code_of[b] >= 0 ? ref.code_of[b] : ref.ncodes - 1);
