@@ -204,7 +204,9 @@ int mi355_sw_last_timings(const mi355_sw_ctx *ctx, double out[6]);
 
 /* What the candidate filters of the last batch / align call did: [0] queries that exceeded their
  * candidate cap and were swept a second time on the exact instances (per-query fallback), [1] times the WHOLE batch was swept
- * again (more than half of it exceeded the cap), [2] candidate sub-chunks re-evaluated exactly, [3] reserved (0). */
+ * again (more than half of it exceeded the cap), [2] candidate sub-chunks re-evaluated exactly, [3] walks of the
+ * many-small-alignments batch that left the decision window in front of their argmax and were redone on whole-problem decisions
+ * (DESIGN.md §4.3). */
 int mi355_sw_last_counters(const mi355_sw_ctx *ctx, uint64_t out[4]);
 
 /* Which sw_score_kernel instance swept the most cells in the last call (what the `iterate` of

@@ -306,7 +306,7 @@ class Context:
         """Candidate-filter counters of the last call (mi355_sw_last_counters)."""
         c = (C.c_uint64 * 4)()
         self._L.mi355_sw_last_counters(self._ctx, c)
-        return dict(requeried=int(c[0]), whole_batch_again=int(c[1]), candidates=int(c[2]))
+        return dict(requeried=int(c[0]), whole_batch_again=int(c[1]), candidates=int(c[2]), left_window=int(c[3]))
 
     def last_kernel(self):
         """The sw_score_kernel instance that swept the most cells in the last call (mi355_sw_last_kernel)."""

@@ -3,7 +3,8 @@
 //
 // Float engine, identity scoring, problems whose short side fits the register wavefront (<= 512): sorted positions
 // [first, first + count) of the batch against one range of the reference, all with the same orientation.
-//   one pass of sw_wave_kernel<TRACK, DIRS>: first maximum in storage order + every cell's greedy decision;
+//   one pass of sw_wave_kernel<TRACK, DIRS>: first maximum in storage order + every cell's greedy decision (or, on
+//   sw_wave_prof_kernel, a checkpointed first pass and decisions for a window in front of each argmax);
 //   walks measured, laid out by a device scan, written; results copied down once.
 // Nothing per-alignment is built on the host before the results arrive (src/mpi_sw_solve_uniprot.cpp:95-138: every
 // database sequence x against the one query y — 561 356 of them in config 4).
@@ -39,8 +40,16 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   const int R = wave_R(maxna);
   const int W = (R + 15) / 16;
   const int64_t stream_total = orient == 0 ? (int64_t)count * nref : q.cumlen[first + count] - q.cumlen[first];
-  const size_t dirs_total = want_trace ? (size_t)batch_dirs_offset(stream_total, (int64_t)count, W) : 0;
-  if (dirs_total > kDirsBudget || count > ((size_t)1 << 30)) {
+  // lanes = columns of the shared second sequence: the profile kernel (three-op cell, first maximum per lane).  With traceback,
+  // decisions are only made where the walk goes: a first pass keeps (maximum, cell) and saves the wavefront every 64 steps, a
+  // second resumes every problem kWindowGuard..+63 rows in front of its argmax and stops at it (a database of mostly unrelated
+  // sequences: walks of a dozen cells; a walk that leaves its window hands the problem to the host-driven path below).
+  const bool prof = orient == 1 && wave_prof_ok(ref, p, R, (int)nref, true);
+  const bool windows = prof && want_trace && !opt().no_wave_window;
+  const size_t dirs_total = !want_trace ? 0 : windows ? count * (size_t)kWindowRows * 16 * (size_t)W * 4
+                                                      : (size_t)batch_dirs_offset(stream_total, (int64_t)count, W);
+  const size_t ckpt_total = windows ? ((size_t)batch_ckpt_row(stream_total, (int64_t)count) + 1) * 16 * (size_t)(R + 1) * 4 : 0;
+  if (dirs_total + ckpt_total > kDirsBudget || count > ((size_t)1 << 30)) {
     if (count == 1) return 0;
     const size_t half = count / 2;
     int rc = exact_full_device(ctx, ref, q, rg, p, first, half, orient, want_trace, loc, tout, handled);
@@ -52,7 +61,8 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   // device scratch: problems, (best, cell), decisions, walk descriptors + (len, pos, status) + consensus offsets + total
   const size_t walk_bytes = n * sizeof(WaveWalk) + n * 24 + (n + 1) * 8 + 64;
   if (ctx->wprobs.ensure(n * sizeof(WaveProblem)) || ctx->outs_f.ensure(n * 4) || ctx->outs_i.ensure(n * 16) ||
-      (dirs_total && ctx->dirs.ensure(dirs_total)) || (want_trace && ctx->walkp.ensure(walk_bytes)))
+      (dirs_total && ctx->dirs.ensure(dirs_total)) || (ckpt_total && ctx->ckpt.ensure(ckpt_total)) ||
+      (want_trace && ctx->walkp.ensure(walk_bytes)))
     return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(batch scratch) failed");
   BatchWaveArgs a;
   a.qbytes = q.bytes.as<uint8_t>(); a.qoff = q.offs.as<int64_t>(); a.qlen = q.lens.as<int32_t>();
@@ -63,6 +73,8 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   a.probs = ctx->wprobs.as<WaveProblem>();
   a.best = ctx->outs_f.as<float>();
   a.cell = ctx->outs_i.as<int64_t>();
+  a.ckpt = windows ? ctx->ckpt.as<float>() : nullptr;
+  a.R = R;
   const unsigned sblocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(batch_wave_setup, dim3(sblocks), dim3(256), 0, ctx->stream, a);
   WaveScoring sc;
@@ -70,15 +82,22 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   sc.u8M = sc.u8X = sc.u8G = 0.0f;
   const unsigned blocks = (unsigned)((n + 15) / 16);
   const WaveProblem *dp = ctx->wprobs.as<WaveProblem>();
-  // lanes = columns of the shared second sequence: the profile kernel (three-op cell, first maximum per lane)
-  int prof_rc = orient == 1 ? launch_wave_prof(ctx, ref, p, R, (int)nref, true, want_trace, blocks, dp, (int)n) : 1;
-  if (prof_rc < 0) return prof_rc;
+  if (windows) {
+    int rc = launch_wave_prof(ctx, ref, p, R, (int)nref, true, false, blocks, dp, (int)n);
+    if (rc) return rc < 0 ? rc : fail(ctx, MI355_SW_ENODEV, "internal: the profile kernel refused a launch it had accepted");
+    hipLaunchKernelGGL(batch_window_setup, dim3(sblocks), dim3(256), 0, ctx->stream, a);
+    rc = launch_wave_prof(ctx, ref, p, R, (int)nref, false, true, blocks, dp, (int)n);
+    if (rc) return rc < 0 ? rc : fail(ctx, MI355_SW_ENODEV, "internal: the profile kernel refused a launch it had accepted");
+  } else {
+    const int prof_rc = prof ? launch_wave_prof(ctx, ref, p, R, (int)nref, true, want_trace, blocks, dp, (int)n) : 1;
+    if (prof_rc < 0) return prof_rc;
 #define BATCH_WAVE(r)                                                                                                   \
   if (orient == 0) launch_wave_batch<r, 0>(want_trace, blocks, ctx->stream, dp, (int)n, sc);                            \
   else launch_wave_batch<r, 1>(want_trace, blocks, ctx->stream, dp, (int)n, sc);
-  if (prof_rc == 0) { }
-  else if (R == 10) { BATCH_WAVE(10) } else if (R == 20) { BATCH_WAVE(20) } else { BATCH_WAVE(32) }
+    if (prof_rc == 0) { }
+    else if (R == 10) { BATCH_WAVE(10) } else if (R == 20) { BATCH_WAVE(20) } else { BATCH_WAVE(32) }
 #undef BATCH_WAVE
+  }
   HIPCHK(ctx, hipGetLastError());
 
   // results land in pinned staging: [best n x 4][cell n x 16][wout n x 24][offs (n + 1) x 8]
@@ -127,12 +146,17 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   parallel_for(n, [&](size_t k0, size_t k1) {
     for (size_t k = k0; k < k1; ++k) {
       const int id = q.order[first + k];
+      const bool hit = h_best[k] > 0;
+      if (want_trace && hit && h_wout[3 * k + 2] != 0) {
+        // a walk that left its window: the problem goes to the host-driven path (handled stays 0); on whole problems: a bug
+        if (!windows || h_wout[3 * k + 2] != 1) bad.store(true, std::memory_order_relaxed);
+        continue;
+      }
       handled[id] = 1;
       Located &L = loc[id];
-      L.score = h_best[k] > 0 ? h_best[k] : 0;
+      L.score = hit ? h_best[k] : 0;
       L.ix = h_cell[2 * k]; L.iy = h_cell[2 * k + 1];
-      if (!want_trace || !(L.score > 0)) continue;
-      if (h_wout[3 * k + 2] != 0) { bad.store(true, std::memory_order_relaxed); continue; }
+      if (!want_trace || !hit) continue;
       TraceOut &t = tout[id];
       t.len = (size_t)h_wout[3 * k];
       t.cx = cons_base + h_offs[k];
@@ -141,6 +165,8 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     }
   });
   if (bad.load()) return fail(ctx, MI355_SW_ENODEV, "internal: a walk over a whole-problem window failed");
+  if (windows && want_trace)
+    for (size_t k = 0; k < n; ++k) ctx->left_window += (h_best[k] > 0 && h_wout[3 * k + 2] == 1) ? 1 : 0;
   return 0;
 }
 

@@ -918,7 +918,7 @@ void reset_timings(mi355_sw_ctx *ctx) {
   for (double &t : ctx->timings) t = 0;
   ctx->score_ev_used = 0; ctx->arenas.clear(); ctx->cons_used = 0;
   ctx->last_kernel = mi355_sw_kernel_info{};
-  ctx->requeried = 0; ctx->whole_again = 0; ctx->candidates = 0;
+  ctx->requeried = 0; ctx->whole_again = 0; ctx->candidates = 0; ctx->left_window = 0;
 }
 
 }  // namespace

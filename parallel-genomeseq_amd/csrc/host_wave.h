@@ -144,6 +144,7 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
     w.best = ctx->outs_f.as<float>() + k;
     w.cell = ctx->outs_i.as<int64_t>() + 2 * k;
     w.target = j.target; w.own_lo = j.own_lo; w.full_n = nref;
+    w.ckpt = nullptr; w.k0 = 0;
   }
   });
   const bool keyed = jobs[0].keyed;
@@ -453,7 +454,7 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         w.orient = orient;
         w.R = groupR;
         w.lanes = strips ? 64 * strip_count(na, groupR) : 16;
-        w.skew = strips ? 0 : 1;
+        w.skew = strips ? 0 : 1; w.row0 = 0;
         w.need_slope = slope;
         w.b_offset = j.s_lo;
         w.start_i = loc[k].ix; w.start_j = loc[k].iy;

@@ -84,7 +84,7 @@ void mi355_sw_destroy(mi355_sw_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   DevBuf *bufs[] = {&c->qcnt, &c->sel2, &c->gcnt, &c->wlut, &c->ref.bytes, &c->ref.codes, &c->batch.bytes, &c->batch.lens, &c->keys, &c->ranges, &c->stab,
-                    &c->batch.offs, &c->batch.sel, &c->ftab, &c->ftab_s, &c->htab, &c->htab8, &c->soloblk, &c->flags, &c->submax, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow, &c->wprobs, &c->scan, &c->batch.cum};
+                    &c->batch.offs, &c->batch.sel, &c->ftab, &c->ftab_s, &c->htab, &c->htab8, &c->soloblk, &c->flags, &c->submax, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow, &c->wprobs, &c->scan, &c->batch.cum, &c->ckpt};
   for (DevBuf *b : bufs) b->release();
   c->adhoc.release(); c->one.release();
   c->pin_probs.release(); c->pin_walk.release(); c->pin_out.release(); c->pin_solo_up.release(); c->pin_solo_down.release();
@@ -448,7 +448,7 @@ int mi355_sw_last_timings(const mi355_sw_ctx *ctx, double out[6]) {
 
 int mi355_sw_last_counters(const mi355_sw_ctx *ctx, uint64_t out[4]) {
   if (!ctx || !out) return MI355_SW_EINVAL;
-  out[0] = ctx->requeried; out[1] = ctx->whole_again; out[2] = ctx->candidates; out[3] = 0;
+  out[0] = ctx->requeried; out[1] = ctx->whole_again; out[2] = ctx->candidates; out[3] = ctx->left_window;
   return 0;
 }
 

@@ -33,7 +33,21 @@ struct BatchWaveArgs {
   WaveProblem *probs;        // [count]
   float *best;               // [count]
   int64_t *cell;             // [2 * count]
+  // checkpointed whole problems (orient 1 on sw_wave_prof_kernel, host_batch.h): the first pass keeps (best, cell) and saves
+  // the wavefront's state every 64 steps; batch_window_setup then turns every problem into its last kWindowGuard .. + 63 rows in
+  // front of the argmax, resumed from the saved state, and only those rows get decisions
+  float *ckpt;               // null: whole problems in one pass
+  int R;
 };
+
+constexpr int kWindowGuard = 48;                                   // rows in front of the argmax a window holds at least
+constexpr int kWindowRows = kWindowGuard + 64 + 16;                // decision rows per window: guard .. guard + 63 rows, + the skew
+
+// saved states in front of problem k: one row of 16 x (R + 1) floats per 64 steps (as batch_dirs_offset: monotone in k, room for
+// (steps_k + 16) / 64 + 1 rows)
+__device__ __host__ inline int64_t batch_ckpt_row(int64_t stream_positions_before, int64_t k) {
+  return (stream_positions_before + 16 * k) / 64 + k;
+}
 
 // decision bytes in front of problem k of the launch (k = 0 .. count): (stream positions so far + 16 rows of skew per
 // problem) * 16 lanes * W dwords (as wave_dirs_bytes on the host)
@@ -52,10 +66,29 @@ __global__ void batch_wave_setup(const BatchWaveArgs a) {
   if (a.orient == 0) { w.a = xq; w.na = m; w.b = a.ref; w.nb = (int32_t)a.nref; before = (int64_t)k * a.nref; }
   else { w.a = a.ref; w.na = (int32_t)a.nref; w.b = xq; w.nb = m; before = a.qcum[a.first + k] - a.qcum[a.first]; }
   w.b_offset = 0;
-  w.dirs = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(a.dirs) + batch_dirs_offset(before, k, a.W));
+  w.dirs = a.ckpt != nullptr ? nullptr
+                             : reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(a.dirs) + batch_dirs_offset(before, k, a.W));
+  w.ckpt = a.ckpt != nullptr ? a.ckpt + (size_t)batch_ckpt_row(before, k) * 16 * (size_t)(a.R + 1) : nullptr;
+  w.k0 = 0;
   w.best = a.best + k;
   w.cell = a.cell + 2 * (size_t)k;
   w.target = 0.0f; w.own_lo = 0; w.full_n = a.nref;
+  a.probs[k] = w;
+}
+
+// after the first pass of a checkpointed launch: problem k becomes the rows [k0, row of its argmax) with decisions, resumed from
+// the state saved at step k0 (whole from step 0 when the argmax lies within the first window; nothing when no cell is positive)
+__global__ void batch_window_setup(const BatchWaveArgs a) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.count) return;
+  WaveProblem w = a.probs[k];
+  const bool hit = a.best[k] > 0.0f;
+  const int32_t rows = hit ? (int32_t)a.cell[2 * (size_t)k] : 0;   // 1-based row of the argmax = rows to run
+  const int32_t k0 = hit ? 64 * (max(0, rows - 1 - kWindowGuard) / 64) : 0;
+  w.nb = rows;
+  w.k0 = k0;
+  w.ckpt = k0 > 0 ? w.ckpt + (size_t)(k0 / 64 - 1) * 16 * (size_t)(a.R + 1) : nullptr;
+  w.dirs = a.dirs + (size_t)k * kWindowRows * 16 * (size_t)a.W;
   a.probs[k] = w;
 }
 
@@ -82,7 +115,7 @@ __global__ void batch_walk_setup(const BatchWalkArgs a) {
   w.y = a.ref;
   w.dirs = P.dirs;
   w.na = P.na; w.nb = P.nb; w.orient = a.orient;
-  w.R = a.R; w.lanes = 16; w.skew = 1;
+  w.R = a.R; w.lanes = 16; w.skew = 1; w.row0 = P.k0;
   w.need_slope = 0.0f;
   w.b_offset = 0;
   const bool hit = a.best[k] > 0.0f;

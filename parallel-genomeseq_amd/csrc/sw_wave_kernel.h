@@ -37,6 +37,11 @@ struct WaveProblem {
   float target;
   int32_t own_lo;
   int64_t full_n;        // |y| of the full problem (uint8 storage order)
+  // sw_wave_prof_kernel only (checkpointed whole problems, host_batch.h).  TRACK without DIRS: where the state of the slot's
+  // wavefront is saved after every 64th step (null: nowhere).  DIRS without TRACK: k0 > 0 resumes the problem at step k0 (a
+  // multiple of 64) from the state saved there; nb is then the END of the rows to run, dirs rows count from step k0.
+  float *ckpt;
+  int32_t k0;
 };
 
 struct WaveScoring {
@@ -59,7 +64,7 @@ __global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, 
   WaveProblem P;
   if (active) P = probs[pid];
   else { P.a = nullptr; P.b = nullptr; P.na = 0; P.nb = 0; P.b_offset = 0; P.dirs = nullptr; P.best = nullptr; P.cell = nullptr;
-         P.target = -1.0f; P.own_lo = 0; P.full_n = 0; }
+         P.target = -1.0f; P.own_lo = 0; P.full_n = 0; P.ckpt = nullptr; P.k0 = 0; }
   const int na = P.na, nb = P.nb;
 
   // this lane's R characters of the short side (0xFFFF = padding, never equal to a byte)
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
   WaveProblem P;
   if (active) P = probs[pid];
   else { P.a = nullptr; P.b = nullptr; P.na = 0; P.nb = 0; P.b_offset = 0; P.dirs = nullptr; P.best = nullptr; P.cell = nullptr;
-         P.target = -1.0f; P.own_lo = 0; P.full_n = 0; }
+         P.target = -1.0f; P.own_lo = 0; P.full_n = 0; P.ckpt = nullptr; P.k0 = 0; }
   const int nb = P.nb;
   // the lane side is the same for every problem of the launch (the range of the resident reference)
   const uint8_t *ya = probs[blockIdx.x * 16].a;
@@ -297,33 +302,46 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
   uint8_t *buf = win + slot * kWaveBuf;
   uint32_t *buf32 = reinterpret_cast<uint32_t *>(buf);
   const uint8_t *buf_lane = buf + 16 - l;
-  auto stage_load = [&](int seg) -> uint32_t {
-    const int c0 = seg * kWaveSeg + 4 * l;
+  const int k0 = (DIRS && !TRACK) ? P.k0 : 0;                       // first step of this launch (a resumed problem: > 0)
+  auto stage_load = [&](int seg) -> uint32_t {                     // (seg = -1: the sixteen positions in front of step k0)
+    const int c0 = k0 + seg * kWaveSeg + 4 * l;
     uint32_t w = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int t = c0 + k;
-      const uint32_t ch = (t < nb) ? (uint32_t)lut_s[P.b[t]] : other;     // beyond the stream: matches nothing
+      const uint32_t ch = ((uint32_t)t < (uint32_t)nb && (seg >= 0 || l >= 12)) ? (uint32_t)lut_s[P.b[t]] : other;   // outside the stream: matches nothing
       w |= ch << (8 * k);
     }
     return w;
   };
-  int steps = nb + 16;
+  int steps = nb - k0 + 16;
   steps = max(steps, __shfl_xor(steps, 16));
   steps = max(steps, __shfl_xor(steps, 32));
   const int nseg = (steps + kWaveSeg - 1) / kWaveSeg;
 
   uint32_t nextc = stage_load(0);
-  if (l < 4) buf32[l] = other * 0x01010101u;
+  {
+    // history: the 16 positions in front of the first step (lanes 12..15 of stage_load(-1) cover k0 - 16 .. k0 - 1)
+    const uint32_t hw = stage_load(-1);
+    const uint32_t h4 = (uint32_t)__shfl((int)hw, 12 + (l & 3), 16);
+    if (l < 4) buf32[l] = h4;
+  }
   buf32[4 + l] = nextc;
   nextc = stage_load(1);
 
   float gv = sa.gap_s;
   asm volatile("" : "+v"(gv));                                     // (a VGPR operand: v_sub_f32 then issues at the double rate)
   float H[R], Hg[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) { H[r] = 0.0f; Hg[r] = -gv; }
   uint32_t up_prev = 0;
+  if (DIRS && !TRACK && k0 > 0 && P.ckpt != nullptr) {
+    const float *ck = P.ckpt + (size_t)l * (R + 1);
+#pragma unroll
+    for (int r = 0; r < R; ++r) { H[r] = ck[r]; Hg[r] = H[r] - gv; }
+    up_prev = __float_as_uint(ck[R]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) { H[r] = 0.0f; Hg[r] = -gv; }
+  }
   float blk = 0.0f;                                                // TRACK: this lane's best key (value | 31 - column in the lane) ...
   int tl = 0;                                                      // ... and the stream position it was first seen at
   const float *prof_lane = prof + l * LS;
@@ -331,7 +349,7 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
   for (int seg = 0; seg < nseg; ++seg) {
 #pragma unroll 4
     for (int k = 0; k < kWaveSeg; ++k) {
-      const int t = seg * kWaveSeg + k - l;                        // this lane's stream position
+      const int t = k0 + seg * kWaveSeg + k - l;                   // this lane's stream position
       const uint32_t c = (uint32_t)buf_lane[k];
       const u32x4 *pp = static_cast<const u32x4 *>(__builtin_assume_aligned(prof_lane + c * (16 * LS), 16));
       uint32_t p[NQ4 * 4];
@@ -409,6 +427,15 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
         }
       }
     }
+    if (TRACK && !DIRS) {
+      // the slot's wavefront as it stands after step 64 (seg + 1) - 1: what a later launch needs to resume there
+      if (P.ckpt != nullptr && (seg + 1) * kWaveSeg < nb + 16) {
+        float *ck = P.ckpt + ((size_t)seg * 16 + (size_t)l) * (R + 1);
+#pragma unroll
+        for (int r = 0; r < R; ++r) ck[r] = H[r];
+        ck[R] = __uint_as_float(up_prev);
+      }
+    }
     const uint32_t hist = buf32[kWaveSeg / 4 + (l & 3)];
     if (l < 4) buf32[l] = hist;
     buf32[4 + l] = nextc;
@@ -444,7 +471,9 @@ struct WaveWalk {
   int32_t na, nb, orient;
   int32_t R;               // rows per lane of the instance that wrote dirs
   int32_t lanes;           // lanes that share one stream position in dirs
-  int32_t skew;            // 1: the decisions of (stream position t, lane) are in row t + lane (sw_wave_kernel); 0: in row t
+  int32_t skew;            // 1: the decisions of (stream position t, lane) are in row t + lane - row0 (sw_wave_kernel); 0: in row t
+  int32_t row0;            // skew = 1: the step the decision rows start at (a resumed problem, sw_wave_prof_kernel); a cell in
+                           // front of it is outside the window (status 1)
   float need_slope;        // > 0: a cell with lane-side index a is already exact a + ceil(a * need_slope) + 2 stream
                            // positions into the window (DESIGN.md §3.3 for a path confined to a rows/columns)
   int64_t b_offset;        // as WaveProblem
@@ -496,7 +525,9 @@ __global__ void sw_wave_walk_kernel(const WaveWalk *probs, int n, char *cons, co
     if (len >= W.cap) { status = 2; break; }
     const int lane = (int)((aidx - 1) / W.R), r = (int)((aidx - 1) % W.R);
     const int wd = (W.R + 15) / 16;
-    const int dir = (int)((W.dirs[((size_t)(t + W.skew * lane) * (size_t)W.lanes + (size_t)lane) * wd + (r >> 4)] >> (2 * (r & 15))) & 3u);
+    const long long row = W.skew ? t + lane - W.row0 : t;
+    if (row < 0) { status = 1; break; }                            // in front of a resumed problem's first step
+    const int dir = (int)((W.dirs[((size_t)row * (size_t)W.lanes + (size_t)lane) * wd + (r >> 4)] >> (2 * (r & 15))) & 3u);
     if (dir == kDirStop) {
       if (WRITE) { cons_x[len] = (char)W.x[ix - 1]; cons_y[len] = (char)W.y[iy - 1]; }
       ++len;
@@ -552,7 +583,8 @@ __global__ __launch_bounds__(64) void sw_wave_walk_long_kernel(const WaveWalk *p
       else if (len + p >= W.cap) code = 5;
       else {
         const int lane = (int)((cx - 1) / W.R), r = (int)((cx - 1) % W.R);
-        code = (int)((W.dirs[((size_t)(t + W.skew * lane) * (size_t)W.lanes + (size_t)lane) * wd + (r >> 4)] >> (2 * (r & 15))) & 3u);
+        const long long row = W.skew ? t + lane - W.row0 : t;
+        code = row < 0 ? 4 : (int)((W.dirs[((size_t)row * (size_t)W.lanes + (size_t)lane) * wd + (r >> 4)] >> (2 * (r & 15))) & 3u);
       }
     }
     const unsigned long long other = __ballot(code != kDirNW);

@@ -68,7 +68,8 @@ def fuzz_cases(pgs, oracle):
 # every switch that selects another kernel instance / pipeline for the same answer
 SWITCHES = ["no_f16", "no_unsat", "no_sample", "no_satflag", "no_solo", "no_wave", "no_comb", "no_twin", "no_wide",
             "no_strip", "no_quant", "no_f16_wide", "no_devlist", "no_strip_groups", "u8_long_twin", "long_twin", "no_long",
-            "no_requery", "slot=16", "strip_r=24", "few_r=5", "long_pipes=2", "no_long_p32", "long_groups=2", "force_f32", "no_opt_margin", "no_wave_prof"]
+            "no_requery", "slot=16", "strip_r=24", "few_r=5", "long_pipes=2", "no_long_p32", "long_groups=2", "force_f32", "no_opt_margin", "no_wave_prof",
+            "no_wave_window"]
 
 
 def test_option_names_cover_the_switch_list(pgs):
@@ -451,3 +452,57 @@ def test_optimistic_margin_is_certified_or_swept_again(pgs, oracle):
     finally:
         c.close()
         c2.close()
+
+
+@pytest.mark.parametrize("ylen", [144, 300, 500])
+def test_small_alignment_batch_windows(pgs, oracle, ylen):
+    """The many-small-alignments batch with traceback on sw_wave_prof_kernel: checkpointed first pass + decisions for a window in
+    front of each argmax (host_batch.h).  Database sequences that make the walk do everything it can: unrelated ones (short walks),
+    the second sequence planted at the start / in the middle / at the very end of a long x (argmax inside the first window,
+    across a checkpoint, walks LONGER than a window -> the host-driven path takes the problem), mutated copies with indels,
+    lengths around the 64-row checkpoints, empty and one-letter sequences.  Every field against the oracle, and the same call
+    with whole-problem decisions (option no_wave_window) and with the compare-and-select kernel (no_wave_prof)."""
+    rng = np.random.default_rng(4242 + ylen)
+    y = pgs.synth.protein(77 + ylen, ylen).tobytes()
+    xs = [b"", b"A", y[:1], y, y[:40], y[-40:]]
+    for m in (1, 2, 15, 16, 17, 63, 64, 65, 111, 112, 113, 127, 128, 129, 191, 192, 193, 255, 256, 257, 400, 1000, 3000):
+        xs.append(pgs.synth.protein(9000 + m, m).tobytes())                     # unrelated
+    for k, m in enumerate((300, 700, 1500, 4000)):
+        base = bytearray(pgs.synth.protein(9500 + k, m).tobytes())
+        cut = [y, y[: ylen // 2], y[ylen // 3:], y[10:60]][k % 4]
+        for at in (0, m // 2 - 7, m - len(cut)):
+            x = bytearray(base)
+            x[at:at + len(cut)] = cut
+            xs.append(bytes(x))
+            # a diverged copy with substitutions and a few indels: a long walk with gaps
+            c = bytearray(cut)
+            for i in rng.choice(len(c), max(1, len(c) // 12), replace=False):
+                c[i] = b"ACDEFGHIKLMNPQRSTVWY"[int(rng.integers(0, 20))]
+            for i in sorted(rng.choice(len(c) - 2, 3, replace=False), reverse=True):
+                if rng.random() < 0.5:
+                    del c[i]
+                else:
+                    c.insert(i, b"ACDEFGHIKLMNPQRSTVWY"[int(rng.integers(0, 20))])
+            x = bytearray(base)
+            x[at:at + len(c)] = c
+            xs.append(bytes(x[:m]) if at + len(c) > m else bytes(x))
+    xs.append((y * 6)[:5 * ylen + 17])                                          # tandem copies: ties between equal maxima
+    exp = [oracle.align(x, y, 0) for x in xs]
+    c = pgs.Context(0)
+    try:
+        for var in ({}, {"no_wave_window": 1}, {"no_wave_prof": 1}):
+            for k, v in var.items():
+                c.set_option(k, v)
+            got = c.align_batch(xs, y, semantics=0)
+            for k, (g, e) in enumerate(zip(got, exp)):
+                _cmp(g, e, "windows |y|=%d x[%d] |x|=%d %r" % (ylen, k, len(xs[k]), var))
+            left = c.last_counters()["left_window"]
+            assert (left >= 8) if not var else (left == 0), (var, left)         # the planted copies walk further than a window
+            for k in var:
+                c.set_option(k, None)
+        # other dyadic scorings on the same batch (other scale; a cheap gap: long gapped walks)
+        for sc in ((2.0, -1.0, 0.5), (5.0, -4.0, 3.0)):
+            for g, x in zip(c.align_batch(xs, y, semantics=0, match=sc[0], mismatch=sc[1], gap=sc[2]), xs):
+                _cmp(g, oracle.align(x, y, 0, *sc), "windows |y|=%d |x|=%d scoring %r" % (ylen, len(x), sc))
+    finally:
+        c.close()
