@@ -363,6 +363,17 @@ def extra_repeat_rich(pgs, device, args, headline_gcups):
                          "whole_batch_swept_again": cnt["whole_batch_again"], "candidate_subchunks": cnt["candidates"],
                          "score_kernel_ms": tm["score_us"] * 1e-3, "locate_ms": tm["locate_us"] * 1e-3, "traceback_ms": tm["trace_us"] * 1e-3,
                          "reads_found_at_their_origin": found, "kernel": ctx.last_kernel()["name"]}
+            if sem == pgs.U8SAT:
+                # the uint8 engine settles reads over their candidate cap by their first candidates in order: check the whole
+                # batch once against the path that sweeps every such read a second time on the exact instances
+                out[name]["settled_by_first_candidates"] = cnt["first_settled"]
+                ctx.set_option("no_first")
+                ref_res = ctx.batch_run(semantics=sem, raw=True)
+                swept = ctx.last_counters()["requeried"]
+                ctx.set_option("no_first", None)
+                fields = ("score", "pos", "end_x", "end_y", "cons_len")
+                out[name]["parity_vs_second_sweep"] = {"queries_swept_again_there": swept, "fields": list(fields),
+                                                       "mismatches": int(sum(int(np.sum(res[f] != ref_res[f])) for f in fields))}
         return out
     finally:
         ctx.close()

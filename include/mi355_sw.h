@@ -208,6 +208,10 @@ int mi355_sw_last_timings(const mi355_sw_ctx *ctx, double out[6]);
  * many-small-alignments batch that left the decision window in front of their argmax and were redone on whole-problem decisions
  * (DESIGN.md §4.3). */
 int mi355_sw_last_counters(const mi355_sw_ctx *ctx, uint64_t out[4]);
+/* One counter of the last call by name: "requeried", "whole_batch_again", "candidates", "left_window" (= [0..3] above) and
+ * "first_settled" — uint8 engine: queries over their candidate cap whose first candidates, evaluated in order, settled them
+ * without a second sweep.  MI355_SW_EINVAL for an unknown name. */
+int mi355_sw_last_counter(const mi355_sw_ctx *ctx, const char *name, uint64_t *out);
 
 /* Which sw_score_kernel instance swept the most cells in the last call (what the `iterate` of
  * similaritymatrix.cpp:99-264 / :386-561 became for this input): reporting aid for drivers and bench.py, so

@@ -20,7 +20,7 @@ EXPORTS = [
     "mi355_sw_multi_create", "mi355_sw_multi_destroy", "mi355_sw_multi_last_error", "mi355_sw_multi_device_count",
     "mi355_sw_multi_rccl_version", "mi355_sw_multi_align_split", "mi355_sw_multi_set_reference",
     "mi355_sw_multi_align_batch", "mi355_sw_multi_last_timings",
-    "mi355_sw_set_option", "mi355_sw_option_names", "mi355_sw_multi_set_option", "mi355_sw_last_counters", "mi355_sw_batch_upload_packed", "mi355_sw_best_range",
+    "mi355_sw_set_option", "mi355_sw_option_names", "mi355_sw_multi_set_option", "mi355_sw_last_counters", "mi355_sw_last_counter", "mi355_sw_batch_upload_packed", "mi355_sw_best_range",
 ]
 MULTI_RCCL = 1
 
@@ -306,7 +306,11 @@ class Context:
         """Candidate-filter counters of the last call (mi355_sw_last_counters)."""
         c = (C.c_uint64 * 4)()
         self._L.mi355_sw_last_counters(self._ctx, c)
-        return dict(requeried=int(c[0]), whole_batch_again=int(c[1]), candidates=int(c[2]), left_window=int(c[3]))
+        out = dict(requeried=int(c[0]), whole_batch_again=int(c[1]), candidates=int(c[2]), left_window=int(c[3]))
+        v = C.c_uint64(0)
+        self._chk(self._L.mi355_sw_last_counter(self._ctx, b"first_settled", C.byref(v)))
+        out["first_settled"] = int(v.value)
+        return out
 
     def last_kernel(self):
         """The sw_score_kernel instance that swept the most cells in the last call (mi355_sw_last_kernel)."""

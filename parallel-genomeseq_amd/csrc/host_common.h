@@ -14,7 +14,7 @@ constexpr size_t kExactLdsMax = 159 * 1024;    // dynamic part; the wide instanc
 #define MI355_SW_BOOL_OPTIONS(X) \
   X(no_f16) X(no_unsat) X(no_sample) X(no_satflag) X(no_solo) X(no_wave) X(no_comb) X(no_twin) X(no_wide) X(no_strip) \
   X(no_quant) X(no_f16_wide) X(no_devlist) X(no_ref_cache) X(no_strip_groups) X(u8_long_twin) X(long_twin) X(no_long) \
-  X(no_requery) X(force_f32) X(no_long_p32) X(no_opt_margin) X(no_wave_prof) X(no_wave_window) X(trace)
+  X(no_requery) X(force_f32) X(no_long_p32) X(no_opt_margin) X(no_wave_prof) X(no_wave_window) X(no_first) X(trace)
 #define MI355_SW_INT_OPTIONS(X) X(strip_r) X(slot) X(few_r) X(chunk) X(long_pipes) X(long_wgs) X(long_sub) X(long_r) X(long_groups)
 struct Options {
 #define X(n) bool n = false;
@@ -255,6 +255,8 @@ struct mi355_sw_ctx {
   QueryBatch one;                 // the single query of such a call
   // scratch
   uint32_t flag_cap = 0;          // entries of `flags` (score_begin)
+  bool first_valid = false;       // sw_sample_first ran in this score pass (ctx->first holds the offenders' first candidates)
+  size_t first_settled = 0;       // queries over their candidate cap that their first candidates settled (uint8 engine)
   size_t left_window = 0;         // walks of the running call that left their decision window (host_batch.h) and were redone whole
   size_t requeried = 0;           // queries of the running call that were swept a second time on the exact instances
   size_t whole_again = 0;         // ... times the whole batch was (most of it exceeded its candidate cap)
@@ -266,7 +268,7 @@ struct mi355_sw_ctx {
   float long_cert = -1.0f;        // maxima ABOVE this value were swept exactly by the last sw_long_kernel launch (-1: all of them)
   int64_t long_nsub = 0;          // sub-chunks per range of the last sampled sw_long_kernel launch (decodes its flag entries)
   bool long_launched = false;     // a sw_long_kernel launch since the last score_fetch (its status word is flags[1])
-  DevBuf qcnt, sel2, gcnt, wlut, ckpt, keys, ranges, stab, ftab, ftab_s, htab, htab8, soloblk, flags, submax, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs, scan;
+  DevBuf qcnt, sel2, gcnt, wlut, ckpt, first, keys, ranges, stab, ftab, ftab_s, htab, htab8, soloblk, flags, submax, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs, scan;
   // host sides of small per-call uploads: they must outlive the asynchronous copies, and the tables are only
   // sent again when they change
   std::vector<int64_t> h_ranges;

@@ -573,6 +573,54 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       std::vector<int> offenders;
       for (size_t k = 0; k < nq; ++k) if (qsat[k] && qcount[k] > qcap) offenders.push_back((int)k);
       if (trace_on) std::fprintf(stderr, "[mi355_sw] %zu of %zu queries exceed %u candidates\n", offenders.size(), nsatq, qcap);
+      // uint8 engine, key at the cap of 255: the answer is the 255 that comes first in the skewed storage order, i.e. on the
+      // lowest anti-diagonal i + j.  Sub-chunks are longer than |x| + 64, so that cell lies in the first sub-chunk s1 that truly
+      // holds a 255 or in s1 + 1; a sub-chunk that is no candidate holds none (its unsaturated maximum stays below 255, and the
+      // saturating rule never exceeds the unsaturated one).  sw_sample_first listed the query's first candidates in order:
+      // evaluate them exactly; when a 255 turns up and every candidate up to two sub-chunks right of the winner was on the
+      // list, the query is settled without a second sweep (a read inside a repeat family: thousands of equal candidates).
+      if (!offenders.empty() && ctx->first_valid && p.semantics == MI355_SW_U8SAT) {
+        constexpr int K = kFirstCandidates;
+        std::vector<uint32_t> first(nq * (size_t)(K + 1));
+        HIPCHK(ctx, hipMemcpy(first.data(), ctx->first.p, first.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<std::pair<uint32_t, uint32_t>> ff;
+        std::vector<int> tried;
+        std::vector<float> qlow(nq, 0.0f);
+        for (int id : offenders) {
+          if (qsat[id] != 2 || qfloat[id] != 2 || qchunk[id] <= (int64_t)q.len[id] + 64) continue;
+          if (half_value((uint16_t)(keys[id] >> 32)) * kF16Scale != 255.0f) continue;
+          const uint32_t *f = &first[(size_t)id * (K + 1)];
+          const uint32_t cnt = f[0] & 0x7FFFFFFFu;
+          if (cnt == 0 || cnt > (uint32_t)K) continue;
+          for (uint32_t e = 0; e < cnt; ++e) ff.push_back({(uint32_t)id, f[1 + e]});
+          tried.push_back(id);
+          qlow[id] = 255.0f;
+        }
+        if (!ff.empty()) {
+          HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+          rc = locate_saturated(ctx, ref, q, rg, p, qchunk, qwarm, qlow, table, ff, loc, qdone);
+          if (rc) return rc;
+          HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+          ctx->timings[1] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
+          std::vector<char> settled(nq, 0);
+          size_t nsettled = 0;
+          for (int id : tried) {
+            const uint32_t *f = &first[(size_t)id * (K + 1)];
+            const uint32_t cnt = f[0] & 0x7FFFFFFFu;
+            bool ok = qdone[id] && loc[id].score == 255.0f;
+            if (ok && (f[0] & 0x80000000u)) ok = (int64_t)f[cnt] >= (loc[id].iy - 1) / qchunk[id] + 2;   // f[cnt]: the last one listed
+            if (ok) { settled[id] = 1; ++nsettled; }
+            else { loc[id] = Located(); qdone[id] = 0; }
+          }
+          if (nsettled) {
+            flagged.erase(std::remove_if(flagged.begin(), flagged.end(), [&](const std::pair<uint32_t, uint32_t> &f) { return f.first < nq && settled[f.first]; }),
+                          flagged.end());
+            offenders.erase(std::remove_if(offenders.begin(), offenders.end(), [&](int id) { return settled[id] != 0; }), offenders.end());
+            ctx->first_settled += nsettled;
+          }
+          if (trace_on) std::fprintf(stderr, "[mi355_sw] %zu of %zu offenders settled by their first candidates\n", nsettled, tried.size());
+        }
+      }
       if (!offenders.empty() && (opt().no_requery || 2 * offenders.size() > nsatq)) { whole_batch_again(); continue; }
       if (!offenders.empty()) {
         flagged.erase(std::remove_if(flagged.begin(), flagged.end(), [&](const std::pair<uint32_t, uint32_t> &f) { return qcount[f.first] > qcap; }),
@@ -918,7 +966,7 @@ void reset_timings(mi355_sw_ctx *ctx) {
   for (double &t : ctx->timings) t = 0;
   ctx->score_ev_used = 0; ctx->arenas.clear(); ctx->cons_used = 0;
   ctx->last_kernel = mi355_sw_kernel_info{};
-  ctx->requeried = 0; ctx->whole_again = 0; ctx->candidates = 0; ctx->left_window = 0;
+  ctx->requeried = 0; ctx->whole_again = 0; ctx->candidates = 0; ctx->left_window = 0; ctx->first_settled = 0;
 }
 
 }  // namespace

@@ -641,7 +641,9 @@ int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range>
   // room for the flagged (query, sub-chunk) pairs: a few per query (sampled / saturating sweeps), at least kFlagCap
   // (the filter of the sampled sweeps appends at most query_flag_cap + 1 entries per query: its list cannot overflow)
   ctx->flag_cap = (uint32_t)std::min<size_t>(0x7FFFFFFFu, std::max<size_t>(kFlagCap, (size_t)(query_flag_cap(q.nq) + 2) * q.nq + 4096));
-  if (ctx->flags.ensure(8 + (size_t)ctx->flag_cap * 8) || ctx->qcnt.ensure(q.nq * 4 + 16))
+  ctx->first_valid = false;
+  if (ctx->flags.ensure(8 + (size_t)ctx->flag_cap * 8) || ctx->qcnt.ensure(q.nq * 4 + 16) ||
+      ctx->first.ensure(q.nq * (size_t)(kFirstCandidates + 1) * 4 + 16))
     return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(score scratch) failed");
   HIPCHK(ctx, hipMemsetAsync(ctx->flags.p, 0, 8, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->qcnt.p, 0, q.nq * 4, ctx->stream));
@@ -953,6 +955,14 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
                            (const int32_t *)a.qsel, a.qfirst + f0, fc, (const unsigned long long *)a.keys, 3.0f * (float)t.gap,
                            ctx->flags.as<unsigned int>(), reinterpret_cast<uint2 *>(ctx->flags.as<unsigned int>() + 2), ctx->flag_cap,
                            ctx->qcnt.as<unsigned int>(), query_flag_cap(q.nq));
+      // uint8 engine: the first candidates, in order, of the queries over their cap (settled without a second sweep when the
+      // key sits at 255, align_range_core)
+      if (b.unsat && b.sem != kSemF32 && nr == 1 && !opt().no_first) {
+        hipLaunchKernelGGL(sw_sample_first<false>, dim3((unsigned)fc), dim3(64), 0, ctx->stream, rows, nsub, nsub,
+                           (const int32_t *)a.qsel, a.qfirst + f0, fc, (const unsigned long long *)a.keys, 3.0f * (float)t.gap,
+                           (const unsigned int *)ctx->qcnt.as<unsigned int>(), query_flag_cap(q.nq), 0u, ctx->first.as<uint32_t>());
+        ctx->first_valid = true;
+      }
       HIPCHK(ctx, hipGetLastError());
     }
   }

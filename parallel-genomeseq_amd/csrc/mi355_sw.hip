@@ -84,7 +84,7 @@ void mi355_sw_destroy(mi355_sw_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   DevBuf *bufs[] = {&c->qcnt, &c->sel2, &c->gcnt, &c->wlut, &c->ref.bytes, &c->ref.codes, &c->batch.bytes, &c->batch.lens, &c->keys, &c->ranges, &c->stab,
-                    &c->batch.offs, &c->batch.sel, &c->ftab, &c->ftab_s, &c->htab, &c->htab8, &c->soloblk, &c->flags, &c->submax, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow, &c->wprobs, &c->scan, &c->batch.cum, &c->ckpt};
+                    &c->batch.offs, &c->batch.sel, &c->ftab, &c->ftab_s, &c->htab, &c->htab8, &c->soloblk, &c->flags, &c->submax, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow, &c->wprobs, &c->scan, &c->batch.cum, &c->ckpt, &c->first};
   for (DevBuf *b : bufs) b->release();
   c->adhoc.release(); c->one.release();
   c->pin_probs.release(); c->pin_walk.release(); c->pin_out.release(); c->pin_solo_up.release(); c->pin_solo_down.release();
@@ -449,6 +449,18 @@ int mi355_sw_last_timings(const mi355_sw_ctx *ctx, double out[6]) {
 int mi355_sw_last_counters(const mi355_sw_ctx *ctx, uint64_t out[4]) {
   if (!ctx || !out) return MI355_SW_EINVAL;
   out[0] = ctx->requeried; out[1] = ctx->whole_again; out[2] = ctx->candidates; out[3] = ctx->left_window;
+  return 0;
+}
+
+int mi355_sw_last_counter(const mi355_sw_ctx *ctx, const char *name, uint64_t *out) {
+  if (!ctx || !name || !out) return MI355_SW_EINVAL;
+  const std::string k(name);
+  if (k == "requeried") *out = ctx->requeried;
+  else if (k == "whole_batch_again") *out = ctx->whole_again;
+  else if (k == "candidates") *out = ctx->candidates;
+  else if (k == "left_window") *out = ctx->left_window;
+  else if (k == "first_settled") *out = ctx->first_settled;
+  else return MI355_SW_EINVAL;
   return 0;
 }
 

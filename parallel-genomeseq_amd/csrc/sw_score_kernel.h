@@ -699,4 +699,44 @@ __global__ __launch_bounds__(256) void sw_sample_filter(const void *submax, int6
   }
 }
 
+// The FIRST candidates, in ascending sub-chunk order, of the queries that exceeded their cap in sw_sample_filter (one wavefront
+// per query position; everybody else returns at once).  The uint8 engine's maximum is capped at 255: a query whose key sits at the
+// cap is decided by the first sub-chunk that truly holds a 255 and its right neighbour (the skewed storage order runs along
+// anti-diagonals, host_pipeline.h), so its first few candidates usually settle it without a second sweep.
+// first[q * (K + 1)]: count (bit 31: the scan stopped before the end of the row), then the sub-chunk indices.
+constexpr int kFirstCandidates = 8;
+template <bool F32V>
+__global__ __launch_bounds__(64) void sw_sample_first(const void *submax, int64_t stride, int64_t nsub, const int32_t *qsel,
+                                                      int qfirst, int qcount, const unsigned long long *keys, float slack,
+                                                      const unsigned int *qcnt, uint32_t per_query_cap, uint32_t sub_offset,
+                                                      uint32_t *first) {
+  constexpr int K = kFirstCandidates;
+  const int pos = blockIdx.x;
+  if (pos >= qcount) return;
+  const int q = qsel[qfirst + pos];
+  if (qcnt[q] <= per_query_cap) return;
+  const float best = F32V ? __uint_as_float((uint32_t)(keys[q] >> 32))
+                          : (float)__builtin_bit_cast(_Float16, (uint16_t)(keys[q] >> 32)) * 2048.0f;
+  const float thr = best - slack;
+  const int lane = threadIdx.x;
+  uint32_t *out = first + (size_t)q * (K + 1);
+  int n = 0;
+  int64_t base = 0;
+  for (; base < nsub && n < K; base += 64) {
+    const int64_t s = base + lane;
+    float v = 0.0f;
+    if (s < nsub) {
+      const size_t at = (size_t)pos * (size_t)stride + (size_t)s;
+      v = F32V ? __uint_as_float(static_cast<const uint32_t *>(submax)[at])
+               : (float)__builtin_bit_cast(_Float16, static_cast<const uint16_t *>(submax)[at]) * 2048.0f;
+    }
+    const bool hit = v > 0.0f && v >= thr;
+    const unsigned long long mask = __ballot(hit);
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    if (hit && n + rank < K) out[1 + n + rank] = (uint32_t)s + sub_offset;
+    n += __popcll(mask);
+  }
+  if (lane == 0) out[0] = (uint32_t)(n < K ? n : K) | ((base < nsub || n > K) ? 0x80000000u : 0u);
+}
+
 }  // namespace mi355sw

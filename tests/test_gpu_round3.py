@@ -69,7 +69,7 @@ def fuzz_cases(pgs, oracle):
 SWITCHES = ["no_f16", "no_unsat", "no_sample", "no_satflag", "no_solo", "no_wave", "no_comb", "no_twin", "no_wide",
             "no_strip", "no_quant", "no_f16_wide", "no_devlist", "no_strip_groups", "u8_long_twin", "long_twin", "no_long",
             "no_requery", "slot=16", "strip_r=24", "few_r=5", "long_pipes=2", "no_long_p32", "long_groups=2", "force_f32", "no_opt_margin", "no_wave_prof",
-            "no_wave_window"]
+            "no_wave_window", "no_first"]
 
 
 def test_option_names_cover_the_switch_list(pgs):
@@ -305,8 +305,23 @@ def test_per_query_fallback_on_repeat_rich_reference(pgs, oracle, sem):
         for k, (g, e) in enumerate(zip(got, exp)):
             _cmp(g, e, "repeat-rich sem=%d read %d%s" % (sem, k, " (repeat)" if k in which else ""))
         # (reads that merely overlap a repeat copy may exceed their cap too — in the uint8 engine every hit of >= 83 bp saturates)
-        assert 1 <= cnt["requeried"] < len(qs) // 2 and cnt["whole_batch_again"] == 0, cnt
+        assert cnt["whole_batch_again"] == 0 and cnt["requeried"] < len(qs) // 2, cnt
+        if sem == 1:
+            # uint8 engine: most offenders are settled by their first candidates in order (key at 255); without that step
+            # (option no_first) every offender is swept again — same answers
+            assert cnt["first_settled"] >= 1, cnt
+            settled = cnt["first_settled"] + cnt["requeried"]
+            c.set_option("no_first")
+            got = c.align_batch(qs, refb, semantics=sem)
+            cnt = c.last_counters()
+            c.set_option("no_first", None)
+            for k, (g, e) in enumerate(zip(got, exp)):
+                _cmp(g, e, "repeat-rich, no_first, read %d" % k)
+            assert cnt["first_settled"] == 0 and cnt["requeried"] == settled, (cnt, settled)
+        else:
+            assert 1 <= cnt["requeried"] and cnt["first_settled"] == 0, cnt
         c.set_option("no_requery")
+        c.set_option("no_first")                                                # (else nobody is left over its cap in the uint8 engine)
         got = c.align_batch(qs, refb, semantics=sem)
         cnt = c.last_counters()
         for k, (g, e) in enumerate(zip(got, exp)):
