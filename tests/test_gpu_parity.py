@@ -18,6 +18,14 @@ def ctx(pgs):
     c.close()
 
 
+def _pmap(fn, items, workers=8):
+    """fn over items on a few threads (the oracle is a C library behind ctypes: its calls release the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    items = list(items)
+    with ThreadPoolExecutor(workers) as ex:
+        return list(ex.map(fn, items))
+
+
 def _cmp(got, exp, what):
     assert abs(got["score"] - exp["score"]) <= SCORE_TOL, "%s: score %r != %r" % (what, got["score"], exp["score"])
     for k in ("pos", "end_x", "end_y", "cons_x", "cons_y"):
@@ -230,7 +238,7 @@ def test_multi_context_vs_oracle(oracle, pgs):
         reads = [pgs.synth.read_from_ref(refa, 900 + k, [33, 64, 150, 151, 400, 700][k % 6])[0].tobytes() for k in range(40)]
         for sem in (0, 1):
             res, best = m.align_batch(reads, ref, semantics=sem)
-            exp = [oracle.align(r, ref, sem) for r in reads]
+            exp = _pmap(lambda r: oracle.align(r, ref, sem), reads)
             for g, e in zip(res, exp):
                 _cmp(g, e, ("multi batch", sem))
             scores = [e["score"] for e in exp]
@@ -426,7 +434,7 @@ def test_non_dyadic_fractional_scoring(ctx, oracle, pgs):
     bad = []
     for sc in (dict(match=0.7, mismatch=-0.3, gap=0.1), dict(match=0.1, mismatch=-0.3, gap=0.7),
                dict(match=1.1, mismatch=-0.9, gap=0.37), dict(match=3.3, mismatch=-3.3, gap=2.2)):
-        exp = [oracle.align(q, refb, 0, **sc) for q in reads]
+        exp = _pmap(lambda q: oracle.align(q, refb, 0, **sc), reads)
         got = ctx.align_batch(reads, refb, semantics=0, **sc)
         assert ctx.last_kernel()["dtype"] == "f32" and ctx.last_kernel()["cells"] > 0        # the tiled float32 instance ran
         got += [ctx.align(q, refb, 0, **sc) for q in reads[1:4]]
@@ -436,7 +444,7 @@ def test_non_dyadic_fractional_scoring(ctx, oracle, pgs):
             if any(g[k] != e[k] for k in ("score", "pos", "end_x", "end_y", "cons_x", "cons_y")):
                 bad.append((sc, len(e["cons_x"]), g["score"], e["score"], g["pos"], e["pos"]))
     lut = (pgs.synth.make_lut(4711, 1.0) * np.float32(0.37)).astype(np.float32)
-    exp = [oracle.align(q, refb, 0, gap=0.53, lut=lut) for q in reads]
+    exp = _pmap(lambda q: oracle.align(q, refb, 0, gap=0.53, lut=lut), reads)
     for g, e in zip(ctx.align_batch(reads, refb, semantics=0, gap=0.53, lut=lut), exp):
         worst = max(worst, abs(g["score"] - e["score"]))
         if any(g[k] != e[k] for k in ("score", "pos", "end_x", "end_y", "cons_x", "cons_y")):
@@ -876,7 +884,7 @@ def test_u8_unsaturated_sweep_edges(ctx, oracle, pgs):
     refb = bytes(refb)
     for sc in (dict(), dict(match=5.0, mismatch=-4.0, gap=3.0), dict(match=2.0, mismatch=0.0, gap=1.0),
                dict(match=255.0, mismatch=-255.0, gap=200.0), dict(match=7.9, mismatch=-1.2, gap=1.99)):
-        exp = [oracle.align(q, refb, 1, **sc) for q in reads]
+        exp = _pmap(lambda q: oracle.align(q, refb, 1, **sc), reads)
         got = ctx.align_batch(reads, refb, semantics=1, **sc)
         for k, (g, e) in enumerate(zip(got, exp)):
             _cmp(g, e, ("u8 batch", sc, k))
@@ -936,7 +944,7 @@ def test_float_engine_saturating_sweep(ctx, oracle, pgs):
              bytes(ref[80_000:80_700]), pgs.synth.dna(302, 900).tobytes(),
              pgs.synth.read_from_ref(refa, 303, 1200, sub_rate=0.05, indel_rate=0.01)[0].tobytes(),
              pgs.synth.read_from_ref(refa, 304, 2000, sub_rate=0.25, indel_rate=0.05)[0].tobytes()]
-    exp = [oracle.align(q, refb, 0) for q in reads]
+    exp = _pmap(lambda q: oracle.align(q, refb, 0), reads)
     got = ctx.align_batch(reads, refb, semantics=0)
     name = ctx.last_kernel()["name"]
     for k, (g, e) in enumerate(zip(got, exp)):

@@ -7,6 +7,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _pmap(fn, items, workers=8):
+    """fn over items on a few threads (the oracle is a C library behind ctypes: its calls release the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    items = list(items)
+    with ThreadPoolExecutor(workers) as ex:
+        return list(ex.map(fn, items))
+
+
 def _cmp(got, exp, what):
     assert got["score"] == exp["score"], "%s: score %r != %r" % (what, got["score"], exp["score"])
     for k in ("pos", "end_x", "end_y", "cons_x", "cons_y"):
@@ -47,7 +55,8 @@ def fuzz_cases(pgs, oracle):
             q = pgs.synth.dna(int(rng.integers(1, 1 << 30)), m).tobytes()
         sem = int(rng.integers(0, 2))
         sc = scorings[int(rng.integers(0, len(scorings)))]
-        singles.append((q, ref, sem, sc, oracle.align(q, ref, sem, *sc)))
+        singles.append((q, ref, sem, sc))
+    singles = [a + (e,) for a, e in zip(singles, _pmap(lambda a: oracle.align(a[0], a[1], a[2], *a[3]), singles))]
     batches = []
     ref = pgs.synth.dna(5151, 70_000)
     refb = ref.tobytes()
@@ -56,12 +65,13 @@ def fuzz_cases(pgs, oracle):
     qs += [b"", pgs.synth.dna(99, 150).tobytes()]
     for sem in (0, 1):
         for sc in ((3.0, -3.0, 2.0), (3.5, -3.25, 2.0)):
-            batches.append((qs, refb, sem, sc, [oracle.align(q, refb, sem, *sc) for q in qs]))
+            batches.append((qs, refb, sem, sc, _pmap(lambda q: oracle.align(q, refb, sem, *sc), qs)))
     lone = []
     for k, m in enumerate((700, 1500, 2100, 3000)):
         q = pgs.synth.read_from_ref(ref, 6100 + k, m, sub_rate=0.02, indel_rate=0.004)[0].tobytes()
         for sem in (0, 1):
-            lone.append((q, refb, sem, (3.0, -3.0, 2.0), oracle.align(q, refb, sem)))
+            lone.append((q, refb, sem, (3.0, -3.0, 2.0)))
+    lone = [a + (e,) for a, e in zip(lone, _pmap(lambda a: oracle.align(a[0], a[1], a[2]), lone))]
     return singles, batches, lone
 
 
@@ -133,10 +143,11 @@ def test_long_kernel_vs_oracle(pgs, oracle, sem):
             rng = np.random.default_rng(100 + k)
             for i in rng.choice(m, m // 50, replace=False):
                 q[i] = b"ACGT"[int(rng.integers(0, 4))]
-            q = bytes(q).replace(b"N", b"A")
-            cases.append((q, oracle.align(q, refb, sem)))
+            cases.append(bytes(q).replace(b"N", b"A"))
         unrelated = pgs.synth.dna(7100 + sem, 4000).tobytes()                   # background maximum
-        unrelated_exp = oracle.align(unrelated, refb, sem)
+        exps = _pmap(lambda q: oracle.align(q, refb, sem), cases + [unrelated])
+        cases = list(zip(cases, exps[:-1]))
+        unrelated_exp = exps[-1]
         for var in variants:
             for k, v in var.items():
                 c.set_option(k, v)
@@ -188,8 +199,9 @@ def test_align_scored_range_is_the_pieces_alignment(pgs, oracle):
                 for npiece in (2, 5):
                     ranges = pgs.capi.make_string_range(npiece, m, len(refb), 2.0)
                     mx = c.score_ranges(ranges, semantics=sem)[:, 0]
+                    exps = _pmap(lambda r: oracle.align(q, refb[r[0]:r[1]], sem), ranges)
                     for k, (lo, hi) in enumerate(ranges):
-                        exp = oracle.align(q, refb[lo:hi], sem)
+                        exp = exps[k]
                         assert mx[k] == exp["score"], (m, sem, npiece, k)
                         _cmp(c.align_scored_range(k, semantics=sem), exp, "scored range m=%d sem=%d piece %d/%d" % (m, sem, k, npiece))
                     # another scoring for the finish: swept again under it
@@ -297,7 +309,7 @@ def test_per_query_fallback_on_repeat_rich_reference(pgs, oracle, sem):
     assert len(which) >= 6
     refb = ref.tobytes()
     qs = [r.tobytes() for r in reads]
-    exp = [oracle.align(q, refb, sem) for q in qs]
+    exp = _pmap(lambda q: oracle.align(q, refb, sem), qs)
     c = pgs.Context(0)
     try:
         got = c.align_batch(qs, refb, semantics=sem)
@@ -439,7 +451,7 @@ def test_optimistic_margin_is_certified_or_swept_again(pgs, oracle):
             assert again == (0 if name == "strong" else 1), (name, again, exp["score"])
             # reference sharding: ranges and the oracle's per-piece answers
             ranges = pgs.capi.make_string_range(6, m, len(refb), 2.0)
-            true = [oracle.score_only(q, refb[lo:hi], 0) for lo, hi in ranges]
+            true = _pmap(lambda r: oracle.score_only(q, refb[r[0]:r[1]], 0), ranges)
             c.set_reference(refb); c.batch_upload([q])
             best, which, mx = c.best_range(ranges, semantics=0)
             assert best[0] == max(true) and which[0] == true.index(max(true)), (name, best, which, true)
