@@ -129,7 +129,8 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(h_offs, offs, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h_wout, wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));              // the one mid-call round trip: how many bytes to expect
+    { HostTrace t_("  batch: passes + walk measure");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }            // the one mid-call round trip: how many bytes to expect
     const size_t ctot = (size_t)h_offs[n];
     if (ctx->pin_cons.size() <= ctx->cons_used) ctx->pin_cons.resize(ctx->cons_used + 1);
     PinBuf &cons = ctx->pin_cons[ctx->cons_used];
@@ -141,8 +142,11 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     ctx->cons_used++;
     cons_base = cons.as<char>();
   }
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  { HostTrace t_("  batch: to the last download");
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
+  HostTrace t_results("  batch: results on the host");
   std::atomic<bool> bad{false};
+  std::atomic<size_t> left{0};
   parallel_for(n, [&](size_t k0, size_t k1) {
     for (size_t k = k0; k < k1; ++k) {
       const int id = q.order[first + k];
@@ -150,6 +154,7 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
       if (want_trace && hit && h_wout[3 * k + 2] != 0) {
         // a walk that left its window: the problem goes to the host-driven path (handled stays 0); on whole problems: a bug
         if (!windows || h_wout[3 * k + 2] != 1) bad.store(true, std::memory_order_relaxed);
+        else left.fetch_add(1, std::memory_order_relaxed);
         continue;
       }
       handled[id] = 1;
@@ -165,8 +170,7 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     }
   });
   if (bad.load()) return fail(ctx, MI355_SW_ENODEV, "internal: a walk over a whole-problem window failed");
-  if (windows && want_trace)
-    for (size_t k = 0; k < n; ++k) ctx->left_window += (h_best[k] > 0 && h_wout[3 * k + 2] == 1) ? 1 : 0;
+  ctx->left_window += left.load();
   return 0;
 }
 

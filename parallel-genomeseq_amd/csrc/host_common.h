@@ -214,6 +214,12 @@ struct Located {
   int64_t ix = 0, iy = 0;         // argmax, iy relative to the range start (1-based)
 };
 
+struct TraceOut {                  // consensus strings of one alignment: views into buffers the context keeps until its next call
+  const char *cx = nullptr, *cy = nullptr;
+  size_t len = 0;
+  uint32_t pos = 0;
+};
+
 }  // namespace
 
 // What mi355_sw_score_ranges leaves behind for mi355_sw_align_scored_range: the sweep's keys per (range, query) and the
@@ -257,6 +263,10 @@ struct mi355_sw_ctx {
   uint32_t flag_cap = 0;          // entries of `flags` (score_begin)
   bool first_valid = false;       // sw_sample_first ran in this score pass (ctx->first holds the offenders' first candidates)
   size_t first_settled = 0;       // queries over their candidate cap that their first candidates settled (uint8 engine)
+  // per-query results of the running call (kept between calls: half a million alignments per call would otherwise fault in
+  // 30 MB of fresh pages every time)
+  std::vector<Located> loc_store;
+  std::vector<TraceOut> tout_store;
   size_t left_window = 0;         // walks of the running call that left their decision window (host_batch.h) and were redone whole
   size_t requeried = 0;           // queries of the running call that were swept a second time on the exact instances
   size_t whole_again = 0;         // ... times the whole batch was (most of it exceeded its candidate cap)
@@ -457,11 +467,12 @@ Hash128 content_hash_part(const char *p, size_t n) {
 template <class F>
 void parallel_for(size_t n, F fn) {
   if (n < 65536) { fn((size_t)0, n); return; }
-  const size_t step = (n + 3) / 4;
-  std::future<void> parts[3];
-  for (int t = 0; t < 3; ++t) parts[t] = std::async(std::launch::async, fn, std::min(n, (size_t)(t + 1) * step), std::min(n, (size_t)(t + 2) * step));
+  const int nt = n >= 262144 ? 8 : 4;                              // (half a million alignments per call: eight threads)
+  const size_t step = (n + nt - 1) / nt;
+  std::future<void> parts[7];
+  for (int t = 0; t + 1 < nt; ++t) parts[t] = std::async(std::launch::async, fn, std::min(n, (size_t)(t + 1) * step), std::min(n, (size_t)(t + 2) * step));
   fn((size_t)0, std::min(n, step));
-  for (auto &f : parts) f.get();
+  for (int t = 0; t + 1 < nt; ++t) parts[t].get();
 }
 
 inline Hash128 combine_hash(Hash128 r, const Hash128 &o) {

@@ -115,11 +115,6 @@ int run_exact(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
 
 // Consensus of one alignment: views into a D2H buffer the context keeps until the next call (ctx->arenas) —
 // with half a million alignments per call, a std::string pair each was a quarter of the host time.
-struct TraceOut {
-  const char *cx = nullptr, *cy = nullptr;
-  size_t len = 0;
-  uint32_t pos = 0;
-};
 
 // Walk over decisions of jobs[lo,hi) (all with want_dirs), starting at (start_i, local nw...).
 int run_walk(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const std::vector<ExactJob> &jobs,

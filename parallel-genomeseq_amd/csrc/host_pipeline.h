@@ -463,8 +463,13 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
   const int64_t n = rg.hi - rg.lo;
   HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
   // (half a million small alignments per call: the per-query host arrays are sized only where a path reads them)
-  loc.assign(nq, Located());
-  tout.assign(want_trace ? nq : 0, TraceOut());
+  { HostTrace t_("  per-query arrays");
+  loc.resize(nq);
+  tout.resize(want_trace ? nq : 0);
+  parallel_for(nq, [&](size_t k0, size_t k1) {
+    std::fill(loc.begin() + k0, loc.begin() + k1, Located());
+    if (want_trace) std::fill(tout.begin() + k0, tout.begin() + k1, TraceOut());
+  }); }
   // No score can be positive (uint8 engine whose match score saturates to 0; float engine whose best substitution
   // score is <= 0 with a positive gap): every cell of the matrix is 0 and the defined no-match result stands.
   bool all_zero = false;
@@ -750,8 +755,8 @@ int align_range(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
                 const mi355_sw_params &p, int flags, mi355_sw_result *outs, const ScoredRanges *pre = nullptr, size_t pre_range = 0) {
   const bool want_trace = !(flags & MI355_SW_SCORE_ONLY);
   const size_t nq = q.nq;
-  std::vector<Located> loc;
-  std::vector<TraceOut> tout;
+  std::vector<Located> &loc = ctx->loc_store;
+  std::vector<TraceOut> &tout = ctx->tout_store;
   int rc = align_range_core(ctx, ref, q, rg, p, flags, loc, tout, pre, pre_range);
   if (rc) return rc;
   HostTrace trace_results("set_results");
@@ -772,8 +777,8 @@ int align_range_view(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
                      const mi355_sw_params &p, int flags, mi355_sw_batch_view *out) {
   const bool want_trace = !(flags & MI355_SW_SCORE_ONLY);
   const size_t nq = q.nq;
-  std::vector<Located> loc;
-  std::vector<TraceOut> tout;
+  std::vector<Located> &loc = ctx->loc_store;
+  std::vector<TraceOut> &tout = ctx->tout_store;
   int rc = align_range_core(ctx, ref, q, rg, p, flags, loc, tout);
   if (rc) return rc;
   HostTrace trace_results("view_results");
