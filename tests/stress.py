@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential stress run: the HIP path (C-ABI) against the CPU oracle for a time budget.
 Covers single alignments, ragged batches and the split aligner over a wide range of shapes, alphabets and
-scorings.  Usage: python tools/stress.py [seconds] [seed]"""
+scorings.  Usage: python tests/stress.py [seconds] [seed]"""
 import os
 import sys
 import time
