@@ -579,7 +579,8 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       for (size_t k = 0; k < nq; ++k) if (qsat[k] && qcount[k] > qcap) offenders.push_back((int)k);
       if (trace_on) std::fprintf(stderr, "[mi355_sw] %zu of %zu queries exceed %u candidates\n", offenders.size(), nsatq, qcap);
       // uint8 engine, key at the cap of 255: the answer is the 255 that comes first in the skewed storage order, i.e. on the
-      // lowest anti-diagonal i + j.  Sub-chunks are longer than |x| + 64, so that cell lies in the first sub-chunk s1 that truly
+      // lowest anti-diagonal i + j (the bottom-right triangle i + j > |y| aside: the order wraps it to the front, and its two
+      // sub-chunks are always evaluated).  Sub-chunks are longer than |x| + 64, so that cell lies in the first sub-chunk s1 that truly
       // holds a 255 or in s1 + 1; a sub-chunk that is no candidate holds none (its unsaturated maximum stays below 255, and the
       // saturating rule never exceeds the unsaturated one).  sw_sample_first listed the query's first candidates in order:
       // evaluate them exactly; when a 255 turns up and every candidate up to two sub-chunks right of the winner was on the
@@ -598,6 +599,14 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
           const uint32_t cnt = f[0] & 0x7FFFFFFFu;
           if (cnt == 0 || cnt > (uint32_t)K) continue;
           for (uint32_t e = 0; e < cnt; ++e) ff.push_back({(uint32_t)id, f[1 + e]});
+          // ... and the last two sub-chunks: the storage order wraps the bottom-right triangle (i + j > |y|) in front of
+          // everything else (order_key<1>, region 3), so a 255 there beats any other (locate_fast lists them for the same reason)
+          const int64_t nsub = (n + qchunk[id] - 1) / qchunk[id];
+          for (int64_t s : {nsub - 2, nsub - 1}) {
+            bool listed = s < 0;
+            for (uint32_t e = 0; e < cnt; ++e) listed = listed || (int64_t)f[1 + e] == s;
+            if (!listed) ff.push_back({(uint32_t)id, (uint32_t)s});
+          }
           tried.push_back(id);
           qlow[id] = 255.0f;
         }
@@ -613,7 +622,10 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
             const uint32_t *f = &first[(size_t)id * (K + 1)];
             const uint32_t cnt = f[0] & 0x7FFFFFFFu;
             bool ok = qdone[id] && loc[id].score == 255.0f;
-            if (ok && (f[0] & 0x80000000u)) ok = (int64_t)f[cnt] >= (loc[id].iy - 1) / qchunk[id] + 2;   // f[cnt]: the last one listed
+            // list cut short: every candidate up to two sub-chunks right of the winner must have been on it (f[cnt]: the last one
+            // listed) — unless the winner lies in the wrapped triangle, which precedes every cell of the sub-chunks not listed
+            if (ok && (f[0] & 0x80000000u) && !(loc[id].ix + loc[id].iy > n && n >= (int64_t)q.len[id]))
+              ok = (int64_t)f[cnt] >= (loc[id].iy - 1) / qchunk[id] + 2;
             if (ok) { settled[id] = 1; ++nsettled; }
             else { loc[id] = Located(); qdone[id] = 0; }
           }

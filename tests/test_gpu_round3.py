@@ -533,3 +533,43 @@ def test_small_alignment_batch_windows(pgs, oracle, ylen):
                 _cmp(g, oracle.align(x, y, 0, *sc), "windows |y|=%d |x|=%d scoring %r" % (ylen, len(x), sc))
     finally:
         c.close()
+
+
+def test_first_candidates_and_the_wrapped_triangle(pgs, oracle):
+    """uint8 engine, reads over their candidate cap settled by their first candidates in order (sw_sample_first): the skewed
+    storage order wraps the bottom-right triangle (i + j > |y|) IN FRONT of every other cell, so a 255 in the reference's last
+    |x| columns beats the first copy — the last two sub-chunks are always evaluated.  A 150 bp element planted 160 times, one copy
+    ending exactly at the end of the reference, one at its start; reads = the element, diverged copies, unrelated reads.
+    (Found by tests/stress.py: seed 2026.)"""
+    n, m = 400_000, 150
+    ref = bytearray(pgs.synth.dna(8801, n).tobytes())
+    elem = pgs.synth.dna(8802, m).tobytes()
+    for k in range(158):
+        at = 3000 + 2500 * k
+        ref[at:at + m] = elem
+    ref[n - m:] = elem                                                          # ends with the reference: the wrapped triangle
+    ref[0:m] = elem
+    refb = bytes(ref)
+    rng = np.random.default_rng(8803)
+    reads = [elem, elem[10:] + b"ACGTACGTAC", elem[:120] + pgs.synth.dna(8804, 30).tobytes()]
+    for k in range(5):
+        q = bytearray(elem)
+        for i in rng.choice(m, 6, replace=False):
+            q[i] = b"ACGT"[int(rng.integers(0, 4))]
+        reads.append(bytes(q))
+    reads += [pgs.synth.dna(8810 + k, m).tobytes() for k in range(24)]
+    exp = _pmap(lambda q: oracle.align(q, refb, 1), reads)
+    assert exp[0]["end_y"] > n - m, exp[0]                                      # the oracle's first 255 IS in the wrapped triangle
+    c = pgs.Context(0)
+    try:
+        got = c.align_batch(reads, refb, semantics=1)
+        cnt = c.last_counters()
+        for k, (g, e) in enumerate(zip(got, exp)):
+            _cmp(g, e, "wrapped triangle, read %d" % k)
+        assert cnt["first_settled"] >= 4, cnt
+        # the same reference without the copy at the end: the first copy (at the reference's start) wins
+        ref2 = refb[:n - m] + pgs.synth.dna(8805, m).tobytes()
+        for k, (g, q) in enumerate(zip(c.align_batch(reads[:8], ref2, semantics=1), reads[:8])):
+            _cmp(g, oracle.align(q, ref2, 1), "no copy at the end, read %d" % k)
+    finally:
+        c.close()
