@@ -52,24 +52,40 @@ int main(int argc, char **argv) {
   mi355_sw_ctx *ctx = multi ? nullptr : parseq::context();
   if (multi) parseq::check_multi(mi355_sw_multi_set_reference(multi, fa_string.data(), fa_string.size()), "set_reference");
   else parseq::check(mi355_sw_set_reference(ctx, fa_string.data(), fa_string.size()), "set_reference");
-  std::vector<const char *> xs(seqs.size());
-  std::vector<size_t> nxs(seqs.size());
   double cells = 0;
-  for (size_t k = 0; k < seqs.size(); ++k) { xs[k] = seqs[k].data(); nxs[k] = seqs[k].size(); cells += (double)nxs[k] * fa_string.size(); }
-  std::vector<mi355_sw_result> res(seqs.size());
+  for (const std::string &sq : seqs) cells += (double)sq.size() * fa_string.size();
   mi355_sw_params p;
   mi355_sw_default_params(&p);
   int64_t best_index = -1;
   double t[6];
+  std::vector<float> score(seqs.size());
+  std::vector<uint32_t> pos(seqs.size());
   if (multi) {
+    std::vector<const char *> xs(seqs.size());
+    std::vector<size_t> nxs(seqs.size());
+    for (size_t k = 0; k < seqs.size(); ++k) { xs[k] = seqs[k].data(); nxs[k] = seqs[k].size(); }
+    std::vector<mi355_sw_result> res(seqs.size());
     parseq::check_multi(mi355_sw_multi_align_batch(multi, seqs.size(), xs.data(), nxs.data(), &p, 0, res.data(), &best_index), "align_batch");
     mi355_sw_multi_last_timings(multi, t);
     std::cout << mi355_sw_multi_device_count(multi) << " devices";
     if (mi355_sw_multi_rccl_version(multi)) std::cout << ", RCCL " << mi355_sw_multi_rccl_version(multi);
     std::cout << std::endl;
+    for (size_t k = 0; k < seqs.size(); ++k) { score[k] = res[k].score; pos[k] = res[k].pos; }
+    mi355_sw_free_results(res.data(), res.size());
   } else {
-    parseq::check(mi355_sw_align_batch(ctx, seqs.size(), xs.data(), nxs.data(), &p, 0, res.data()), "align_batch");
+    // one device: the database as ONE buffer + offsets (what the concatenated FASTA lines are), results as a struct of arrays
+    // in library memory — no pointer, no allocation and no string copy per sequence (the CSV needs pos and score only)
+    std::string all;
+    std::vector<int64_t> offs(seqs.size() + 1, 0);
+    size_t total = 0;
+    for (const std::string &sq : seqs) total += sq.size();
+    all.reserve(total);
+    for (size_t k = 0; k < seqs.size(); ++k) { all += seqs[k]; offs[k + 1] = (int64_t)all.size(); }
+    parseq::check(mi355_sw_batch_upload_packed(ctx, seqs.size(), all.data(), offs.data()), "batch_upload_packed");
+    mi355_sw_batch_view v;
+    parseq::check(mi355_sw_batch_run_view(ctx, &p, 0, &v), "batch_run_view");
     mi355_sw_last_timings(ctx, t);
+    for (size_t k = 0; k < seqs.size(); ++k) { score[k] = v.score[k]; pos[k] = v.pos[k]; }
   }
   std::ofstream out(output_file_path);
   out << "read,pos_pred,score\n";
@@ -77,13 +93,12 @@ int main(int argc, char **argv) {
   for (size_t k = 0; k < seqs.size(); ++k) {
     char buff[127];
     std::snprintf(buff, sizeof buff, "%.126s", seqs[k].c_str());
-    out << buff << ", " << res[k].pos << ", " << res[k].score << "\n";
-    if (res[k].score > res[best].score) best = k;
+    out << buff << ", " << pos[k] << ", " << score[k] << "\n";
+    if (score[k] > score[best]) best = k;
   }
   if (multi && best_index >= 0 && (size_t)best_index != best) { std::cerr << "internal: best index mismatch" << std::endl; return 3; }
   if (!seqs.empty())
-    std::cout << "best: sequence " << best << " score " << res[best].score << " pos " << res[best].pos << std::endl;
+    std::cout << "best: sequence " << best << " score " << score[best] << " pos " << pos[best] << std::endl;
   std::cout << "[INFO] device time " << t[3] * 1e-6 << "s, GCUPS:" << cells / t[3] * 1e-3 << std::endl;
-  mi355_sw_free_results(res.data(), res.size());
   return 0;
 }
