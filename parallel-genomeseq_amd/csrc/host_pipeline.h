@@ -517,7 +517,7 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       for (Bucket &b : buckets) {
         b.fast = bucket_fast_ok(ref, table, b, n, p); any_fast |= b.fast; any_sat |= b.fast && (b.satflag || b.sampled);
         // (not for the uint8 engine's unsaturated sweep: there every cell that reaches 255 must be exact, wherever it lies)
-        b.opt_margin = b.longp && !b.unsat && !opt().no_opt_margin;
+        b.opt_margin = b.longp && !b.unsat && nq == 1 && !opt().no_opt_margin;   // (certified below for a lone query only)
       }
       if (!any_fast) break;
       const std::vector<Range> ranges{rg};

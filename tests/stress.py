@@ -53,6 +53,39 @@ def plant(ref, m, alpha):
     return rseq(m, alpha)
 
 
+def bisect_batch(qs, ref, sem, sc, exps):
+    """A mismatching batch again under the switches of DESIGN.md §8.1: which path holds the difference.  The case is saved."""
+    out = os.path.join(ROOT, "gpurun_out", "stress_case_%d.npz" % int(time.time()))
+    try:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        np.savez_compressed(out, ref=np.frombuffer(ref, dtype=np.uint8), sem=sem, sc=np.array(sc),
+                            lens=np.array([len(q) for q in qs]), qs=np.frombuffer(b"".join(qs), dtype=np.uint8))
+        print("case saved to %s" % out, flush=True)
+    except OSError as e:
+        print("case not saved: %r" % (e,), flush=True)
+    for var in ({}, {"no_long": 1}, {"no_sample": 1}, {"no_satflag": 1}, {"no_opt_margin": 1}, {"no_requery": 1}, {"no_f16": 1}, {"force_f32": 1},
+                {"no_strip": 1}, {"no_wave": 1}, {"no_strip_groups": 1}, {"no_first": 1}, {"no_unsat": 1}):
+        c = pgs.Context(0)
+        try:
+            for k, v in var.items():
+                c.set_option(k, v)
+            res = c.align_batch(qs, ref, semantics=sem, match=sc[0], mismatch=sc[1], gap=sc[2])
+            bad = [(i, len(qs[i]), [k for k in KEYS if res[i][k] != exps[i][k]]) for i in range(len(qs)) if any(res[i][k] != exps[i][k] for k in KEYS)]
+            print("  %-22s %s  kernel: %s  counters: %s" % (var, "OK" if not bad else "BAD %r" % (bad[:3],), c.last_kernel()["name"][:110], c.last_counters()), flush=True)
+            for i, m, keys in bad[:1]:
+                print("     got score %r pos %r end %r/%r; expected score %r pos %r end %r/%r" % (res[i]["score"], res[i]["pos"], res[i]["end_x"], res[i]["end_y"],
+                      exps[i]["score"], exps[i]["pos"], exps[i]["end_x"], exps[i]["end_y"]), flush=True)
+            # the offending queries alone
+            if bad and not var:
+                for i, m, keys in bad[:2]:
+                    r1 = c.align(qs[i], ref, sem, *sc)
+                    print("     alone: %s (kernel %s)" % ("OK" if all(r1[k] == exps[i][k] for k in KEYS) else "BAD score %r" % r1["score"], c.last_kernel()["name"][:90]), flush=True)
+        except Exception as e:
+            print("  %-22s raised %r" % (var, e), flush=True)
+        finally:
+            c.close()
+
+
 t0 = time.time()
 ncase = nbad = 0
 tick = t0
@@ -120,13 +153,17 @@ while time.time() - t0 < budget:
         qs = [plant(ref, int(rng.choice([0, 1, 20, 100, 150, 151, 300, 600, 1100, 2300])), alpha) if rng.random() > 0.05 else b""
               for _ in range(int(rng.integers(1, 24)))]
         res = ctx.align_batch(qs, ref, semantics=sem, match=ma, mismatch=mi, gap=gp)
-        for q, got in zip(qs, res):
-            exp = ob.align(q, ref, sem, ma, mi, gp)
+        exps = [ob.align(q, ref, sem, ma, mi, gp) for q in qs]
+        anybad = False
+        for q, got, exp in zip(qs, res, exps):
             bad = [k for k in KEYS if got[k] != exp[k]]
             if bad:
                 nbad += 1
-                print("MISMATCH batch |q|=%d n=%d sem=%d sc=%s keys=%s" % (len(q), n, sem, (ma, mi, gp), bad), flush=True)
+                anybad = True
+                print("MISMATCH batch |q|=%d n=%d sem=%d sc=%s keys=%s (batch lengths %r)" % (len(q), n, sem, (ma, mi, gp), bad, [len(x) for x in qs]), flush=True)
             ncase += 1
+        if anybad:
+            bisect_batch(qs, ref, sem, (ma, mi, gp), exps)
     elif kind >= 10:    # many small whole problems against a short reference (device-built job lists, struct-of-arrays view)
         n = int(rng.choice([1, 40, 144, 300, 700, 1023]))
         ref = rseq(n, alpha)

@@ -573,3 +573,33 @@ def test_first_candidates_and_the_wrapped_triangle(pgs, oracle):
             _cmp(g, oracle.align(q, ref2, 1), "no copy at the end, read %d" % k)
     finally:
         c.close()
+
+
+def test_lone_long_query_inside_a_batch(pgs, oracle):
+    """A batch whose only long query (2300 rows) has a bucket of its own runs it on sw_long_kernel — with the PROVEN warm-up margin:
+    the optimistic margin is certified for single-query calls only.  The case is the one tests/stress.py (seed 777) found: scoring
+    7 / -7 / 1 (cheap gaps: the best alignment spans 5963 columns, far beyond the optimistic margin), 20 000 columns, sixteen
+    queries of 0 .. 2300 bp (tests/golden/stress_seed777_long_query_in_batch.npz holds its bytes)."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stress_seed777_long_query_in_batch.npz"))
+    ref = d["ref"].tobytes()
+    offs = np.concatenate([[0], np.cumsum(d["lens"])])
+    allq = d["qs"].tobytes()
+    qs = [allq[offs[k]:offs[k + 1]] for k in range(len(d["lens"]))]
+    sc = tuple(float(v) for v in d["sc"])
+    exp = _pmap(lambda q: oracle.align(q, ref, 0, *sc), qs)
+    c = pgs.Context(0)
+    try:
+        for var in ({}, {"no_sample": 1}, {"long_pipes": 1}, {"chunk": 4096}):
+            for k, v in var.items():
+                c.set_option(k, v)
+            for k, (g, e) in enumerate(zip(c.align_batch(qs, ref, semantics=0, match=sc[0], mismatch=sc[1], gap=sc[2]), exp)):
+                _cmp(g, e, "long query in a batch, query %d (%d bp) %r" % (k, len(qs[k]), var))
+            assert "sw_long_kernel" in c.last_kernel()["name"], c.last_kernel()["name"]
+            for k in var:
+                c.set_option(k, None)
+        # the same query alone: optimistic margin, not certified (score 10362 of 16100), swept again
+        _cmp(c.align(qs[6], ref, 0, *sc), exp[6], "the long query alone")
+        assert c.last_counters()["whole_batch_again"] == 1
+    finally:
+        c.close()
