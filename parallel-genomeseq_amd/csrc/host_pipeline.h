@@ -413,6 +413,7 @@ int locate_saturated(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
     }
     int64_t pieces = 1;
     if (q.len[k] > 512) pieces = std::max<int64_t>(1, std::min<int64_t>((sub_hi - sub_lo) / 256, 224 / (int64_t)std::max<size_t>(1, nlong)));
+    if (warm >= sub_hi) pieces = 1;                               // (every piece would start at column 0: no point in cutting)
     const int64_t plen = (sub_hi - sub_lo + pieces - 1) / pieces;
     for (int64_t own_lo = sub_lo; own_lo < sub_hi; own_lo += plen) {
       const int64_t own_hi = std::min(own_lo + plen, sub_hi);
@@ -743,6 +744,43 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
     }
     std::vector<int> slow;
     for (size_t k = 0; k < nq; ++k) if (!qfast[k] && !handled[k]) slow.push_back((int)k);
+    // Problems the score kernel does not take (no finite warm-up margin: a gap penalty that is, or truncates to, 0 ...) and whose
+    // anti-diagonal does not fit the LDS kernel either: the strip kernel over the WHOLE range as one window — a window that starts
+    // at column 0 needs no margin — for the first maximum (locate_saturated with one sub-chunk = the range) and for the decisions
+    // (wave_trace starts its windows at 0 when no margin is finite).  Identity scoring; not the uint8 engine's |x| == |y| quirk.
+    if (!slow.empty() && !pre && wave_scoring_ok(p) && strip_scoring_ok(ref, p) && n > kWaveMaxLanesSide) {
+      std::vector<int> huge, rest;
+      for (int id : slow) {
+        const int64_t m = q.len[id];
+        const bool quirk = p.semantics == MI355_SW_U8SAT && m == n;
+        if (m > kWaveMaxLanesSide && !quirk && exact_lds_bytes((int)m, (int)std::min<int64_t>(n, INT32_MAX)) > kExactLdsMax) huge.push_back(id);
+        else rest.push_back(id);
+      }
+      if (!huge.empty()) {
+        std::vector<int64_t> hchunk(nq, n), hwarm(nq, kColsMax);
+        std::vector<float> hlow(nq, 0.0f);
+        std::vector<char> hdone(nq, 0);
+        std::vector<std::pair<uint32_t, uint32_t>> whole;
+        for (int id : huge) whole.push_back({(uint32_t)id, 0u});
+        HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+        int rc = locate_saturated(ctx, ref, q, rg, p, hchunk, hwarm, hlow, table, whole, loc, hdone);
+        if (rc) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+        ctx->timings[1] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
+        if (want_trace) {
+          std::vector<Located> hl;
+          for (int id : huge) hl.push_back(loc[id]);
+          std::vector<TraceOut> ht;
+          HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+          rc = trace_located(ctx, ref, q, rg, p, hwarm, table, huge, hl, ht);
+          if (rc) return rc;
+          HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+          ctx->timings[2] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
+          for (size_t t = 0; t < huge.size(); ++t) tout[huge[t]] = std::move(ht[t]);
+        }
+        slow.swap(rest);
+      }
+    }
     if (!slow.empty()) {
       std::vector<Located> sl;
       std::vector<TraceOut> st;

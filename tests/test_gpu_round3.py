@@ -603,3 +603,29 @@ def test_lone_long_query_inside_a_batch(pgs, oracle):
         assert c.last_counters()["whole_batch_again"] == 1
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("sc", [(1.1, -0.9, 0.37), (3.0, -3.0, 0.5)])
+def test_uint8_gap_truncated_to_zero_and_too_long_for_lds(pgs, oracle, sc):
+    """uint8 engine, a gap penalty that truncates to 0 (_saturate, similaritymatrix.cpp:376-384): no finite warm-up margin, so the
+    problem never takes the score kernel; with an anti-diagonal that does not fit the LDS kernel either it used to return ENOTSUP
+    (tests/stress.py seed 777: 17 000 x 17 647 at 1.1 / -0.9 / 0.37).  It runs on the strip kernel over the whole range as ONE
+    window (a window that starts at column 0 needs no margin): every field against the oracle, alone and inside a batch."""
+    m, n = 14_000, 14_500
+    ref = pgs.synth.protein(9901, n).tobytes()
+    q = bytearray(ref[200:200 + m])
+    rng = np.random.default_rng(9902)
+    for i in rng.choice(m, m // 10, replace=False):
+        q[i] = b"ACDEFGHIKLMNPQRSTVWY"[int(rng.integers(0, 20))]
+    del q[5000:5040]
+    q = bytes(q)
+    others = [q[:300], q[:4000], b"", pgs.synth.protein(9903, 700).tobytes()]
+    exps = _pmap(lambda x: oracle.align(x, ref, 1, *sc), [q] + others)
+    c = pgs.Context(0)
+    try:
+        _cmp(c.align(q, ref, 1, *sc), exps[0], "gap truncated to 0 %r" % (sc,))
+        got = c.align_batch([q] + others, ref, semantics=1, match=sc[0], mismatch=sc[1], gap=sc[2])
+        for g, e, x in zip(got, exps, [q] + others):
+            _cmp(g, e, "gap truncated to 0 %r, in a batch, |x| = %d" % (sc, len(x)))
+    finally:
+        c.close()
