@@ -7,6 +7,10 @@
 // batch's offsets, lengths and length-sorted ids — and the only things that cross PCIe are the results:
 //   batch_wave_setup   WaveProblem[k] for sorted positions [first, first + count): whole problem, TRACK + DIRS
 //   (sw_wave_kernel)   one pass: first maximum in storage order AND the greedy decision of every cell
+//     or, lanes = columns of the shared second sequence with dyadic scores (sw_wave_prof_kernel, host_batch.h):
+//     (TRACK pass)       first maximum, the slot's wavefront saved every 64 steps
+//     batch_window_setup WaveProblem[k] <- the rows [k0, row of the argmax), resumed from the state saved at step k0
+//     (DIRS pass)        decisions for those rows only (a walk that leaves them: the problem goes to the host-driven path)
 //   batch_walk_setup   WaveWalk[k] from the argmax the pass just found
 //   (sw_wave_walk_kernel<kWalkMeasure>)  ->  walk_sizes  ->  exclusive scan  ->  (sw_wave_walk_kernel<kWalkWrite>)
 // plus a three-kernel exclusive scan of int64 (block sums, scan of the sums, add).
