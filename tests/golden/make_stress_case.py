@@ -2,11 +2,12 @@
 """How tests/golden/stress_seed777_long_query_in_batch.npz was made: tests/stress.py's generator replayed on the CPU with seed 777
 (device and oracle replaced by stubs that consume no random numbers), saving the ragged batches with a 2300 bp query against 20 000
 columns at 7 / -7 / 1; the second one is the batch that came out wrong on the device.
-Usage: python tests/golden/make_stress_case.py   (writes stress_seed777_case<k>.npz next to this file)"""
+Usage: python tests/golden/make_stress_case.py [outdir]   (writes stress_seed777_case<k>.npz there; default: next to this file)"""
 import sys, os, types, numpy as np
 ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import binding as real_ob
+OUTDIR = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden")
 class Stop(Exception): pass
 R = dict(score=0.0,pos=0,end_x=0,end_y=0,cons_x="",cons_y="",piece=0)
 class FakeOb:
@@ -23,7 +24,7 @@ class FakeCtx:
     def align_batch(self, qs, ref, **kw):
         if len(ref) == 20000 and kw.get("match") == 7.0 and kw.get("gap") == 1.0 and kw.get("semantics") == 0 and any(len(q) == 2300 for q in qs):
             found.append(1)
-            np.savez_compressed(os.path.join(ROOT, "tests", "golden", "stress_seed777_case%d.npz" % len(found)), ref=np.frombuffer(ref, dtype=np.uint8),
+            np.savez_compressed(os.path.join(OUTDIR, "stress_seed777_case%d.npz" % len(found)), ref=np.frombuffer(ref, dtype=np.uint8),
                                 lens=np.array([len(q) for q in qs]), qs=np.frombuffer(b"".join(qs), dtype=np.uint8), sc=np.array([kw["match"], kw["mismatch"], kw["gap"]]))
             print("saved case", len(found), [len(q) for q in qs], flush=True)
             if len(found) >= 3: raise Stop()

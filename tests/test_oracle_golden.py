@@ -164,3 +164,26 @@ def test_eval_mismatch_counts_of_data_small(data_small):
     for sem, want in ((ob.F32, 188), (ob.U8SAT, 222)):
         bad = sum(1 for q, p in zip(data_small["reads"], data_small["sam_pos"]) if ob.align(q.encode(), ref, sem)["pos"] != p)
         assert bad == want, (sem, bad)
+
+
+def test_stress_fixture_is_what_its_script_makes(tmp_path):
+    """tests/golden/stress_seed777_long_query_in_batch.npz (the batch tests/stress.py seed 777 found, replayed on the device by
+    test_lone_long_query_inside_a_batch) is reproduced byte for byte by the committed script, and the oracle's answer for its long
+    query is the one DESIGN.md §3.7 quotes (score 10362, an alignment that spans 5963 columns)."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    from oracle import binding as ob
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    subprocess.check_call([sys.executable, os.path.join(here, "make_stress_case.py"), str(tmp_path)], stdout=subprocess.DEVNULL)
+    made = np.load(str(tmp_path / "stress_seed777_case2.npz"))
+    kept = np.load(os.path.join(here, "stress_seed777_long_query_in_batch.npz"))
+    assert sorted(made.files) == sorted(kept.files)
+    for k in kept.files:
+        assert np.array_equal(made[k], kept[k]), k
+    lens = kept["lens"]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    q = kept["qs"].tobytes()[offs[6]:offs[7]]
+    r = ob.align(q, kept["ref"].tobytes(), 0, *[float(v) for v in kept["sc"]])
+    assert (len(q), r["score"], r["pos"], r["end_y"]) == (2300, 10362.0, 11966, 17929), r
