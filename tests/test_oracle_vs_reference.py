@@ -43,3 +43,26 @@ def test_random_differential(oracle):
             got = oracle.align(x, y, sem, *sc)
             assert {k: got[k] for k in exp} == exp, (x, y, sem, sc)
     go(list(range(len(cases))))
+
+
+def test_wrapped_triangle_comes_first_in_the_skewed_order(oracle):
+    """Similarity_Matrix_Skewed stores the bottom-right triangle (i + j > |y|) in the first columns of its skewed layout, so its
+    find_index_of_maximum meets a saturated cell there BEFORE an equal one anywhere else (similaritymatrix.cpp:291-299, :330-364):
+    the same 150 bp element at columns 1000.. and at the very end of the second sequence — the real reference and the restatement
+    both report the copy at the end; without it, the first copy.  (What the uint8 engine's first-candidates step must respect,
+    DESIGN.md §3.4.)"""
+    rng = random.Random(11)
+    elem = _rs(rng, 150)
+    n = 3000
+    y = list(_rs(rng, n))
+    y[1000:1150] = elem
+    y[n - 150:] = elem
+    y = "".join(y)
+    y2 = y[:n - 150] + _rs(rng, 150)
+    outs = rp.run([rp.align_cmd(elem, y, 1, 3.0, -3.0, 2.0), rp.align_cmd(elem, y2, 1, 3.0, -3.0, 2.0)])
+    for o, yy, where in zip(outs, (y, y2), ("end", "first")):
+        exp = rp.parse_align(o)
+        got = oracle.align(elem, yy, 1, 3.0, -3.0, 2.0)
+        assert {k: got[k] for k in exp} == exp, where
+        assert got["score"] == 255.0
+        assert (got["pos"] >= n - 150) == (where == "end"), (where, got["pos"])
