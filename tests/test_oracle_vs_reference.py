@@ -66,3 +66,38 @@ def test_wrapped_triangle_comes_first_in_the_skewed_order(oracle):
         assert {k: got[k] for k in exp} == exp, where
         assert got["score"] == 255.0
         assert (got["pos"] >= n - 150) == (where == "end"), (where, got["pos"])
+
+
+def test_uint8_scorings_that_truncate_differential(oracle):
+    """The uint8 engine truncates its scoring to integers (_saturate, similaritymatrix.cpp:376-384): a gap of 0.37 or 0.5 becomes 0, a
+    mismatch of -0.9 becomes 0.  Real reference against the restatement on 120 random pairs under such scorings — the semantics
+    test_uint8_gap_truncated_to_zero_and_too_long_for_lds relies on at 14 000 rows."""
+    rng = random.Random(23)
+    cases = []
+    for t in range(120):
+        m = rng.choice([1, 5, 31, 32, 33, 64, 100, 150])
+        n = rng.choice([1, 7, 33, 64, 127, 150, 400])
+        if t % 6 == 0:
+            n = m
+        y = _rs(rng, n)
+        x = y[:m] if (t % 3 == 0 and n >= m) else _rs(rng, m)
+        x = x + "C" * (m - len(x))
+        cases.append((x, y, rng.choice([(1.1, -0.9, 0.37), (3.0, -3.0, 0.5), (7.9, -1.2, 0.99), (2.0, -0.5, 1.0)])))
+
+    def go(idx):
+        try:
+            outs = rp.run([rp.align_cmd(cases[i][0], cases[i][1], 1, *cases[i][2]) for i in idx])
+        except RuntimeError:
+            if len(idx) == 1:       # reference aborts only on an all-zero matrix
+                x, y, sc = cases[idx[0]]
+                assert oracle.align(x, y, 1, *sc)["score"] == 0
+                return
+            h = len(idx) // 2
+            go(idx[:h]); go(idx[h:])
+            return
+        for i, o in zip(idx, outs):
+            x, y, sc = cases[i]
+            exp = rp.parse_align(o)
+            got = oracle.align(x, y, 1, *sc)
+            assert {k: got[k] for k in exp} == exp, (x, y, sc)
+    go(list(range(len(cases))))
