@@ -2,6 +2,7 @@
 where the reference build exists (this container); skipped on the GPU box."""
 import random
 
+import numpy as np
 import pytest
 
 from oracle import refproc as rp
@@ -100,4 +101,47 @@ def test_uint8_scorings_that_truncate_differential(oracle):
             exp = rp.parse_align(o)
             got = oracle.align(x, y, 1, *sc)
             assert {k: got[k] for k in exp} == exp, (x, y, sc)
+    go(list(range(len(cases))))
+
+
+def test_fractional_and_cheap_gap_scorings_differential(oracle):
+    """Float engine under scorings whose float32 sums round (0.7 / -0.3 / 0.1, 1.1 / -0.9 / 0.37), dyadic fractions (3.5 / -2.25 / 1.5)
+    and cheap gaps (7 / -7 / 1: long gapped alignments): the restatement follows dp_func's operation order (similaritymatrix.cpp:49-54)
+    bit for bit — scores compared as the reference prints them, positions and consensus strings exactly."""
+    rng = random.Random(31)
+    cases = []
+    for t in range(160):
+        m = rng.choice([2, 7, 31, 33, 64, 100, 150])
+        n = rng.choice([7, 33, 64, 127, 150, 400, 900])
+        y = _rs(rng, n)
+        if t % 3 == 0 and n > m + 10:
+            o = rng.randrange(0, n - m)
+            x = list(y[o:o + m])
+            for _ in range(max(1, m // 12)):
+                x[rng.randrange(len(x))] = rng.choice("ACGT")
+            if m > 20:
+                del x[m // 2:m // 2 + 3]
+            x = "".join(x)
+        else:
+            x = _rs(rng, m)
+        cases.append((x, y, rng.choice([(0.7, -0.3, 0.1), (1.1, -0.9, 0.37), (3.5, -2.25, 1.5), (7.0, -7.0, 1.0), (0.5, -0.25, 0.25)])))
+
+    def go(idx):
+        try:
+            outs = rp.run([rp.align_cmd(cases[i][0], cases[i][1], 0, *cases[i][2]) for i in idx])
+        except RuntimeError:
+            if len(idx) == 1:
+                x, y, sc = cases[idx[0]]
+                assert oracle.align(x, y, 0, *sc)["score"] == 0
+                return
+            h = len(idx) // 2
+            go(idx[:h]); go(idx[h:])
+            return
+        for i, o in zip(idx, outs):
+            x, y, sc = cases[i]
+            exp = rp.parse_align(o)
+            got = oracle.align(x, y, 0, *sc)
+            # (the driver prints nine significant digits: the same float32)
+            assert np.float32(got["score"]) == np.float32(exp["score"]), (x, y, sc, got["score"], exp["score"])
+            assert {k: got[k] for k in exp if k != "score"} == {k: exp[k] for k in exp if k != "score"}, (x, y, sc)
     go(list(range(len(cases))))
