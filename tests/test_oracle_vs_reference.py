@@ -145,3 +145,46 @@ def test_fractional_and_cheap_gap_scorings_differential(oracle):
             assert np.float32(got["score"]) == np.float32(exp["score"]), (x, y, sc, got["score"], exp["score"])
             assert {k: got[k] for k in exp if k != "score"} == {k: exp[k] for k in exp if k != "score"}, (x, y, sc)
     go(list(range(len(cases))))
+
+
+def test_database_sequence_first_short_query_second_differential(oracle):
+    """The UniProt driver's shape (src/mpi_sw_solve_uniprot.cpp:120): a database sequence as FIRST argument (2 .. 900 residues), the
+    short query as SECOND (<= 200), protein alphabet, float engine, default scoring — planted pieces of the query (ties between equal
+    copies, walks with gaps) and unrelated sequences; what sw_wave_prof_kernel and its windows are compared with on the device."""
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    rng = random.Random(41)
+    cases = []
+    for t in range(200):
+        n = rng.choice([1, 2, 16, 17, 100, 144, 160, 200])
+        y = _rs(rng, n, aa)
+        m = rng.choice([2, 15, 63, 64, 65, 128, 129, 300, 900])
+        x = list(_rs(rng, m, aa))
+        if t % 2 == 0 and n >= 8:
+            a = rng.randrange(0, n - 4)
+            piece = list(y[a:a + rng.randrange(4, n - a + 1)])
+            for _ in range(len(piece) // 10):
+                piece[rng.randrange(len(piece))] = rng.choice(aa)
+            if len(piece) > 12 and t % 4 == 0:
+                del piece[5:7]
+            reps = 2 if t % 6 == 0 else 1
+            for r in range(reps):
+                if len(piece) <= len(x):
+                    at = rng.randrange(0, len(x) - len(piece) + 1)
+                    x[at:at + len(piece)] = piece
+        cases.append(("".join(x), y))
+
+    def go(idx):
+        try:
+            outs = rp.run([rp.align_cmd(cases[i][0], cases[i][1], 0) for i in idx])
+        except RuntimeError:
+            if len(idx) == 1:
+                assert oracle.align(cases[idx[0]][0], cases[idx[0]][1], 0)["score"] == 0
+                return
+            h = len(idx) // 2
+            go(idx[:h]); go(idx[h:])
+            return
+        for i, o in zip(idx, outs):
+            exp = rp.parse_align(o)
+            got = oracle.align(cases[i][0], cases[i][1], 0)
+            assert {k: got[k] for k in exp} == exp, cases[i]
+    go(list(range(len(cases))))
