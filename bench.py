@@ -313,13 +313,14 @@ def engine_rate(pgs, ctx, D, nreads, read_len, ref_len, steps, **kw):
 
 def extra_read_lengths(pgs, device, ref_len):
     """Whole-job rate at other read lengths (other tile shapes / kernel instances), both engines: 512 reads each
-    (256 at 2048 bp), 1 warm-up + 1 timed pass."""
+    (256 at 2048 bp, 128 at 4096 bp: strip-mined batches), 1 warm-up + 1 timed pass; per leg the counters of the candidate
+    filters (queries swept again, candidates re-evaluated, settled by their first candidates)."""
     ref = pgs.synth.dna(3, ref_len)
     ctx = pgs.Context(device)
     out = {}
     try:
         ctx.set_reference(ref)
-        for read_len, nreads in ((300, 512), (600, 512), (1000, 512), (2048, 256)):
+        for read_len, nreads in ((300, 512), (600, 512), (1000, 512), (2048, 256), (4096, 128)):
             reads, _ = pgs.synth.fast_reads_from_ref(ref, 4, nreads, read_len)
             ctx.batch_upload([r.tobytes() for r in reads])
             for sem, name in ((pgs.F32, "f32"), (pgs.U8SAT, "u8")):
@@ -328,8 +329,13 @@ def extra_read_lengths(pgs, device, ref_len):
                 ctx.batch_run(semantics=sem, raw=True)
                 dt = time.perf_counter() - t0
                 ki = ctx.last_kernel()
+                cnt = ctx.last_counters()
+                tm = ctx.last_timings()
                 out["%s_%dbp" % (name, read_len)] = {"gcups": float(nreads) * read_len * ref_len / dt * 1e-9, "reads": nreads,
-                                                     "kernel": ki["name"], "valu_ops_per_cell": ki["valu_ops_per_cell"]}
+                                                     "kernel": ki["name"], "valu_ops_per_cell": ki["valu_ops_per_cell"],
+                                                     "score_kernel_ms": tm["score_us"] * 1e-3, "locate_ms": tm["locate_us"] * 1e-3,
+                                                     "traceback_ms": tm["trace_us"] * 1e-3,
+                                                     "filters": {k: cnt[k] for k in ("requeried", "whole_batch_again", "candidates", "first_settled")}}
         return out
     finally:
         ctx.close()
@@ -422,9 +428,49 @@ def extra_config4(pgs, device, nseq):
             bad |= np.asarray(a[f]) != np.asarray(b[f])
         out["parity_check"] = {"vs": "host-built job lists (option no_devlist)", "alignments": nseq, "fields": list(fields),
                                "mismatches": int(bad.sum())}
+        out["rank_share"] = rank_share_config4(pgs, ctx, allres, offs, lens)
         return out
     finally:
         ctx.close()
+
+
+def rank_share_config4(pgs, ctx, allres, offs, lens):
+    """One rank's share of configs[3] at world = 1 / 2 / 4 / 8, measured on ONE GPU: the database LPT-partitioned by cell count
+    (dist.shard_lpt, the query-sharding of src/mpi_sw_solve_uniprot.cpp:86-138 without its writer rank), the share of the rank
+    with the greatest load — the job's critical path — uploaded as one packed buffer and run (score + argmax; with traceback),
+    best of three.  predicted_speedup = T(world = 1) / T(share): what the sharded job reaches when every rank is as fast as this
+    GPU and the 8-byte all-reduce of the best (score, index) key is free."""
+    dist = importlib.import_module("parallel_genomeseq_amd.dist")
+    out = {"note": "LPT shard (weights |x| * 144) of the rank with the greatest load; run = mi355_sw_batch_run_view on the resident shard", "worlds": {}}
+    base = None
+    w = lens.astype(np.float64) * len(pgs.synth.P02232)
+    for world in (1, 2, 4, 8):
+        parts = dist.shard_lpt(w, world) if world > 1 else [np.arange(len(lens), dtype=np.int64)]
+        loads = [float(w[p].sum()) for p in parts]
+        mine = parts[int(np.argmax(loads))]
+        sl = lens[mine]
+        so = np.concatenate([[0], np.cumsum(sl)]).astype(np.int64)
+        buf = np.empty(int(sl.sum()), dtype=np.uint8)
+        for k, i in enumerate(mine):
+            buf[so[k]:so[k + 1]] = allres[offs[i]:offs[i + 1]]
+        ctx.batch_upload_packed(buf, so)
+        rec = {"sequences": int(len(mine)), "cells": float(max(loads))}
+        for flags, name in ((pgs.capi.SCORE_ONLY, "score_argmax"), (0, "with_traceback")):
+            ctx.batch_run(semantics=pgs.F32, flags=flags, raw=True)
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ctx.batch_run(semantics=pgs.F32, flags=flags, raw=True)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            rec[name + "_ms"] = best * 1e3
+            rec[name + "_device_ms"] = ctx.last_timings()["total_us"] * 1e-3
+        if base is None:
+            base = rec
+        rec["predicted_speedup_score_argmax"] = base["score_argmax_ms"] / rec["score_argmax_ms"]
+        rec["predicted_speedup"] = base["with_traceback_ms"] / rec["with_traceback_ms"]
+        out["worlds"][str(world)] = rec
+    return out
 
 
 def config5_inputs(pgs, ref_len, qlen):
@@ -456,9 +502,11 @@ def extra_config5(pgs, device, ref_len, qlen):
             dt = time.perf_counter() - t0
             tm = ctx.last_timings()
             cells = float(qlen) * ref_len
+            cnt = ctx.last_counters()
             out[name] = {"wall_ms": dt * 1e3, "gcups": cells / dt * 1e-9, "score_kernel_ms": tm["score_us"] * 1e-3,
                          "locate_ms": tm["locate_us"] * 1e-3, "traceback_ms": tm["trace_us"] * 1e-3,
-                         "kernel": ctx.last_kernel()["name"], "score": r["score"], "pos": r["pos"]}
+                         "kernel": ctx.last_kernel()["name"], "score": r["score"], "pos": r["pos"],
+                         "finish_from_saved_state": {k: cnt[k] for k in ("saved_locates", "saved_traces", "saved_fallbacks")}}
         out["rank_share"] = rank_share_config5(pgs, ctx, q, ref_len, qlen)
         # in-run verification at full size: the 16-piece split (best_range + the winner finished from its keys) against the
         # whole-reference alignment — where the serial reference logic says they agree (SURVEY.md §8d cfg 5)
@@ -500,13 +548,16 @@ def rank_share_config5(pgs, ctx, q, ref_len, qlen):
             r = ctx.align_scored_range(k, semantics=pgs.F32)
             t2 = time.perf_counter()
             tm = ctx.last_timings()
+            cnt = ctx.last_counters()
             if best is None or (t2 - t0) < best[0]:
-                best = (t2 - t0, t1 - t0, t2 - t1, tm_score, tm["locate_us"], tm["trace_us"], r)
+                best = (t2 - t0, t1 - t0, t2 - t1, tm_score, tm["locate_us"], tm["trace_us"], r,
+                        {k: cnt[k] for k in ("saved_traces", "saved_fallbacks")})
         assert mine[k] == ranges[winner] and best[6]["score"] == float(fbest[0])
         rec = {"pieces": len(mine), "columns": int(sum(b - a for a, b in mine)), "share_ms": best[0] * 1e3,
                "score_ms": best[1] * 1e3, "score_kernel_ms": best[3] * 1e-3, "finish_ms": best[2] * 1e3,
                "finish_locate_ms": best[4] * 1e-3, "finish_traceback_ms": best[5] * 1e-3,
-               "winning_piece": winner, "owner_rank": owner, "pos": best[6]["pos"] + ranges[winner][0], "score": best[6]["score"]}
+               "winning_piece": winner, "owner_rank": owner, "pos": best[6]["pos"] + ranges[winner][0], "score": best[6]["score"],
+               "finish_from_saved_state": best[7]}
         if base is None:
             base = rec
         rec["predicted_speedup"] = base["share_ms"] / rec["share_ms"]
@@ -551,7 +602,7 @@ def extra_latency(pgs, device):
 def strong_config3(pgs, ctx, D, ref, args, sem):
     """Fixed total: --strong-reads reads of configs[2] split over the ranks (block partition), one pass."""
     total = args.strong_reads
-    reads, _ = pgs.synth.fast_reads_from_ref(ref, 4242, total, args.read_len)
+    reads, _ = pgs.synth.fast_reads_from_ref(ref, 4242, total, args.read_len)     # (100 000 reads: the vectorised generator, substitutions only)
     base, rem = divmod(total, D.world)
     lo = D.rank * base + min(D.rank, rem)
     hi = lo + base + (1 if D.rank < rem else 0)
@@ -610,6 +661,8 @@ def strong_config5(pgs, D, args, device):
                 if gbest > above:
                     break
                 known = max(gbest, 1.0)
+            else:
+                raise RuntimeError("config 5: merged best %r not above what the sweeps certify (%r) after three rounds" % (gbest, above))
             piece = 0xFFFFFFFF - (key & 0xFFFFFFFF)
             res = None
             if piece in mine:
@@ -636,7 +689,8 @@ def worker(args):
     sem = pgs.F32 if args.semantics == "f32" else pgs.U8SAT
     ctx = pgs.Context(local_rank)
     ref = pgs.synth.dna(3, args.ref_len)                                   # seed 3 (SURVEY §8d cfg 3)
-    reads, _ = pgs.synth.fast_reads_from_ref(ref, 4 + 7919 * rank, args.reads, args.read_len)
+    # SURVEY §8(d)'s generator: substrings with 1 % substitutions AND 0.1 % single-base indels, so that the timed traceback emits gaps
+    reads, _ = pgs.synth.reads_from_ref(ref, 4 + 7919 * rank, args.reads, args.read_len)
     ctx.set_reference(ref)
     ctx.batch_upload([r.tobytes() for r in reads])
     flags = pgs.capi.SCORE_ONLY if args.score_only else 0

@@ -155,8 +155,9 @@ int mi355_sw_score_ranges(mi355_sw_ctx *ctx, size_t nranges, const int64_t *left
 /* mi355_sw_score_ranges for callers that only need the WINNER: per resident query the first range with the strictly
  * greatest maximum (best[q], best_range[q]; -1 / -1 without ranges) — all OMPParallelLocalAligner does with the per-piece
  * maxima (plocalaligner.cpp:106,122-129).  That freedom lets a lone long query take the cheaper sampled sweep: ranges that
- * cannot hold the greatest maximum are not re-evaluated, so their entries of `maxima` (optional, may be NULL) are lower
- * bounds within three gap penalties; best / best_range and the winner's entry are exact.
+ * cannot hold the greatest maximum are not re-evaluated, so their entries of `maxima` (optional, may be NULL) are LOWER BOUNDS
+ * of unspecified slack (the sampled running maximum and the optimistic warm-up margin below both only ever lower a value; never
+ * above the true maximum of the range).  Exact: best, best_range, and the entry of every range whose maximum equals `best`.
  * A lone long query is also swept with an OPTIMISTIC warm-up margin in front of its tiles: enough for maxima above 11/12 of
  * the best possible score, not for every cell.  exact_above == NULL: the call checks its own best against
  * what that margin certifies and sweeps again with the margin its best needs when it falls short — results as above.
@@ -210,8 +211,15 @@ int mi355_sw_last_timings(const mi355_sw_ctx *ctx, double out[6]);
 int mi355_sw_last_counters(const mi355_sw_ctx *ctx, uint64_t out[4]);
 /* One counter of the last call by name: "requeried", "whole_batch_again", "candidates", "left_window" (= [0..3] above) and
  * "first_settled" — uint8 engine: queries over their candidate cap whose first candidates, evaluated in order, settled them
- * without a second sweep.  MI355_SW_EINVAL for an unknown name. */
+ * without a second sweep; "saved_locates" / "saved_traces" — finish steps of a lone long query that started from the columns and
+ * strip rows its sweep saved, "saved_fallbacks" — those that took the zero-border windows instead; "wait_retries" — launches
+ * repeated on a non-waiting instance after a wait between workgroups expired.  MI355_SW_EINVAL for an unknown name. */
 int mi355_sw_last_counter(const mi355_sw_ctx *ctx, const char *name, uint64_t *out);
+
+/* Which kernels and pipeline decisions the last call used: space-separated tags, each at most once, e.g.
+ * "score[cell=f16,SL=8,R=19,...,sampled=1,...] strip[R=3,mode=max,...] wave[orient=0,...,dirs=1,...] walk_wave" — what the parity
+ * tests assert a switch of mi355_sw_set_option ENGAGED with.  Valid until the next call on the context; never NULL. */
+const char *mi355_sw_last_path(const mi355_sw_ctx *ctx);
 
 /* Which sw_score_kernel instance swept the most cells in the last call (what the `iterate` of
  * similaritymatrix.cpp:99-264 / :386-561 became for this input): reporting aid for drivers and bench.py, so

@@ -15,6 +15,11 @@
 //   range  <npiece> <shortlen> <longlen> <ratio>
 //   true2raw <m> <n> <ti> <tj>      raw2true <m> <n> <ri> <rj>     (m=|x|, n=|y|)
 //   bench  <file> <npiece> <nrepeat>                     (file: line 1 ref, then reads)
+//   loadref <file>                                       (line 1 of the file = y for the alignref commands that follow)
+//   alignref <f32|u8> <match> <mismatch> <gap> <x>       (align against the loaded y: full-size fixtures, 50 Mbp)
+//   manyfirst <file> <y>                                 (every line of the file as FIRST argument against y, float engine,
+//                                                         default scoring: the loop of src/mpi_sw_solve_uniprot.cpp:95-138;
+//                                                         replies one line "score pos" per sequence, then "done <count>")
 // Replies: one line per command.
 #include <chrono>
 #include <cstdint>
@@ -136,6 +141,7 @@ void do_bench(const std::string &path, int npiece, int nrepeat) {
 int main() {
   std::ios::sync_with_stdio(false);
   std::string line;
+  std::string loaded;                        // y of the alignref commands
   while (std::getline(std::cin, line)) {
     std::istringstream is(line);
     std::string cmd;
@@ -174,6 +180,31 @@ int main() {
       Similarity_Matrix_Skewed sm(std::string(m, 'A'), std::string(n, 'A'));
       auto r = cmd == "true2raw" ? sm.trueindex2rawindex(index_tuple(a, b)) : sm.rawindex2trueindex(index_tuple(a, b));
       std::cout << r.first << " " << r.second << "\n";
+    } else if (cmd == "loadref") {
+      std::string path;
+      is >> path;
+      std::ifstream f(path);
+      std::getline(f, loaded);
+      std::cout << "loaded " << loaded.size() << "\n";
+    } else if (cmd == "alignref") {
+      std::string sem, x; float ma, mi, gap;
+      is >> sem >> ma >> mi >> gap >> x;
+      auto f = [ma, mi](const char &a, const char &b) { return a == b ? ma : mi; };
+      if (sem == "f32") do_align<Similarity_Matrix>(x, loaded, f, gap); else do_align<Similarity_Matrix_Skewed>(x, loaded, f, gap);
+    } else if (cmd == "manyfirst") {
+      std::string path, y, seq;
+      is >> path >> y;
+      std::ifstream f(path);
+      size_t count = 0;
+      char buf[64];
+      while (std::getline(f, seq)) {
+        SWAligner<Similarity_Matrix> la(seq, y);          // (db sequence, query): mpi_sw_solve_uniprot.cpp:120
+        la.calculateScore();
+        std::snprintf(buf, sizeof buf, "%.9g %u\n", (double)la.getScore(), la.getPos());
+        std::cout << buf;
+        ++count;
+      }
+      std::cout << "done " << count << "\n";
     } else if (cmd == "bench") {
       std::string path; int npiece, nrepeat;
       is >> path >> npiece >> nrepeat;

@@ -20,7 +20,7 @@ EXPORTS = [
     "mi355_sw_multi_create", "mi355_sw_multi_destroy", "mi355_sw_multi_last_error", "mi355_sw_multi_device_count",
     "mi355_sw_multi_rccl_version", "mi355_sw_multi_align_split", "mi355_sw_multi_set_reference",
     "mi355_sw_multi_align_batch", "mi355_sw_multi_last_timings",
-    "mi355_sw_set_option", "mi355_sw_option_names", "mi355_sw_multi_set_option", "mi355_sw_last_counters", "mi355_sw_last_counter", "mi355_sw_batch_upload_packed", "mi355_sw_best_range",
+    "mi355_sw_set_option", "mi355_sw_option_names", "mi355_sw_multi_set_option", "mi355_sw_last_counters", "mi355_sw_last_counter", "mi355_sw_batch_upload_packed", "mi355_sw_best_range", "mi355_sw_last_path",
 ]
 MULTI_RCCL = 1
 
@@ -79,6 +79,7 @@ def lib():
         L.mi355_sw_build_info.restype = C.c_char_p
         L.mi355_sw_multi_last_error.restype = C.c_char_p
         L.mi355_sw_option_names.restype = C.c_char_p
+        L.mi355_sw_last_path.restype = C.c_char_p
         for name in EXPORTS:
             getattr(L, name)
         _LIB = L
@@ -307,10 +308,17 @@ class Context:
         c = (C.c_uint64 * 4)()
         self._L.mi355_sw_last_counters(self._ctx, c)
         out = dict(requeried=int(c[0]), whole_batch_again=int(c[1]), candidates=int(c[2]), left_window=int(c[3]))
-        v = C.c_uint64(0)
-        self._chk(self._L.mi355_sw_last_counter(self._ctx, b"first_settled", C.byref(v)))
-        out["first_settled"] = int(v.value)
+        for name in ("first_settled", "saved_locates", "saved_traces", "saved_fallbacks", "wait_retries"):
+            v = C.c_uint64(0)
+            rc = self._L.mi355_sw_last_counter(self._ctx, name.encode(), C.byref(v))
+            if rc:
+                raise MI355Error(rc, "mi355_sw_last_counter(%s)" % name)
+            out[name] = int(v.value)
         return out
+
+    def last_path(self):
+        """Tags of the kernels / pipeline decisions of the last call (mi355_sw_last_path), as a list."""
+        return self._L.mi355_sw_last_path(self._ctx).decode().split()
 
     def last_kernel(self):
         """The sw_score_kernel instance that swept the most cells in the last call (mi355_sw_last_kernel)."""

@@ -46,9 +46,41 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   // sequences: walks of a dozen cells; a walk that leaves its window hands the problem to the host-driven path below).
   const bool prof = orient == 1 && wave_prof_ok(ref, p, R, (int)nref, true);
   const bool windows = prof && want_trace && !opt().no_wave_window;
+  // Long streams in pieces (sw_batch_kernels.h): kPieceRows own rows behind a warm-up of the L1 margin along the stream (a path
+  // that ends in row i of x spans fewer than |y| + ceil(smax |y| / g) rows) plus the reach of a decision window in front of an
+  // own row (kWindowGuard + 63 + 1), so that own rows and the checkpoints their windows resume from are exact.  Only where the
+  // pass keeps no whole-problem decisions (score + argmax, or checkpointed windows).
+  std::vector<int32_t> pc_seq, pc_start, pc_rows, pc_first;
+  std::vector<int64_t> pc_before;
+  int nlong = 0;
+  int64_t piece_stream = 0, long_stream = 0;
+  if (prof && (windows || !want_trace) && !opt().no_wave_pieces) {
+    const Margin mg = make_margin(p.match, p.gap, true, (double)nref);   // (the profile kernel's scores are dyadic: exact arithmetic)
+    const int64_t warm = mg.finite() ? (mg.cols((double)nref) + kWindowGuard + 64 + 63) / 64 * 64 : -1;
+    const int64_t split_above = kPieceRows + warm;                   // (shorter sequences would not get shorter as pieces)
+    if (warm > 0 && warm <= 4 * kPieceRows) {
+      pc_first.push_back(0);
+      for (size_t k = 0; k < count; ++k) {                           // launch order: longest first
+        const int64_t m = q.len[q.order[first + count - 1 - k]];
+        if (m <= split_above) break;
+        for (int64_t own = 0; own < m; own += kPieceRows) {
+          const int64_t start = std::max<int64_t>(0, own - warm), end = std::min<int64_t>(m, own + kPieceRows);
+          pc_seq.push_back((int32_t)k); pc_start.push_back((int32_t)start); pc_rows.push_back((int32_t)(end - start));
+          pc_before.push_back(piece_stream);
+          piece_stream += end - start;
+        }
+        pc_first.push_back((int32_t)pc_seq.size());
+        long_stream += m;
+        ++nlong;
+      }
+    }
+  }
+  const size_t npieces = pc_seq.size();
+  const size_t nprob = npieces + (count - (size_t)nlong);           // problems of the first pass
+  const int64_t stream_all = stream_total - long_stream + piece_stream;
   const size_t dirs_total = !want_trace ? 0 : windows ? count * (size_t)kWindowRows * 16 * (size_t)W * 4
                                                       : (size_t)batch_dirs_offset(stream_total, (int64_t)count, W);
-  const size_t ckpt_total = windows ? ((size_t)batch_ckpt_row(stream_total, (int64_t)count) + 1) * 16 * (size_t)(R + 1) * 4 : 0;
+  const size_t ckpt_total = windows ? ((size_t)batch_ckpt_row(stream_all, (int64_t)nprob) + 1) * 16 * (size_t)(R + 1) * 4 : 0;
   if (dirs_total + ckpt_total > kDirsBudget || count > ((size_t)1 << 30)) {
     if (count == 1) return 0;
     const size_t half = count / 2;
@@ -60,9 +92,11 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   const size_t n = count;
   // device scratch: problems, (best, cell), decisions, walk descriptors + (len, pos, status) + consensus offsets + total
   const size_t walk_bytes = n * sizeof(WaveWalk) + n * 24 + (n + 1) * 8 + 64;
-  if (ctx->wprobs.ensure(n * sizeof(WaveProblem)) || ctx->outs_f.ensure(n * 4) || ctx->outs_i.ensure(n * 16) ||
+  // problems of the first pass, then [n] decision windows; per problem (best, cell), then per sequence (best, cell, problem)
+  const size_t pc_bytes = npieces ? (4 * npieces + (size_t)nlong + 1) * 4 + npieces * 8 + 64 : 0;
+  if (ctx->wprobs.ensure((nprob + n) * sizeof(WaveProblem)) || ctx->outs_f.ensure((nprob + n) * 4 + n * 4 + 64) || ctx->outs_i.ensure((nprob + n) * 16) ||
       (dirs_total && ctx->dirs.ensure(dirs_total)) || (ckpt_total && ctx->ckpt.ensure(ckpt_total)) ||
-      (want_trace && ctx->walkp.ensure(walk_bytes)))
+      (want_trace && ctx->walkp.ensure(walk_bytes)) || (pc_bytes && ctx->pieces.ensure(pc_bytes)))
     return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(batch scratch) failed");
   BatchWaveArgs a;
   a.qbytes = q.bytes.as<uint8_t>(); a.qoff = q.offs.as<int64_t>(); a.qlen = q.lens.as<int32_t>();
@@ -75,22 +109,50 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   a.cell = ctx->outs_i.as<int64_t>();
   a.ckpt = windows ? ctx->ckpt.as<float>() : nullptr;
   a.R = R;
+  a.nlong = nlong; a.npieces = (int)npieces; a.piece_rows = kPieceRows; a.piece_stream = piece_stream; a.long_stream = long_stream;
+  a.pc_seq = a.pc_start = a.pc_rows = a.pc_first = nullptr; a.pc_before = nullptr;
+  if (npieces) {
+    // the piece table: a few thousand entries (the sequences beyond ~1.5 k residues), rebuilt and sent with every call
+    uint8_t *dev = ctx->pieces.as<uint8_t>();
+    const size_t o_before = 0, o_seq = npieces * 8, o_start = o_seq + npieces * 4, o_rows = o_start + npieces * 4, o_first = o_rows + npieces * 4;
+    ctx->h_pieces.resize(pc_bytes);
+    memcpy(ctx->h_pieces.data() + o_before, pc_before.data(), npieces * 8);
+    memcpy(ctx->h_pieces.data() + o_seq, pc_seq.data(), npieces * 4);
+    memcpy(ctx->h_pieces.data() + o_start, pc_start.data(), npieces * 4);
+    memcpy(ctx->h_pieces.data() + o_rows, pc_rows.data(), npieces * 4);
+    memcpy(ctx->h_pieces.data() + o_first, pc_first.data(), ((size_t)nlong + 1) * 4);
+    HIPCHK(ctx, hipMemcpyAsync(dev, ctx->h_pieces.data(), o_first + ((size_t)nlong + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    a.pc_before = reinterpret_cast<const int64_t *>(dev + o_before);
+    a.pc_seq = reinterpret_cast<const int32_t *>(dev + o_seq);
+    a.pc_start = reinterpret_cast<const int32_t *>(dev + o_start);
+    a.pc_rows = reinterpret_cast<const int32_t *>(dev + o_rows);
+    a.pc_first = reinterpret_cast<const int32_t *>(dev + o_first);
+  }
+  // per sequence: results after the merge (whole sequences without pieces: the problem arrays themselves)
+  a.sbest = npieces ? ctx->outs_f.as<float>() + nprob : a.best;
+  a.scell = npieces ? ctx->outs_i.as<int64_t>() + 2 * nprob : a.cell;
+  a.sprob = reinterpret_cast<int32_t *>(ctx->outs_f.as<float>() + nprob + n);
+  a.probs2 = ctx->wprobs.as<WaveProblem>() + nprob;
   const unsigned sblocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(batch_wave_setup, dim3(sblocks), dim3(256), 0, ctx->stream, a);
+  hipLaunchKernelGGL(batch_wave_setup, dim3((unsigned)((nprob + 255) / 256)), dim3(256), 0, ctx->stream, a);
   WaveScoring sc;
   sc.match = p.match; sc.mismatch = p.mismatch; sc.gap = p.gap;
   sc.u8M = sc.u8X = sc.u8G = 0.0f;
-  const unsigned blocks = (unsigned)((n + 15) / 16);
+  const unsigned blocks = (unsigned)((n + 15) / 16), pblocks = (unsigned)((nprob + 15) / 16);
   const WaveProblem *dp = ctx->wprobs.as<WaveProblem>();
+  const WaveProblem *dp_walk = dp;                                   // the problems the walks read their decisions from
   if (windows) {
-    int rc = launch_wave_prof(ctx, ref, p, R, (int)nref, true, false, blocks, dp, (int)n);
+    int rc = launch_wave_prof(ctx, ref, p, R, (int)nref, true, false, pblocks, dp, (int)nprob);
     if (rc) return rc < 0 ? rc : fail(ctx, MI355_SW_ENODEV, "internal: the profile kernel refused a launch it had accepted");
+    hipLaunchKernelGGL(batch_seq_results, dim3(sblocks), dim3(256), 0, ctx->stream, a);   // (always: it also names every sequence's problem)
     hipLaunchKernelGGL(batch_window_setup, dim3(sblocks), dim3(256), 0, ctx->stream, a);
-    rc = launch_wave_prof(ctx, ref, p, R, (int)nref, false, true, blocks, dp, (int)n);
+    rc = launch_wave_prof(ctx, ref, p, R, (int)nref, false, true, blocks, (const WaveProblem *)a.probs2, (int)n);
     if (rc) return rc < 0 ? rc : fail(ctx, MI355_SW_ENODEV, "internal: the profile kernel refused a launch it had accepted");
+    dp_walk = a.probs2;
   } else {
-    const int prof_rc = prof ? launch_wave_prof(ctx, ref, p, R, (int)nref, true, want_trace, blocks, dp, (int)n) : 1;
+    const int prof_rc = prof ? launch_wave_prof(ctx, ref, p, R, (int)nref, true, want_trace, pblocks, dp, (int)nprob) : 1;
     if (prof_rc < 0) return prof_rc;
+    if (prof_rc == 0 && npieces) hipLaunchKernelGGL(batch_seq_results, dim3(sblocks), dim3(256), 0, ctx->stream, a);
 #define BATCH_WAVE(r)                                                                                                   \
   if (orient == 0) launch_wave_batch<r, 0>(want_trace, blocks, ctx->stream, dp, (int)n, sc);                            \
   else launch_wave_batch<r, 1>(want_trace, blocks, ctx->stream, dp, (int)n, sc);
@@ -99,6 +161,7 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
 #undef BATCH_WAVE
   }
   HIPCHK(ctx, hipGetLastError());
+  path_note(ctx, "devlist[orient=%d,R=%d,prof=%d,windows=%d,trace=%d,pieces=%d]", orient, R, (int)prof, (int)windows, (int)want_trace, (int)(npieces != 0));
 
   // results land in pinned staging: [best n x 4][cell n x 16][wout n x 24][offs (n + 1) x 8]
   const size_t o_best = 0, o_cell = (n * 4 + 15) & ~(size_t)15, o_wout = o_cell + n * 16, o_offs = o_wout + n * 24;
@@ -108,17 +171,17 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   int64_t *h_cell = reinterpret_cast<int64_t *>(pin + o_cell);
   int64_t *h_wout = reinterpret_cast<int64_t *>(pin + o_wout);
   int64_t *h_offs = reinterpret_cast<int64_t *>(pin + o_offs);
-  HIPCHK(ctx, hipMemcpyAsync(h_best, ctx->outs_f.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(h_cell, ctx->outs_i.p, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(h_best, a.sbest, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(h_cell, a.scell, n * 16, hipMemcpyDeviceToHost, ctx->stream));
   const char *cons_base = nullptr;
   if (want_trace) {
     WaveWalk *walks = ctx->walkp.as<WaveWalk>();
     int64_t *wout = reinterpret_cast<int64_t *>(ctx->walkp.as<uint8_t>() + n * sizeof(WaveWalk));
     int64_t *offs = wout + 3 * n;                                  // [n] sizes -> offsets, then [1] total
     BatchWalkArgs b;
-    b.probs = dp; b.qbytes = a.qbytes; b.qoff = a.qoff; b.qsel = a.qsel; b.ref = a.ref;
+    b.probs = dp_walk; b.qbytes = a.qbytes; b.qoff = a.qoff; b.qsel = a.qsel; b.ref = a.ref;
     b.first = (int)first; b.count = (int)n; b.orient = orient; b.R = R;
-    b.best = a.best; b.cell = a.cell; b.walks = walks; b.wout = wout;
+    b.best = a.sbest; b.cell = a.scell; b.walks = walks; b.wout = wout;
     hipLaunchKernelGGL(batch_walk_setup, dim3(sblocks), dim3(256), 0, ctx->stream, b);
     const unsigned wblocks = (unsigned)((n + 63) / 64);
     hipLaunchKernelGGL(sw_wave_walk_kernel<kWalkMeasure>, dim3(wblocks), dim3(64), 0, ctx->stream, (const WaveWalk *)walks, (int)n,
@@ -149,7 +212,7 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   std::atomic<size_t> left{0};
   parallel_for(n, [&](size_t k0, size_t k1) {
     for (size_t k = k0; k < k1; ++k) {
-      const int id = q.order[first + k];
+      const int id = q.order[batch_sorted_pos((int)first, (int)n, (int)k)];
       const bool hit = h_best[k] > 0;
       if (want_trace && hit && h_wout[3 * k + 2] != 0) {
         // a walk that left its window: the problem goes to the host-driven path (handled stays 0); on whole problems: a bug

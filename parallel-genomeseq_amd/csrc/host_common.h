@@ -13,9 +13,9 @@ constexpr size_t kExactLdsMax = 159 * 1024;    // dynamic part; the wide instanc
 // calling thread to its context's options for the duration of the call (a context serves one host thread at a time).
 #define MI355_SW_BOOL_OPTIONS(X) \
   X(no_f16) X(no_unsat) X(no_sample) X(no_satflag) X(no_solo) X(no_wave) X(no_comb) X(no_twin) X(no_wide) X(no_strip) \
-  X(no_quant) X(no_f16_wide) X(no_devlist) X(no_ref_cache) X(no_strip_groups) X(u8_long_twin) X(long_twin) X(no_long) \
-  X(no_requery) X(force_f32) X(no_long_p32) X(no_opt_margin) X(no_wave_prof) X(no_wave_window) X(no_first) X(trace)
-#define MI355_SW_INT_OPTIONS(X) X(strip_r) X(slot) X(few_r) X(chunk) X(long_pipes) X(long_wgs) X(long_sub) X(long_r) X(long_groups)
+  X(no_quant) X(no_devlist) X(no_ref_cache) X(no_strip_groups) X(u8_long_twin) X(long_twin) X(no_long) \
+  X(no_requery) X(force_f32) X(no_long_p32) X(no_opt_margin) X(no_wave_prof) X(no_wave_window) X(no_first) X(no_long_save) X(u8_sample_short) X(no_wave_pieces) X(trace)
+#define MI355_SW_INT_OPTIONS(X) X(strip_r) X(slot) X(few_r) X(chunk) X(long_pipes) X(long_wgs) X(long_sub) X(long_r) X(long_groups) X(assume_cus)
 struct Options {
 #define X(n) bool n = false;
   MI355_SW_BOOL_OPTIONS(X)
@@ -23,7 +23,7 @@ struct Options {
 #define X(n) long n = 0;
   MI355_SW_INT_OPTIONS(X)
 #undef X
-  int fault_inject = 0;           // test hook, only through mi355_sw_set_option("fault_inject", "strip_stall"): never from the environment
+  int fault_inject = 0;           // test hook, only through mi355_sw_set_option("fault_inject", "strip_stall" | "long_stall"): never from the environment
 };
 inline std::string option_env_name(const char *n) {
   std::string e = "MI355_SW_";
@@ -53,7 +53,7 @@ inline int option_set(Options &o, const char *key, const char *value) {
 #define X(n) if (k == #n) { o.n = on ? std::atol(v.c_str()) : 0; return 0; }
   MI355_SW_INT_OPTIONS(X)
 #undef X
-  if (k == "fault_inject") { o.fault_inject = v == "strip_stall" ? 1 : 0; return 0; }
+  if (k == "fault_inject") { o.fault_inject = v == "strip_stall" ? 1 : (v == "long_stall" ? 2 : 0); return 0; }
   return -1;
 }
 inline const char *option_names() {
@@ -68,6 +68,25 @@ inline const Options &opt() {
   static const Options env = options_from_env();       // before any context exists on this thread
   return tl_opt ? *tl_opt : env;
 }
+
+// What the launch sizing needs to know about the device (hipGetDeviceProperties in mi355_sw_create; option assume_cus overrides the
+// CU count for tests and partitioned devices), bound to the calling thread with the options.
+struct DevInfo {
+  int cus = 256;                  // multiProcessorCount (MI355X: 256; a CPX partition: 32)
+  size_t lds = 160 * 1024;        // LDS bytes per CU
+};
+thread_local const DevInfo *tl_dev = nullptr;
+inline int dev_cus() {
+  const long v = opt().assume_cus;
+  if (v > 0) return (int)std::min<long>(v, 4096);
+  return tl_dev ? std::max(1, tl_dev->cus) : 256;
+}
+inline size_t dev_lds() { return tl_dev ? tl_dev->lds : (size_t)160 * 1024; }
+// Set for the rest of a C-ABI call after a kernel whose workgroups wait for each other (sw_long_kernel with several workgroups per
+// tile, the grouped sw_strip_kernel) reported an expired wait: the work is repeated on the instances whose waits stay inside one
+// workgroup — resident by construction — instead of failing the call (a partitioned or shared device may not hold every
+// workgroup of a launch at once, whatever the host assumed).
+thread_local bool tl_no_wait = false;
 
 // option `trace`: wall-clock of the host-side phases of every call on stderr (diagnostic)
 struct HostTrace {
@@ -226,6 +245,7 @@ struct TraceOut {                  // consensus strings of one alignment: views 
 // tile geometry they were made with, valid while reference, batch and scoring stay the same.
 struct ScoredRanges {
   bool valid = false;
+  const void *ref = nullptr, *batch = nullptr;   // the RefData / QueryBatch objects the sweep ran on, and their versions
   uint64_t ref_version = 0, batch_version = 0;
   mi355_sw_params params = {};
   std::vector<Range> ranges;
@@ -238,6 +258,22 @@ struct ScoredRanges {
   bool sampled = false;
   std::vector<char> has_located;          // [nranges]
   std::vector<Located> located;           // [nranges]
+};
+
+// What the last sw_long_kernel launch saved for the finish (sw_long_kernel.h colsave / rowsave, host_saved.h): the H column
+// in front of every sub-chunk and the bottom row of every strip, so that locate and traceback windows start from stored exact
+// values instead of a zero border and a warm-up margin.  Valid for the (reference, batch, scoring, ranges) of that launch.
+struct LongSaved {
+  bool valid = false;
+  const void *ref = nullptr, *batch = nullptr;
+  uint64_t ref_version = 0, batch_version = 0;
+  mi355_sw_params params = {};
+  int qid = 0;
+  std::vector<Range> ranges;
+  int64_t chunk = 0, sub_len = 0, warm = 0;   // tile geometry of the launch (own columns, sub-chunk, warm-up actually used)
+  int nstrips = 0, R = 0, spt = 0;            // strips of the query, rows per lane, sub-chunks per tile
+  int64_t tiles_stride = 0, col_subs = 0, col_rows = 0, row_stride = 0;
+  int fshift = 0;                             // saved values are H * 2^-fshift
 };
 
 // results of mi355_sw_batch_run_view: arrays the context owns until its next call
@@ -278,6 +314,13 @@ struct mi355_sw_ctx {
   float long_cert = -1.0f;        // maxima ABOVE this value were swept exactly by the last sw_long_kernel launch (-1: all of them)
   int64_t long_nsub = 0;          // sub-chunks per range of the last sampled sw_long_kernel launch (decodes its flag entries)
   bool long_launched = false;     // a sw_long_kernel launch since the last score_fetch (its status word is flags[1])
+  std::string path;               // which kernels / pipelines the running call used (mi355_sw_last_path): space-separated tags
+  DevInfo dev;                    // CU count and LDS per CU of this context's device
+  size_t wait_retries = 0;        // launches of the running call that were repeated on a non-waiting instance (tl_no_wait)
+  LongSaved lsaved;
+  DevBuf colsave, rowsave, pieces;
+  std::vector<uint8_t> h_pieces;  // host side of the piece table of the running call (host_batch.h)
+  size_t saved_locates = 0, saved_traces = 0, saved_fallbacks = 0;   // finish steps of the running call that started from saved state / fell back
   DevBuf qcnt, sel2, gcnt, wlut, ckpt, first, keys, ranges, stab, ftab, ftab_s, htab, htab8, soloblk, flags, submax, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs, scan;
   // host sides of small per-call uploads: they must outlive the asynchronous copies, and the tables are only
   // sent again when they change
@@ -309,8 +352,9 @@ namespace {
 // binds the calling thread to a context's options for the duration of a C-ABI call (nests)
 struct OptScope {
   const Options *prev;
-  explicit OptScope(const mi355_sw_ctx *c) : prev(tl_opt) { if (c) tl_opt = &c->opts; }
-  ~OptScope() { tl_opt = prev; }
+  const DevInfo *prev_dev;
+  explicit OptScope(const mi355_sw_ctx *c) : prev(tl_opt), prev_dev(tl_dev) { if (c) { tl_opt = &c->opts; tl_dev = &c->dev; } }
+  ~OptScope() { tl_opt = prev; tl_dev = prev_dev; if (!prev) tl_no_wait = false; }
 };
 
 #define HIPCHK(ctx, call)                                                                  \
@@ -321,6 +365,21 @@ struct OptScope {
       return MI355_SW_ENODEV;                                                              \
     }                                                                                      \
   } while (0)
+
+// One tag per kernel family / pipeline decision of the running call, each at most once (mi355_sw_last_path: what the parity
+// tests assert a switch ENGAGED with — a switch that is silently ignored would still give the oracle's answers).
+void path_note(mi355_sw_ctx *ctx, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void path_note(mi355_sw_ctx *ctx, const char *fmt, ...) {
+  char buf[192];
+  va_list ap;
+  va_start(ap, fmt);
+  std::vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  const std::string tag(buf), hay = " " + ctx->path + " ";
+  if (ctx->path.size() > 8192 || hay.find(" " + tag + " ") != std::string::npos) return;
+  if (!ctx->path.empty()) ctx->path += ' ';
+  ctx->path += tag;
+}
 
 int fail(mi355_sw_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->err = msg;
@@ -470,7 +529,9 @@ void parallel_for(size_t n, F fn) {
   const int nt = n >= 262144 ? 8 : 4;                              // (half a million alignments per call: eight threads)
   const size_t step = (n + nt - 1) / nt;
   std::future<void> parts[7];
-  for (int t = 0; t + 1 < nt; ++t) parts[t] = std::async(std::launch::async, fn, std::min(n, (size_t)(t + 1) * step), std::min(n, (size_t)(t + 2) * step));
+  const Options *caller = tl_opt;                                  // the workers see the calling context's options, not the environment's
+  auto bound = [caller, &fn](size_t k0, size_t k1) { const Options *was = tl_opt; tl_opt = caller; fn(k0, k1); tl_opt = was; };
+  for (int t = 0; t + 1 < nt; ++t) parts[t] = std::async(std::launch::async, bound, std::min(n, (size_t)(t + 1) * step), std::min(n, (size_t)(t + 2) * step));
   fn((size_t)0, std::min(n, step));
   for (int t = 0; t + 1 < nt; ++t) parts[t].get();
 }
@@ -628,32 +689,34 @@ int upload_queries(mi355_sw_ctx *ctx, QueryBatch &q, size_t n, const char *const
 // on the host), sequence k = buf[offsets[k], offsets[k + 1]).
 int upload_queries_packed(mi355_sw_ctx *ctx, QueryBatch &q, size_t n, const char *buf, const int64_t *offsets) {
   HostTrace trace_("upload_queries_packed");
+  // the offsets are validated BEFORE anything is sized from them or leaves the caller's buffer
   if (n && offsets[0] < 0) return fail(ctx, MI355_SW_EINVAL, "negative offset");
+  for (size_t k = 0; k < n; ++k) {
+    const int64_t len = offsets[k + 1] - offsets[k];
+    if (len < 0 || len > 0x3fffffff) return fail(ctx, MI355_SW_EINVAL, "offsets must ascend (sequence longer than 2^30 or negative length)");
+  }
   const size_t base = n ? (size_t)offsets[0] : 0, tot = n ? (size_t)(offsets[n] - offsets[0]) : 0;
   if (q.bytes.ensure(tot + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(queries) failed");
+  // every exit after the first enqueue waits for the stream: no copy out of caller-owned memory is in flight when the call returns
+  auto leave = [&](int rc) { (void)hipStreamSynchronize(ctx->stream); if (rc) q.nq = 0; return rc; };
   const size_t piece = (size_t)32 << 20;
   for (size_t at = 0; at < tot; at += piece)                         // asynchronous to the host work below
-    HIPCHK(ctx, hipMemcpyAsync(q.bytes.as<uint8_t>() + at, buf + base + at, std::min(piece, tot - at), hipMemcpyHostToDevice, ctx->stream));
+    if (hipMemcpyAsync(q.bytes.as<uint8_t>() + at, buf + base + at, std::min(piece, tot - at), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      return leave(fail(ctx, MI355_SW_ENODEV, "hipMemcpyAsync(queries) failed"));
   q.nq = n;
   ++q.version;
   q.len.resize(n);
   q.off.resize(n);
   size_t mx = 0;
-  bool bad = false;
   for (size_t k = 0; k < n; ++k) {
     const int64_t len = offsets[k + 1] - offsets[k];
-    bad |= len < 0 || len > 0x3fffffff;
     q.len[k] = (int32_t)len;
     q.off[k] = offsets[k] - (int64_t)base;
-    mx = std::max(mx, (size_t)std::max<int64_t>(len, 0));
+    mx = std::max(mx, (size_t)len);
   }
-  if (bad) { (void)hipStreamSynchronize(ctx->stream); q.nq = 0; return fail(ctx, MI355_SW_EINVAL, "offsets must ascend (sequence longer than 2^30 or negative length)"); }
   q.maxlen = (int)mx;
   sort_queries_by_length(q, mx);
-  int rc = upload_query_index(ctx, q, tot);
-  if (rc) return rc;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  return 0;
+  return leave(upload_query_index(ctx, q, tot));
 }
 
 }  // namespace

@@ -54,6 +54,7 @@ int run_exact(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
     if (j.want_dirs) { j.dirs_off = dirs_total; dirs_total += dirs_bytes(q.len[j.q], j.nw); dirs_total = (dirs_total + 15) & ~(size_t)15; }
   }
   if (lds > kExactLdsMax) return fail(ctx, MI355_SW_ENOTSUP, "anti-diagonal longer than the exact kernel's LDS window");
+  path_note(ctx, "exact[u8=%d,dirs=%d]", (int)(p.semantics == MI355_SW_U8SAT), (int)(dirs_total != 0));
   if (ctx->probs.ensure(n * sizeof(ExactProblem)) || ctx->outs_f.ensure(n * 4) || ctx->outs_i.ensure(n * 16) ||
       (dirs_total && ctx->dirs.ensure(dirs_total)))
     return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(exact scratch) failed");

@@ -208,11 +208,11 @@ int mi355_sw_multi_align_split(mi355_sw_multi *m, const char *x, size_t nx, cons
   OptScope opt_scope0_(m->ctx[0]);
   mi355_sw_params ps = *params;
   ps.semantics = sm_semantics;
-  std::vector<float> pmax(npiece, 0.0f);
   std::vector<unsigned long long> gkey(ndev, 0ull);
   std::vector<const RefData *> refs(ndev, nullptr);
   std::vector<std::vector<Range>> local(ndev);                     // device d's pieces inside ITS resident buffer
   std::vector<std::vector<int>> ids(ndev);
+  // first pass: every device stages, hashes and uploads its pieces and the query
   rc = on_devices(m, [&](int d) -> int {
     mi355_sw_ctx *c = m->ctx[d];
     OptScope opt_scope_(c);
@@ -224,40 +224,61 @@ int mi355_sw_multi_align_split(mi355_sw_multi *m, const char *x, size_t nx, cons
       local[d].push_back(ndev == 1 ? Range{lefts[p], rights[p]} : Range{(int64_t)total, (int64_t)total + (rights[p] - lefts[p])});
       total += (size_t)(rights[p] - lefts[p]);
     }
-    unsigned long long key = 0;                                    // "no piece": below every real key
-    if (!ids[d].empty()) {
-      int r = 0;
-      if (ndev == 1) {
-        r = adhoc_reference(c, y, ny, &refs[d]);
-      } else {
-        std::unique_ptr<char[]> stage(new char[total + 1]);
-        for (size_t k = 0; k < ids[d].size(); ++k)
-          memcpy(stage.get() + local[d][k].lo, y + lefts[ids[d][k]], (size_t)(rights[ids[d][k]] - lefts[ids[d][k]]));
-        r = adhoc_reference(c, stage.get(), total, &refs[d]);
-      }
-      if (!r) r = upload_queries(c, c->one, 1, &x, &nx);
-      std::vector<float> mx(ids[d].size(), 0.0f);
-      if (!r) r = range_maxima(c, *refs[d], c->one, local[d], ps, mx.data());
-      if (r) return r;
-      for (size_t k = 0; k < ids[d].size(); ++k) {
-        pmax[ids[d][k]] = mx[k];
-        key = std::max(key, pack_best(mx[k], (uint32_t)ids[d][k]));
-      }
+    if (ids[d].empty()) return 0;
+    int r = 0;
+    if (ndev == 1) {
+      r = adhoc_reference(c, y, ny, &refs[d]);
+    } else {
+      std::unique_ptr<char[]> stage(new char[total + 1]);
+      for (size_t k = 0; k < ids[d].size(); ++k)
+        memcpy(stage.get() + local[d][k].lo, y + lefts[ids[d][k]], (size_t)(rights[ids[d][k]] - lefts[ids[d][k]]));
+      r = adhoc_reference(c, stage.get(), total, &refs[d]);
     }
-    gkey[d] = key;
-    return 0;
+    if (!r) r = upload_queries(c, c->one, 1, &x, &nx);
+    return r;
   });
   if (rc) return rc;
+  // Winner-only sweeps (what mi355_sw_best_range offers a rank of the one-process-per-GPU form): all the reference does with the
+  // per-piece maxima is pick the first piece with the strictly greatest one (plocalaligner.cpp:122-129).  A lone long query is
+  // swept behind an optimistic warm-up margin; the certification is GLOBAL: every device reports the value above which its
+  // sweep was exact (the same on all of them), the merged best must exceed it, else every device sweeps again with the
+  // margin the merged best needs — decided here, once, for all devices (at most three rounds).
   unsigned long long best = 0;
-  if (m->flags & MI355_SW_MULTI_RCCL) {
-    // second phase, entered only when every device finished its sweep: nobody can be left waiting in the collective
-    rc = merge_keys_rccl(m, gkey);
+  float known = 0.0f;
+  for (int round = 0; round < 3; ++round) {
+    std::vector<float> above(ndev, -1.0f);
+    rc = on_devices(m, [&](int d) -> int {
+      mi355_sw_ctx *c = m->ctx[d];
+      OptScope opt_scope_(c);
+      HIPCHK(c, hipSetDevice(c->device));
+      unsigned long long key = 0;                                  // "no piece": below every real key
+      if (!ids[d].empty()) {
+        std::vector<float> mx(ids[d].size(), 0.0f);
+        const int r = range_maxima(c, *refs[d], c->one, local[d], ps, mx.data(), true, known, &above[d]);
+        if (r) return r;
+        for (size_t k = 0; k < ids[d].size(); ++k) key = std::max(key, pack_best(mx[k], (uint32_t)ids[d][k]));
+      }
+      gkey[d] = key;
+      return 0;
+    });
     if (rc) return rc;
-    best = gkey[0];
-    for (int d = 1; d < ndev; ++d)
-      if (gkey[d] != best) return mfail(m, MI355_SW_ENODEV, "internal: devices disagree after the all-reduce");
-  } else {
-    for (int d = 0; d < ndev; ++d) best = std::max(best, gkey[d]);
+    if (m->flags & MI355_SW_MULTI_RCCL) {
+      // second phase, entered only when every device finished its sweep: nobody can be left waiting in the collective
+      rc = merge_keys_rccl(m, gkey);
+      if (rc) return rc;
+      best = gkey[0];
+      for (int d = 1; d < ndev; ++d)
+        if (gkey[d] != best) return mfail(m, MI355_SW_ENODEV, "internal: devices disagree after the all-reduce");
+    } else {
+      best = 0;
+      for (int d = 0; d < ndev; ++d) best = std::max(best, gkey[d]);
+    }
+    float gbest, cert = -1.0f;
+    { const uint32_t bits = (uint32_t)(best >> 32); memcpy(&gbest, &bits, 4); }
+    for (int d = 0; d < ndev; ++d) cert = std::max(cert, above[d]);
+    if (gbest > cert) break;
+    if (round == 2) return mfail(m, MI355_SW_ENODEV, "internal: the merged best is not above what the sweeps certify after three rounds");
+    known = std::max(gbest, 1.0f);
   }
   const int bp = (int)(0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull));   // first piece with the strictly greatest maximum
   const int owner = bp % ndev;
@@ -269,7 +290,15 @@ int mi355_sw_multi_align_split(mi355_sw_multi *m, const char *x, size_t nx, cons
   mi355_sw_params pd;
   mi355_sw_default_params(&pd);                                    // LAT(x, piece): default scoring (plocalaligner.cpp:135)
   pd.semantics = la_semantics;
-  rc = align_range(c, *refs[owner], c->one, local[owner][(size_t)(bp / ndev)], pd, 0, out);
+  // default scoring in both roles: the owner finishes its piece from the sweep's keys instead of sweeping it a second time
+  // (the reference does sweep twice, :132-136)
+  const bool same_sweep = params->lut == nullptr && params->match == 3.0f && params->mismatch == -3.0f && params->gap == 2.0f &&
+                          sm_semantics == la_semantics;
+  const size_t li = (size_t)(bp / ndev);
+  const ScoredRanges &sc = c->scored;
+  const bool from_keys = same_sweep && sc.valid && sc.ref == (const void *)refs[owner] && sc.batch == (const void *)&c->one &&
+                         li < sc.ranges.size() && (!sc.sampled || sc.has_located[li]);
+  rc = align_range(c, *refs[owner], c->one, local[owner][li], pd, 0, out, from_keys ? &sc : nullptr, li);
   if (rc) return mfail(m, rc, c->err);
   if (out->score > 0) { out->pos += (uint32_t)lefts[bp]; out->end_y += lefts[bp]; }
   else out->pos = (uint32_t)lefts[bp];

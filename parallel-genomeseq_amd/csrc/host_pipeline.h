@@ -44,6 +44,18 @@ int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, co
       if (is_long ? strip_ok : wave_ok) { sub.push_back(qidx[k]); sl.push_back(loc[k]); owner.push_back(k); }
       else todo.push_back(k);
     }
+    // a lone long query whose sweep saved its columns / strip rows (host_saved.h): decisions from stored exact values, one
+    // block per (strip, sub-chunk) the walk can reach; what the walk's checks refuse takes the zero-border windows below
+    if (pass == 1 && q.nq == 1 && sub.size() == 1) {
+      const int sr = saved_range_index(ctx, ref, q, rg, p, sub[0]);
+      if (sr >= 0) {
+        TraceOut t1;
+        const int rc1 = trace_from_saved(ctx, ref, q, rg, p, sr, sub[0], sl[0], table, t1);
+        if (rc1 < 0) return rc1;
+        if (rc1 == 0) { tout[owner[0]] = t1; continue; }
+        ctx->saved_fallbacks += 1;
+      }
+    }
     if (sub.empty()) continue;
     std::vector<TraceOut> t2;
     const bool latency_mode = pass == 0 && sub.size() <= kLatencyJobs && strip_ok;
@@ -306,7 +318,7 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
       const int64_t sub_lo = std::max<int64_t>(0, cand[t] * chunk_len - 63);   // range-relative, 0-based
       const int64_t sub_hi = std::min((cand[t] + 1) * chunk_len, n);
       int64_t pieces = 1;
-      if (q.len[k] > 512) pieces = std::max<int64_t>(1, std::min<int64_t>((sub_hi - sub_lo) / 256, 224 / (int64_t)nlong));   // one 1024-thread workgroup per CU
+      if (q.len[k] > 512) pieces = std::max<int64_t>(1, std::min<int64_t>((sub_hi - sub_lo) / 256, (int64_t)(dev_cus() * 7 / 8) / (int64_t)nlong));   // one 1024-thread workgroup per CU
       const int64_t plen = (sub_hi - sub_lo + pieces - 1) / pieces;
       for (int64_t own_lo = sub_lo; own_lo < sub_hi; own_lo += plen) {
         const int64_t own_hi = std::min(own_lo + plen, sub_hi);
@@ -412,7 +424,7 @@ int locate_saturated(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       warm = std::min<int64_t>(warm, clamp_cols((double)q.len[k] + std::ceil(spare / mg.g) + 2.0));
     }
     int64_t pieces = 1;
-    if (q.len[k] > 512) pieces = std::max<int64_t>(1, std::min<int64_t>((sub_hi - sub_lo) / 256, 224 / (int64_t)std::max<size_t>(1, nlong)));
+    if (q.len[k] > 512) pieces = std::max<int64_t>(1, std::min<int64_t>((sub_hi - sub_lo) / 256, (int64_t)(dev_cus() * 7 / 8) / (int64_t)std::max<size_t>(1, nlong)));
     if (warm >= sub_hi) pieces = 1;                               // (every piece would start at column 0: no point in cutting)
     const int64_t plen = (sub_hi - sub_lo + pieces - 1) / pieces;
     for (int64_t own_lo = sub_lo; own_lo < sub_hi; own_lo += plen) {
@@ -441,6 +453,41 @@ int locate_saturated(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       }
     }
   }
+  return 0;
+}
+
+// locate_saturated, with the candidates of a lone long query taken from the state its sweep saved where that state covers
+// them (host_saved.h): blocks with known left column and top row instead of windows behind a zero border and a margin.
+int locate_flagged(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const Range &rg, const mi355_sw_params &p,
+                   const std::vector<int64_t> &qchunk, const std::vector<int64_t> &qwarm, const std::vector<float> &qlower,
+                   const ScoreTable &table, const std::vector<std::pair<uint32_t, uint32_t>> &flagged, std::vector<Located> &loc,
+                   std::vector<char> &done) {
+  const int qid = q.nq == 1 ? q.order[0] : -1;
+  const int sr = qid >= 0 ? saved_range_index(ctx, ref, q, rg, p, qid) : -1;
+  if (sr < 0 || flagged.empty() || qchunk[qid] != ctx->lsaved.sub_len)
+    return locate_saturated(ctx, ref, q, rg, p, qchunk, qwarm, qlower, table, flagged, loc, done);
+  std::vector<uint32_t> subs, rest;
+  for (const auto &f : flagged) if ((int)f.first == qid) subs.push_back(f.second);
+  Located L;
+  bool found = false;
+  int rc = locate_from_saved(ctx, ref, q, rg, p, sr, qid, qlower[qid], table, subs, L, found, rest);
+  if (rc) return rc;
+  if (!rest.empty()) {
+    ctx->saved_fallbacks += rest.size();
+    std::vector<std::pair<uint32_t, uint32_t>> fr;
+    for (uint32_t sgl : rest) fr.push_back({(uint32_t)qid, sgl});
+    std::vector<Located> l2(q.nq);
+    std::vector<char> d2(q.nq, 0);
+    rc = locate_saturated(ctx, ref, q, rg, p, qchunk, qwarm, qlower, table, fr, l2, d2);
+    if (rc) return rc;
+    if (d2[qid]) {
+      const int64_t m = q.len[qid], n = rg.hi - rg.lo;
+      const bool better = !found || l2[qid].score > L.score ||
+                          (l2[qid].score == L.score && host_order_key(p.semantics, l2[qid].ix, l2[qid].iy, m, n) < host_order_key(p.semantics, L.ix, L.iy, m, n));
+      if (better) { L = l2[qid]; found = true; }
+    }
+  }
+  if (found) { loc[qid] = L; done[qid] = 1; }
   return 0;
 }
 
@@ -508,6 +555,7 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       ctx->long_margin = (int64_t)(m + std::ceil(((double)table.smax * m - (double)best) / (double)table.gap)) + 2 + 64;
       ctx->last_kernel.cells = 0; ctx->timings[4] = 0; ctx->timings[5] = 0;
       ctx->whole_again += 1;
+      path_note(ctx, "margin_again");
       return false;
     };
     for (int attempt = 0; attempt < 4 && !pre; ++attempt) {
@@ -536,6 +584,10 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
         }
       }
       rc = score_fetch(ctx, nq, keys);
+      if (rc == kRetryNoWait) {                                       // (an expired wait between workgroups: the non-waiting layout)
+        ctx->last_kernel.cells = 0; ctx->timings[4] = 0; ctx->timings[5] = 0;
+        continue;
+      }
       if (rc) return rc;
       if (!any_sat) {
         if (ctx->long_cert >= 0.0f && nq == 1) {                       // exact keys: the lone query's maximum as swept
@@ -560,6 +612,7 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
         ctx->timings[4] = 0; ctx->timings[5] = 0;                    // launches / cells: only the sweep that produced the result
                                                                      // (its device time stays in timings[0]: honest extra cost)
         ctx->whole_again += 1;
+        path_note(ctx, "whole_again");
       };
       if (nflag > ctx->flag_cap) { whole_batch_again(); continue; }  // (only the unfiltered saturating sweep can overflow the list)
       std::vector<uint32_t> raw(2 * (size_t)nflag);
@@ -635,6 +688,7 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
                           flagged.end());
             offenders.erase(std::remove_if(offenders.begin(), offenders.end(), [&](int id) { return settled[id] != 0; }), offenders.end());
             ctx->first_settled += nsettled;
+            path_note(ctx, "first_settled");
           }
           if (trace_on) std::fprintf(stderr, "[mi355_sw] %zu of %zu offenders settled by their first candidates\n", nsettled, tried.size());
         }
@@ -671,9 +725,11 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
         }
         std::vector<unsigned long long> keys2;
         rc = score_fetch(ctx, nq, keys2);
+        if (rc == kRetryNoWait) return fail(ctx, MI355_SW_ENODEV, "sw_long_kernel: a pipeline wait expired");   // (offenders never take sw_long_kernel)
         if (rc) return rc;
         for (int id : offenders) keys[id] = keys2[id];
         ctx->requeried += offenders.size();
+        path_note(ctx, "requery");
       }
       HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
       std::vector<float> qlower(nq, 0.0f);                          // the sweep's key: a lower bound of the query's maximum
@@ -683,7 +739,7 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
         if (qfloat[k] == 2) qlower[k] = half_value((uint16_t)hi32) * kF16Scale;
         else if (qfloat[k] == 4) { float v; memcpy(&v, &hi32, 4); qlower[k] = std::ldexp(v, ctx->fshift); }
       }
-      rc = locate_saturated(ctx, ref, q, rg, p, qchunk, qwarm, qlower, table, flagged, loc, qdone);
+      rc = locate_flagged(ctx, ref, q, rg, p, qchunk, qwarm, qlower, table, flagged, loc, qdone);
       if (rc) return rc;
       HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
       ctx->timings[1] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
@@ -899,9 +955,9 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   // what a following mi355_sw_align_scored_range needs (one launch group only: the geometry is per launch)
   ScoredRanges &sc = ctx->scored;
   sc.valid = false;
-  const bool keep = &q == &ctx->batch && &ref == &ctx->ref && nr <= 32768 && p.lut == nullptr;
+  const bool keep = nr <= 32768 && p.lut == nullptr;
   if (keep) {
-    sc.ref_version = ref.version; sc.batch_version = q.version; sc.params = p; sc.ranges = ranges;
+    sc.ref = &ref; sc.batch = &q; sc.ref_version = ref.version; sc.batch_version = q.version; sc.params = p; sc.ranges = ranges;
     sc.keys.assign(nr * nq, 0ull); sc.qfast.assign(nq, 0); sc.qfloat.assign(nq, 0); sc.qchunk.assign(nq, 0); sc.qwarm.assign(nq, 0);
     sc.sampled = false; sc.has_located.assign(nr, 0); sc.located.assign(nr, Located());
   }
@@ -925,6 +981,10 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
     }
     std::vector<unsigned long long> keys;
     rc = score_fetch(ctx, nq * sub.size(), keys);
+    if (rc == kRetryNoWait) {                                       // (an expired wait between workgroups: the non-waiting layout)
+      ctx->timings[4] = 0; ctx->timings[5] = 0; ctx->last_kernel.cells = 0;
+      return range_maxima(ctx, ref, q, ranges, p, maxima, winner_only, known_best, exact_above);
+    }
     if (rc) return rc;
     if (keep) { std::copy(keys.begin(), keys.end(), sc.keys.begin()); sc.qfast = qfast; sc.qfloat = qfloat; sc.fshift = ctx->fshift; }
     for (size_t r = 0; r < sub.size(); ++r)
@@ -967,7 +1027,7 @@ int range_maxima(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
         const std::vector<float> qlower(1, maxima[r]);
         std::vector<int64_t> qchunk(1, 0), qwarm(1, 0);
         for (Bucket &b : buckets) if (b.fast) { qchunk[0] = b.sub_len; qwarm[0] = b.warm; }
-        rc = locate_saturated(ctx, ref, q, ranges[r], p, qchunk, qwarm, qlower, table, fl, loc, done);
+        rc = locate_flagged(ctx, ref, q, ranges[r], p, qchunk, qwarm, qlower, table, fl, loc, done);
         if (rc) return rc;
         if (!done[0]) { ok = false; break; }
         maxima[r] = loc[0].score;
@@ -1022,6 +1082,8 @@ void reset_timings(mi355_sw_ctx *ctx) {
   ctx->score_ev_used = 0; ctx->arenas.clear(); ctx->cons_used = 0;
   ctx->last_kernel = mi355_sw_kernel_info{};
   ctx->requeried = 0; ctx->whole_again = 0; ctx->candidates = 0; ctx->left_window = 0; ctx->first_settled = 0;
+  ctx->saved_locates = 0; ctx->saved_traces = 0; ctx->saved_fallbacks = 0; ctx->wait_retries = 0;
+  ctx->path.clear();
 }
 
 }  // namespace

@@ -152,7 +152,7 @@ bool comb_ok(int ncodes, int R) {
 
 // sw_long_kernel (a lone query beyond 2048 rows): rows per lane and strips per tile such that the whole float16 profile,
 // the rings and the sub-chunk maxima fit the CU's LDS with at most sixteen wavefronts — the shape with the fewest padded rows.
-constexpr size_t kLongLdsMax = 156 * 1024;
+inline size_t long_lds_max() { return std::min<size_t>((size_t)156 * 1024, dev_lds() - 4096); }   // (a CU's LDS minus the static part)
 constexpr int kLongSubsMax = 1024;            // sub-chunk maxima a tile keeps in LDS
 constexpr int kLongMK = 8;                    // sw_long_kernel folds the running maximum every kLongMK-th step when it samples: sub-chunk values
                                               // are lower bounds within (kLongMK - 1) gaps (a cell holding M passes M - k g along its row)
@@ -164,13 +164,13 @@ bool long_shape(int ncodes, int len, int &R, int &nstrips) {
     const int ns = (len + 64 * r - 1) / (64 * r);
     if (ns < 1) continue;
     // one workgroup with the float16 profile, or up to eight with a float32 profile each (long_score_launch decides)
-    const bool one_wg = ns <= long_max_waves(r) && long_lds_bytes(ncodes, ns, 1, r, kLongSubsMax) <= kLongLdsMax;
+    const bool one_wg = ns <= long_max_waves(r) && long_lds_bytes(ncodes, ns, 1, r, kLongSubsMax) <= long_lds_max();
     bool many_wg = false;
     for (int g = 1; g <= 8 && !many_wg; g *= 2) {
       const int spg = (ns + g - 1) / g;
-      many_wg = spg <= long_max_waves(r) && long_lds_bytes(ncodes, spg, 1, r, kLongSubsMax, true) <= kLongLdsMax;
+      many_wg = spg <= long_max_waves(r) && long_lds_bytes(ncodes, spg, 1, r, kLongSubsMax, true) <= long_lds_max();
     }
-    if (!one_wg && (!many_wg || opt().no_long_p32)) continue;
+    if (!one_wg && (!many_wg || opt().no_long_p32 || tl_no_wait)) continue;   // (tl_no_wait: only layouts whose waits stay inside one workgroup)
     const int64_t rows = (int64_t)ns * 64 * r;
     if (best < 0 || rows < best) { best = rows; R = r; nstrips = ns; }    // ties: fewer rows per lane = more wavefronts (measured,
                                                                           // 10 kbp x 250 Mbp: 8 x R=20 strips 244 ms, 5 x R=32 strips 306 ms)
@@ -232,9 +232,14 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
           // ... provided a random background stays clear of 255: with cheap gaps it grows with the read (about 0.2 M per
           // row at 3 / -3 / 2), longer reads reach 255 everywhere and every sub-chunk would be a candidate (measured: 1000 bp
           // reads overflow the flag budget and the call repeats the sweep unsampled)
+          // Longer reads (beyond ~250 bp at 3 / -3 / 2) reach 255 against ANY background, so every sub-chunk is a candidate of
+          // every read — but a key at the cap is decided by the FIRST candidates in storage order (sw_sample_first: the first
+          // eight in ascending order plus the wrapped triangle's two sub-chunks, align_range_core), not by all of them: the
+          // bucket keeps the three-op cell and the filter's per-query cap keeps the list short (round 3 switched the sampling
+          // off there: 3.5 ops, 18-19 TCUPS against the float engine's 21).  Option u8_sample_short restores that limit.
           b.sampled = allow_sample && !b.strips && sampled_instance(b.SL, b.R) && !opt().no_sample &&
                       ref.ncodes - 1 >= 4 &&             // (two- and three-letter alphabets: random matches every other column)
-                      0.3 * (double)t.smax * (double)b.maxlen + 3.0 * (double)t.gap < 230.0;
+                      (!opt().u8_sample_short || 0.3 * (double)t.smax * (double)b.maxlen + 3.0 * (double)t.gap < 230.0);
         }
         else if (twin16_ok && !b.strips && b.SL != 64) {
           b.sem = kSemF16; b.unsat = true; b.twin = true; b.SL = 16; b.R = pick_R(b.maxlen); b.comb = comb_ok(ref.ncodes, b.R);
@@ -256,8 +261,7 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       const bool fits = !opt().force_f32 && t.integral && (int64_t)t.smax * std::min<int64_t>(b.maxlen, std::max<int64_t>(n, 1)) + t.smax <= 32000;
       b.sem = fits ? kSemI16 : kSemF32;
       // small scores on short reads: packed float16 cells (clamped add + three-input maximum: 3.5 instead of 4.5 ops per cell)
-      const bool f16_wide = !opt().no_f16_wide;                                                 // A/B switch
-      if (fits && !t.htab.empty() && !b.strips && (b.SL != 64 || f16_wide) && b.count >= 2 &&
+      if (fits && !t.htab.empty() && !b.strips && b.count >= 2 &&
           (int64_t)t.smax * b.maxlen + t.smax <= 2040 && !opt().no_f16) {
         b.sem = kSemF16;
         // the running maximum every 4th step, the sub-chunks within 3 gaps of the key re-evaluated exactly (sw_score_kernel MK)
@@ -521,12 +525,13 @@ int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int S
                        int64_t sub_len = 0, int64_t quant = 0) {
   int64_t cl = 65536;
   while (cl < 8 * warm) cl *= 2;                 // long queries: keep the warm-up redundancy bounded
-  // fill the chip: 256 CUs x 32 waves x 4 slots; shrink tiles while they stay >> warm-up
+  // fill the chip: CUs x 32 waves x 4 slots (65 536 tiles on 256 CUs); shrink tiles while they stay >> warm-up
+  const double cus = (double)dev_cus();
   while (cl > 2048 && cl / 2 >= 4 * warm &&
-         (double)npairs * (double)((max_range_len + cl - 1) / cl) < 65536.0) cl /= 2;
+         (double)npairs * (double)((max_range_len + cl - 1) / cl) < 256.0 * cus) cl /= 2;
   // few tiles (one long query): filling the SIMDs beats the warm-up redundancy down to cl == warm
   // (measured, 10 kbp x 250 Mbp: 1.17 s at 131 k columns, 0.58 s at 32 k; profiles/r01_config5*.log)
-  const double few = (SL == 64 ? 1536.0 : 8192.0) * (twin ? 2.0 : 1.0);   // a 64-lane tile is a wavefront of its own (two tiles with twin)
+  const double few = (SL == 64 ? 6.0 : 32.0) * cus * (twin ? 2.0 : 1.0);   // (1536 / 8192 on 256 CUs) a 64-lane tile is a wavefront of its own (two tiles with twin)
   while (cl / 2 >= std::max<int64_t>(warm, 2048) &&
          (double)npairs * (double)((max_range_len + cl - 1) / cl) < few) cl /= 2;
   // tiny problems (one read against a short reference): the call's latency is one tile's sweep and the chip is
@@ -536,7 +541,7 @@ int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int S
   if (sub_len > 0 && sub_len < floor_cl) floor_cl = std::max<int64_t>(128, sub_len);   // finer sub-chunks allow shorter tiles (measured:
                                                                                        // 0.30 ms per 150 bp x 1 Mbp call at 128 columns, 0.33 at 256)
   const double per_wg = 256.0 / SL * (twin ? 2.0 : 1.0);
-  while (cl / 2 >= floor_cl && (double)npairs * (double)((max_range_len + cl - 1) / cl) / per_wg < 256.0) cl /= 2;
+  while (cl / 2 >= floor_cl && (double)npairs * (double)((max_range_len + cl - 1) / cl) / per_wg < cus) cl /= 2;
   // Few workgroups per CU: the launch's duration is (workgroups per CU, rounded UP) x (one tile's sweep), so a tile length
   // that lets the workgroup count land just under a multiple of the 256 CUs beats the power of two next to it
   // (50 Mbp, one 400 bp read: 763 workgroups of 2048-column tiles = 3 per CU, 509 of 3072-column tiles = 2 per CU:
@@ -547,7 +552,7 @@ int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int S
     auto rounds = [&](int64_t c) {
       const int64_t tiles = (max_range_len + c - 1) / c;
       const double wgs = (double)npairs * (double)((tiles + tiles_per_wg - 1) / tiles_per_wg);
-      return std::ceil(wgs / 256.0);
+      return std::ceil(wgs / cus);
     };
     auto cost = [&](int64_t c) { return rounds(c) * (double)(c + warm + SL); };
     const double r0 = rounds(cl);
@@ -626,6 +631,7 @@ inline uint32_t query_flag_cap(size_t nq) { return 64u + (uint32_t)(1024 / std::
 int score_begin(mi355_sw_ctx *ctx, const QueryBatch &q, const std::vector<Range> &ranges, const ScoreTable &t) {
   const size_t nq = q.nq, nr = ranges.size();
   ctx->long_cert = -1.0f;                                            // (set by a sw_long_kernel launch with an optimistic margin)
+  ctx->lsaved.valid = false;                                         // (a new score pass: set again by a sw_long_kernel launch that saves)
   if (nr > 32768) return fail(ctx, MI355_SW_ENOTSUP, "more than 32768 ranges per launch");
   // the previous call's copies out of these host vectors have completed: every call ends synchronised
   std::vector<int64_t> &rl = ctx->h_ranges;
@@ -673,19 +679,19 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   int groups = 1, spg = b.nstrips;
   if (p32) {
     p32 = false;
-    for (int g = opt().long_groups > 0 ? (int)opt().long_groups : 1; g <= 8; g *= 2) {
+    for (int g = (opt().long_groups > 0 && !tl_no_wait) ? (int)opt().long_groups : 1; g <= (tl_no_wait ? 1 : 8); g *= 2) {
       const int s1 = (b.nstrips + g - 1) / g;
-      if (s1 <= long_max_waves(b.R) && long_lds_bytes(ref.ncodes, s1, 1, b.R, kLongSubsMax, true) <= kLongLdsMax) { p32 = true; groups = g; spg = s1; break; }
+      if (s1 <= long_max_waves(b.R) && long_lds_bytes(ref.ncodes, s1, 1, b.R, kLongSubsMax, true) <= long_lds_max()) { p32 = true; groups = g; spg = s1; break; }
     }
   }
-  if (!p32 && (b.nstrips > long_max_waves(b.R) || long_lds_bytes(ref.ncodes, b.nstrips, 1, b.R, kLongSubsMax) > kLongLdsMax))
+  if (!p32 && (b.nstrips > long_max_waves(b.R) || long_lds_bytes(ref.ncodes, b.nstrips, 1, b.R, kLongSubsMax) > long_lds_max()))
     return fail(ctx, MI355_SW_ENOTSUP, "internal: no sw_long_kernel layout for this query");
   groups = (b.nstrips + spg - 1) / spg;                                 // (no workgroup without strips)
   int pipes = (int)opt().long_pipes;
   if (pipes < 1) pipes = long_max_waves(b.R) / spg;                     // as many wavefronts per CU as fit: the sweep
                                                                         // is bound by issue slots that only other wavefronts fill
   pipes = std::max(1, std::min(pipes, long_max_waves(b.R) / spg));
-  while (pipes > 1 && long_lds_bytes(ref.ncodes, spg, pipes, b.R, kLongSubsMax, p32) > kLongLdsMax) --pipes;
+  while (pipes > 1 && long_lds_bytes(ref.ncodes, spg, pipes, b.R, kLongSubsMax, p32) > long_lds_max()) --pipes;
   int64_t sub_len = opt().long_sub >= 64 ? opt().long_sub / 64 * 64 : 2048;
   // uint8 engine: a power of two >= |x|, so that the skewed storage order stays within two neighbouring sub-chunks (locate_fast)
   if (p.semantics == MI355_SW_U8SAT) sub_len = std::max<int64_t>(sub_len, score_sub_len(p.semantics, b));
@@ -693,9 +699,9 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   int wg_per_cu = 1;
   for (;;) {
     const size_t lds = long_lds_bytes(ref.ncodes, spg, pipes, b.R, kLongSubsMax, p32);
-    wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(long_max_waves(b.R) / (spg * pipes))));
+    wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(dev_lds() / lds, (size_t)(long_max_waves(b.R) / (spg * pipes))));
     // never more workgroups than the chip holds at once: with several workgroups per tile they WAIT for each other
-    const int64_t G = std::max<int64_t>(groups, opt().long_wgs > 0 ? opt().long_wgs : (int64_t)256 * wg_per_cu);
+    const int64_t G = std::max<int64_t>(groups, opt().long_wgs > 0 ? opt().long_wgs : (int64_t)dev_cus() * wg_per_cu);
     chunk = std::max<int64_t>(sub_len, (int64_t)std::ceil(total_cols / (double)((G / groups) * pipes) / (double)sub_len) * sub_len);
     auto wgs = [&](int64_t c) { int64_t n = 0; for (auto &r : ranges) n += ((((r.hi - r.lo) + c - 1) / c + pipes - 1) / pipes) * groups; return n; };
     while (wgs(chunk) > G) chunk += sub_len;
@@ -757,6 +763,7 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     a.gcount = ctx->gcnt.as<long long>();
   }
   a.status = reinterpret_cast<int32_t *>(ctx->flags.as<unsigned int>() + 1);      // zeroed by score_begin, read by score_fetch
+  a.fault = (opt().fault_inject == 2 && groups > 1) ? 1 : 0;                       // test hook: the waits between workgroups expire at once
   const int64_t nsub = cpr * subs_per_tile;                           // sub-chunks of one range (value rows: one per range)
   a.submax_range_stride = nsub;
   if (b.sampled) {
@@ -764,6 +771,24 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     a.submax_out = ctx->submax.as<uint32_t>();
     // (the workgroups of a tile merge their values by atomic maximum; tiles beyond a short range's end never run)
     HIPCHK(ctx, hipMemsetAsync(ctx->submax.p, 0, (size_t)nr * (size_t)nsub * 4, ctx->stream));
+  }
+  // what the finish starts from instead of zero borders and warm-up margins (sw_long_kernel.h colsave / rowsave, host_saved.h):
+  // 4 B per row and sub-chunk + 4 B per strip boundary and column — 12 GB for 10 kbp x 250 Mbp, written once while the sweep
+  // runs (60 GB/s).  Not for the uint8 engine's unsaturated sweep (its finish evaluates another recurrence).
+  ctx->lsaved.valid = false;
+  a.colsave = nullptr; a.rowsave = nullptr; a.col_subs = nsub; a.col_rows = (int64_t)b.nstrips * 64 * b.R; a.row_stride = a.warm + chunk + 192;
+  if (!opt().no_long_save && !b.unsat && t.integral && p.lut == nullptr) {
+    const size_t col_bytes = (size_t)nr * (size_t)nsub * (size_t)a.col_rows * 4;
+    const size_t row_bytes = (size_t)nr * (size_t)a.tiles_stride * (size_t)std::max(1, b.nstrips - 1) * (size_t)a.row_stride * 4;
+    if (col_bytes + row_bytes <= ((size_t)64 << 30) && !ctx->colsave.ensure(col_bytes + 64) && !ctx->rowsave.ensure(row_bytes + 64)) {
+      a.colsave = ctx->colsave.as<float>();
+      a.rowsave = b.nstrips > 1 ? ctx->rowsave.as<float>() : nullptr;
+      LongSaved &ls = ctx->lsaved;
+      ls.ref = &ref; ls.batch = &q; ls.ref_version = ref.version; ls.batch_version = q.version; ls.params = p; ls.qid = qid;
+      ls.ranges = ranges; ls.chunk = chunk; ls.sub_len = sub_len; ls.warm = a.warm; ls.nstrips = b.nstrips; ls.R = b.R; ls.spt = subs_per_tile;
+      ls.tiles_stride = a.tiles_stride; ls.col_subs = nsub; ls.col_rows = a.col_rows; ls.row_stride = a.row_stride; ls.fshift = ctx->fshift;
+      ls.valid = true;                                                  // (the launch below fills the buffers; every call ends synchronised)
+    }
   }
   const size_t shmem = long_lds_bytes(ref.ncodes, spg, pipes, b.R, subs_per_tile, p32);
   const dim3 grid((unsigned)(tgroups * groups), (unsigned)nr);
@@ -785,6 +810,8 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     return fail(ctx, MI355_SW_ENOTSUP, "no sw_long_kernel instance for this R");
 #undef LONG_CASE
   HIPCHK(ctx, hipGetLastError());
+  path_note(ctx, "long[R=%d,groups=%d,pipes=%d,p32=%d,sampled=%d,opt_margin=%d,saved=%d,unsat=%d]", b.R, groups, pipes, (int)p32, (int)b.sampled,
+            (int)(ctx->long_cert >= 0.0f), (int)(a.colsave != nullptr), (int)b.unsat);
   ctx->long_launched = true;
   if (b.sampled) {
     // one filter launch per range: its value row against ITS key; entries carry the range in the sub-chunk index (r * nsub + s)
@@ -938,6 +965,11 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
                               : launch_score_R<kSemI16>(b.R, b.SL, b.strips, grid, shmem, ctx->stream, a);
   if (rc) return fail(ctx, MI355_SW_ENOTSUP, "no score kernel instance for this R");
   HIPCHK(ctx, hipGetLastError());
+  {
+    static const char *cellname[] = {"i16", "u8i16", "f32", "u8f32", "f16", "u8f16"};
+    path_note(ctx, "score[cell=%s,SL=%d,R=%d,strips=%d,twin=%d,comb=%d,sampled=%d,satflag=%d,unsat=%d,pow2=%d]", cellname[b.sem], b.SL, b.R, (int)b.strips,
+              (int)b.twin, (int)b.comb, (int)b.sampled, (int)b.satflag, (int)b.unsat, (int)((b.chunk_len & (b.chunk_len - 1)) == 0));
+  }
   if (b.sampled) {
     // grid.y = query positions of this launch, at most 65535 per filter launch
     for (int f0 = 0; f0 < a.qcount; f0 += 65535) {
@@ -962,6 +994,7 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
                            (const int32_t *)a.qsel, a.qfirst + f0, fc, (const unsigned long long *)a.keys, 3.0f * (float)t.gap,
                            (const unsigned int *)ctx->qcnt.as<unsigned int>(), query_flag_cap(q.nq), 0u, ctx->first.as<uint32_t>());
         ctx->first_valid = true;
+        path_note(ctx, "sample_first");
       }
       HIPCHK(ctx, hipGetLastError());
     }
@@ -992,6 +1025,8 @@ int score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, con
   return 0;
 }
 
+constexpr int kRetryNoWait = 1;   // score_fetch: not an error — sweep again, tl_no_wait is set
+
 int score_fetch(mi355_sw_ctx *ctx, size_t count, std::vector<unsigned long long> &keys) {
   keys.resize(count);
   HIPCHK(ctx, hipMemcpyAsync(keys.data(), ctx->keys.p, count * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -999,7 +1034,13 @@ int score_fetch(mi355_sw_ctx *ctx, size_t count, std::vector<unsigned long long>
   if (ctx->long_launched) HIPCHK(ctx, hipMemcpyAsync(&long_status, ctx->flags.as<unsigned int>() + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->long_launched = false;
-  if (long_status != 0) return fail(ctx, MI355_SW_ENODEV, "sw_long_kernel: a pipeline wait expired (a wavefront of the workgroup made no progress)");
+  if (long_status != 0) {
+    // the workgroups of a tile wait for each other (several per tile): on a device that does not hold them all at once the wait
+    // expires — the caller sweeps again on a layout whose waits stay inside one workgroup (once per call)
+    ctx->score_ev_used = 0;
+    if (!tl_no_wait) { tl_no_wait = true; ctx->wait_retries += 1; return kRetryNoWait; }
+    return fail(ctx, MI355_SW_ENODEV, "sw_long_kernel: a pipeline wait expired (a wavefront of the workgroup made no progress)");
+  }
   for (size_t e = 0; e + 1 < ctx->score_ev_used; e += 2) {     // device time of the score launches
     float ms = 0;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->score_ev[e], ctx->score_ev[e + 1]));

@@ -126,6 +126,7 @@ int solo_align(mi355_sw_ctx *ctx, const RefData &ref, const char *x, size_t nx, 
   else { if (u8) SOLO_LAUNCH(5, true); else SOLO_LAUNCH(5, false); }
 #undef SOLO_LAUNCH
   HIPCHK(ctx, hipGetLastError());
+  path_note(ctx, "solo[R=%d,u8=%d,ranges=%zu]", R, (int)u8, nr);
   HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
   uint8_t *down = ctx->pin_solo_down.as<uint8_t>();
   HIPCHK(ctx, hipMemcpyAsync(down, dev + kSoloResultOff, down_bytes, hipMemcpyDeviceToHost, ctx->stream));

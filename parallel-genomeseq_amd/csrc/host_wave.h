@@ -172,6 +172,7 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
   else if (R == 20) launch_wave_R<20>(orient, u8, track, dirs, blocks, ctx->stream, dp, (int)n, sc);
   else launch_wave_R<32>(orient, u8, track, dirs, blocks, ctx->stream, dp, (int)n, sc);
   HIPCHK(ctx, hipGetLastError());
+  path_note(ctx, "wave[orient=%d,R=%d,track=%d,dirs=%d,keyed=%d,prof=%d,u8=%d]", orient, R, (int)track, (int)dirs, (int)keyed, (int)(prof_rc == 0), (int)u8);
   if (track) {
     int64_t *ci = ctx->pin_out.as<int64_t>();
     float *bf = reinterpret_cast<float *>(ci + 2 * n);
@@ -266,11 +267,13 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   for (size_t k = 0; k < n; ++k) nsmax = std::max(nsmax, strip_count(q.len[jobs[k].q], R));
   // the decisions of a FEW long alignments: the strips of each dealt to several workgroups, four wavefronts (one per
   // SIMD) each, instead of sixteen wavefronts on one CU (config 5: the sweep of the 26 k-column window)
-  const bool no_groups = opt().no_strip_groups;
+  const bool no_groups = opt().no_strip_groups || tl_no_wait;
   const int spg = 4;
   // ... and the locate windows of a few long queries (first-cell / maximum tracking): each workgroup reports the best cell of
   // its strips, merged below
-  const int groups = (!no_groups && nsmax > spg && n <= (track ? (size_t)32 : (size_t)8)) ? (nsmax + spg - 1) / spg : 1;
+  // (every workgroup of a launch must be resident: the grid stays below the CU count)
+  int groups = (!no_groups && nsmax > spg && n <= (track ? (size_t)32 : (size_t)8)) ? (nsmax + spg - 1) / spg : 1;
+  if ((size_t)groups * n > (size_t)dev_cus()) groups = 1;
   const size_t og = track ? (size_t)groups : 1;                    // result slots per job
   for (size_t k = 0; k < n; ++k) {
     WaveJob &j = jobs[k];
@@ -337,6 +340,7 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   else if (R == 10) launch_strip<10>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups, maxmode);
   else launch_strip<16>(u8, track, grid, block, ctx->stream, dp, sc, gtab, ref.ncodes, groups, maxmode);
   HIPCHK(ctx, hipGetLastError());
+  path_note(ctx, "strip[R=%d,mode=%s,grouped=%d,lut=%d,u8=%d]", R, maxmode ? "max" : (track ? "track" : "dirs"), (int)(groups > 1), (int)use_table, (int)u8);
   std::vector<int32_t> st(n);
   std::vector<int64_t> ci(2 * n * og);
   std::vector<float> bv(maxmode ? n * og : 0);
@@ -345,7 +349,11 @@ int run_strip(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const 
   if (track) HIPCHK(ctx, hipMemcpyAsync(ci.data(), ctx->outs_i.p, n * og * 16, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   for (size_t k = 0; k < n; ++k) {
-    if (st[k] != 0) return fail(ctx, MI355_SW_ENODEV, "internal: strip pipeline wait expired");
+    if (st[k] != 0) {
+      // strips dealt to several workgroups that wait for each other: once more with every strip of a problem in ONE workgroup
+      if (groups > 1 && !tl_no_wait) { tl_no_wait = true; ctx->wait_retries += 1; return run_strip(ctx, ref, q, rg, p, jobs, R); }
+      return fail(ctx, MI355_SW_ENODEV, "internal: strip pipeline wait expired");
+    }
     if (!track) continue;
     // the workgroups of a job: the greatest value (kStripMax), then the smallest storage-order key
     float best = 0.0f;
@@ -461,6 +469,7 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         w.exact_from = j.s_lo == 0 ? 0 : j.s_lo + warm[k];
         w.cap = na + j.nb + 2;                                      // a walk inside the window emits <= na + nb pairs
         w.out = wout + 3 * t;
+        w.zchunk = 0; w.zwarm = 0;
       }
       });
       HIPCHK(ctx, hipMemcpyAsync(ctx->walkp.p, wp, n * sizeof(WaveWalk), hipMemcpyHostToDevice, ctx->stream));
@@ -479,6 +488,7 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         for (size_t t = 0; t < n; ++t) { offs[t] = (int64_t)at; at += 2 * (size_t)wp[t].cap; }
         if (ctx->cons.ensure(captot + 16)) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(consensus) failed");
         HIPCHK(ctx, hipMemcpyAsync(woffs, offs, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        path_note(ctx, strips && orient == 0 ? "walk_long" : "walk_wave");
         if (strips && orient == 0)     // a few long walks: one wavefront each, looking ahead along the diagonal
           hipLaunchKernelGGL(sw_wave_walk_long_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const WaveWalk *)ctx->walkp.as<WaveWalk>(), (int)n,
                              ctx->cons.as<char>(), (const int64_t *)woffs);
@@ -491,6 +501,7 @@ int wave_trace(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const
         HIPCHK(ctx, hipMemcpyAsync(cons.p, ctx->cons.p, captot, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       } else {
+        path_note(ctx, "walk_wave");
         hipLaunchKernelGGL(sw_wave_walk_kernel<kWalkMeasure>, dim3(wblocks), dim3(64), 0, ctx->stream, ctx->walkp.as<WaveWalk>(), (int)n,
                            (char *)nullptr, (const int64_t *)nullptr);
         HIPCHK(ctx, hipGetLastError());

@@ -24,6 +24,7 @@
 #include <thread>
 #include <memory>
 #include <cmath>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +47,7 @@ using namespace mi355sw;
 #include "host_exact.h"
 #include "host_wave.h"
 #include "host_batch.h"
+#include "host_saved.h"
 #include "host_pipeline.h"
 #include "host_solo.h"
 #include "host_multi.h"   // mi355_sw_multi_*: its own extern "C" block
@@ -70,6 +72,13 @@ int mi355_sw_create(mi355_sw_ctx **out, int device) {
   if (!c) return MI355_SW_ENOMEM;
   c->device = device;
   c->opts = options_from_env();
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+      if (prop.multiProcessorCount > 0) c->dev.cus = prop.multiProcessorCount;
+      if (prop.maxSharedMemoryPerMultiProcessor >= 64 * 1024) c->dev.lds = (size_t)prop.maxSharedMemoryPerMultiProcessor;
+    }
+  }
   if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return MI355_SW_ENODEV; }
   for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return MI355_SW_ENODEV; }
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_exact_kernel<0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kExactLdsMax);
@@ -84,7 +93,7 @@ void mi355_sw_destroy(mi355_sw_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   DevBuf *bufs[] = {&c->qcnt, &c->sel2, &c->gcnt, &c->wlut, &c->ref.bytes, &c->ref.codes, &c->batch.bytes, &c->batch.lens, &c->keys, &c->ranges, &c->stab,
-                    &c->batch.offs, &c->batch.sel, &c->ftab, &c->ftab_s, &c->htab, &c->htab8, &c->soloblk, &c->flags, &c->submax, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow, &c->wprobs, &c->scan, &c->batch.cum, &c->ckpt, &c->first};
+                    &c->batch.offs, &c->batch.sel, &c->colsave, &c->rowsave, &c->pieces, &c->ftab, &c->ftab_s, &c->htab, &c->htab8, &c->soloblk, &c->flags, &c->submax, &c->lut, &c->probs, &c->dirs, &c->outs_f, &c->outs_i, &c->cons, &c->walkp, &c->hmat, &c->brow, &c->wprobs, &c->scan, &c->batch.cum, &c->ckpt, &c->first};
   for (DevBuf *b : bufs) b->release();
   c->adhoc.release(); c->one.release();
   c->pin_probs.release(); c->pin_walk.release(); c->pin_out.release(); c->pin_solo_up.release(); c->pin_solo_down.release();
@@ -289,8 +298,12 @@ int mi355_sw_align_split(mi355_sw_ctx *ctx, const char *x, size_t nx, const char
     }
     int r = upload_queries(ctx, q, 1, &x, &nx);
     if (r) return r;
+    // All the reference does with the per-piece maxima is pick the first piece with the strictly greatest one
+    // (plocalaligner.cpp:106,122-129), so the sweep is the winner-only one of mi355_sw_best_range: a lone long query on the sampled
+    // maximum behind an optimistic warm-up margin, certified by the call itself (range_maxima; pieces that tie with the
+    // winner come out exact, so the first-piece rule holds).
     std::vector<float> pmax(npiece, 0.0f);
-    r = range_maxima(ctx, *refp, q, ranges, ps, pmax.data());
+    r = range_maxima(ctx, *refp, q, ranges, ps, pmax.data(), true);
     if (r) return r;
     float best = -1.0f;                                  // plocalaligner.cpp:106,122-129
     bp = 0;
@@ -299,7 +312,12 @@ int mi355_sw_align_split(mi355_sw_ctx *ctx, const char *x, size_t nx, const char
     mi355_sw_default_params(&pd);                        // LAT(x, piece): default scoring (:135)
     pd.semantics = la_semantics;
     const double t_score = ctx->timings[0];
-    r = align_range(ctx, *refp, q, ranges[bp], pd, 0, out);
+    // The reference sweeps the winning piece a second time (:132-136).  With default scoring in both roles that sweep is the one
+    // just made: the winner is finished from its keys (argmax window + traceback only), as mi355_sw_align_scored_range does.
+    const ScoredRanges &sc = ctx->scored;
+    const bool from_keys = same_sweep && sc.valid && sc.ref == (const void *)refp && sc.batch == (const void *)&q &&
+                           (size_t)bp < sc.ranges.size() && (!sc.sampled || sc.has_located[bp]);
+    r = align_range(ctx, *refp, q, ranges[bp], pd, 0, out, from_keys ? &sc : nullptr, (size_t)bp);
     if (r) return r;
     if (out->score > 0) { out->pos += (uint32_t)lefts[bp]; out->end_y += lefts[bp]; }
     else out->pos = (uint32_t)lefts[bp];
@@ -376,7 +394,8 @@ int mi355_sw_align_scored_range(mi355_sw_ctx *ctx, size_t range_index, const mi3
   if (!outs) return fail(ctx, MI355_SW_EINVAL, "outs is NULL");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const ScoredRanges &sc = ctx->scored;
-  if (!sc.valid || sc.ref_version != ctx->ref.version || sc.batch_version != ctx->batch.version || range_index >= sc.ranges.size())
+  if (!sc.valid || sc.ref != (const void *)&ctx->ref || sc.batch != (const void *)&ctx->batch || sc.ref_version != ctx->ref.version ||
+      sc.batch_version != ctx->batch.version || range_index >= sc.ranges.size())
     return fail(ctx, MI355_SW_EINVAL, "mi355_sw_align_scored_range: no mi355_sw_score_ranges call on this reference and batch covers that range");
   reset_timings(ctx);
   if (ctx->batch.nq == 0) return 0;
@@ -460,9 +479,15 @@ int mi355_sw_last_counter(const mi355_sw_ctx *ctx, const char *name, uint64_t *o
   else if (k == "candidates") *out = ctx->candidates;
   else if (k == "left_window") *out = ctx->left_window;
   else if (k == "first_settled") *out = ctx->first_settled;
+  else if (k == "wait_retries") *out = ctx->wait_retries;
+  else if (k == "saved_locates") *out = ctx->saved_locates;
+  else if (k == "saved_traces") *out = ctx->saved_traces;
+  else if (k == "saved_fallbacks") *out = ctx->saved_fallbacks;
   else return MI355_SW_EINVAL;
   return 0;
 }
+
+const char *mi355_sw_last_path(const mi355_sw_ctx *ctx) { return ctx ? ctx->path.c_str() : ""; }
 
 int mi355_sw_last_kernel(const mi355_sw_ctx *ctx, mi355_sw_kernel_info *out) {
   if (!ctx || !out) return MI355_SW_EINVAL;

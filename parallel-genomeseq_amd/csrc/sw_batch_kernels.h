@@ -42,8 +42,24 @@ struct BatchWaveArgs {
   // front of the argmax, resumed from the saved state, and only those rows get decisions
   float *ckpt;               // null: whole problems in one pass
   int R;
+  // Long streams cut into PIECES (orient 1 on sw_wave_prof_kernel, host_batch.h): a launch is at least as long as its longest
+  // stream, and a 7 k-residue sequence is 20 average ones — a fixed cost that does not shrink with a rank's share of the
+  // database.  The first `npieces` problems of the launch are pieces of the `nlong` longest sequences (launch order = longest
+  // first): piece e = rows [pc_start[e], pc_start[e] + pc_rows[e]) of sequence pc_seq[e], pc_before[e] stream positions in
+  // front of it; the other count - nlong problems are whole sequences.  A piece starts kPieceWarm-ish rows in front of its own
+  // rows (the margin of DESIGN.md L1 along the stream + the decision window's reach), so its own rows — and every checkpoint
+  // a decision window in front of an own row resumes from — are exact; results are merged per sequence by batch_seq_results.
+  int nlong, npieces, piece_rows;
+  const int32_t *pc_seq, *pc_start, *pc_rows, *pc_first;   // pc_first[k], k = 0 .. nlong: first piece of sequence k
+  const int64_t *pc_before;
+  int64_t piece_stream, long_stream;                       // stream positions of all pieces / of the nlong sequences as wholes
+  float *sbest;              // per SEQUENCE (launch order), after batch_seq_results: maximum,
+  int64_t *scell;            // ... its first cell,
+  int32_t *sprob;            // ... and the problem (piece) whose own rows hold that cell: the one a decision window resumes in
+  WaveProblem *probs2;       // [count] the decision windows (batch_window_setup)
 };
 
+constexpr int kPieceRows = 1024;                                   // own rows of a piece of a long stream (BatchWaveArgs)
 constexpr int kWindowGuard = 48;                                   // rows in front of the argmax a window holds at least
 constexpr int kWindowRows = kWindowGuard + 64 + 16;                // decision rows per window: guard .. guard + 63 rows, + the skew
 
@@ -59,25 +75,65 @@ __device__ __host__ inline int64_t batch_dirs_offset(int64_t stream_positions_be
   return (stream_positions_before + 16 * k) * 16 * (int64_t)W * 4;
 }
 
+// sorted position of problem k of a launch over sorted positions [first, first + count): longest first (see batch_wave_setup)
+__device__ __host__ inline int batch_sorted_pos(int first, int count, int k) { return first + count - 1 - k; }
+
 __global__ void batch_wave_setup(const BatchWaveArgs a) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= a.count) return;
-  const int id = a.qsel[a.first + k];
+  const int kk = blockIdx.x * blockDim.x + threadIdx.x;            // problem of the launch: a piece, or a whole sequence
+  if (kk >= a.npieces + a.count - a.nlong) return;
+  const bool piece = kk < a.npieces;
+  const int k = piece ? a.pc_seq[kk] : a.nlong + (kk - a.npieces); // its sequence (launch order)
+  // LONGEST FIRST: problem k of the launch is sorted position first + count - 1 - k.  Workgroups are dispatched in index order,
+  // and a launch is at least as long as its longest stream (a 7 k-residue sequence: 0.8 ms on one 16-lane slot); started
+  // last it ran alone at the end of the launch — a fixed cost that does not shrink with a rank's share of the database
+  const int sp = batch_sorted_pos(a.first, a.count, k);
+  const int id = a.qsel[sp];
   const uint8_t *xq = a.qbytes + a.qoff[id];
   const int32_t m = a.qlen[id];
   WaveProblem w;
   int64_t before;                                                  // stream positions of the problems in front of this one
-  if (a.orient == 0) { w.a = xq; w.na = m; w.b = a.ref; w.nb = (int32_t)a.nref; before = (int64_t)k * a.nref; }
-  else { w.a = a.ref; w.na = (int32_t)a.nref; w.b = xq; w.nb = m; before = a.qcum[a.first + k] - a.qcum[a.first]; }
   w.b_offset = 0;
+  if (a.orient == 0) { w.a = xq; w.na = m; w.b = a.ref; w.nb = (int32_t)a.nref; before = (int64_t)k * a.nref; }
+  else if (piece) { w.a = a.ref; w.na = (int32_t)a.nref; w.b = xq + a.pc_start[kk]; w.nb = a.pc_rows[kk]; w.b_offset = a.pc_start[kk]; before = a.pc_before[kk]; }
+  else { w.a = a.ref; w.na = (int32_t)a.nref; w.b = xq; w.nb = m; before = a.piece_stream + (a.qcum[a.first + a.count] - a.qcum[sp + 1]) - a.long_stream; }
   w.dirs = a.ckpt != nullptr ? nullptr
-                             : reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(a.dirs) + batch_dirs_offset(before, k, a.W));
-  w.ckpt = a.ckpt != nullptr ? a.ckpt + (size_t)batch_ckpt_row(before, k) * 16 * (size_t)(a.R + 1) : nullptr;
+                             : reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(a.dirs) + batch_dirs_offset(before, kk, a.W));
+  w.ckpt = a.ckpt != nullptr ? a.ckpt + (size_t)batch_ckpt_row(before, kk) * 16 * (size_t)(a.R + 1) : nullptr;
   w.k0 = 0;
-  w.best = a.best + k;
-  w.cell = a.cell + 2 * (size_t)k;
+  w.best = a.best + kk;
+  w.cell = a.cell + 2 * (size_t)kk;
   w.target = 0.0f; w.own_lo = 0; w.full_n = a.nref;
-  a.probs[k] = w;
+  a.probs[kk] = w;
+}
+
+// per sequence k (launch order): the maximum over its pieces, the first cell holding it in the float engine's storage order
+// (column of y, then row of x; a cell seen by two overlapping pieces is the same cell), and the piece whose OWN rows hold that
+// cell; whole sequences copy their problem's result
+__global__ void batch_seq_results(const BatchWaveArgs a) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.count) return;
+  if (k >= a.nlong) {
+    const int kk = a.npieces + (k - a.nlong);
+    a.sbest[k] = a.best[kk];
+    a.scell[2 * (size_t)k] = a.cell[2 * (size_t)kk];
+    a.scell[2 * (size_t)k + 1] = a.cell[2 * (size_t)kk + 1];
+    a.sprob[k] = kk;
+    return;
+  }
+  float bv = 0.0f;
+  int64_t bi = 0, bj = 0;
+  const int e0 = a.pc_first[k], e1 = a.pc_first[k + 1];
+  for (int e = e0; e < e1; ++e) {
+    const float v = a.best[e];
+    const int64_t i = a.cell[2 * (size_t)e], j = a.cell[2 * (size_t)e + 1];
+    if (v > bv || (v == bv && v > 0.0f && (j < bj || (j == bj && i < bi)))) { bv = v; bi = i; bj = j; }
+  }
+  a.sbest[k] = bv;
+  a.scell[2 * (size_t)k] = bv > 0.0f ? bi : 0;
+  a.scell[2 * (size_t)k + 1] = bv > 0.0f ? bj : 0;
+  int own = bv > 0.0f ? (int)((bi - 1) / a.piece_rows) : 0;
+  if (own > e1 - e0 - 1) own = e1 - e0 - 1;
+  a.sprob[k] = e0 + own;
 }
 
 // after the first pass of a checkpointed launch: problem k becomes the rows [k0, row of its argmax) with decisions, resumed from
@@ -85,15 +141,15 @@ __global__ void batch_wave_setup(const BatchWaveArgs a) {
 __global__ void batch_window_setup(const BatchWaveArgs a) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= a.count) return;
-  WaveProblem w = a.probs[k];
-  const bool hit = a.best[k] > 0.0f;
-  const int32_t rows = hit ? (int32_t)a.cell[2 * (size_t)k] : 0;   // 1-based row of the argmax = rows to run
+  WaveProblem w = a.probs[a.sprob[k]];                             // (a piece: rows count from its first row, b_offset)
+  const bool hit = a.sbest[k] > 0.0f;
+  const int32_t rows = hit ? (int32_t)(a.scell[2 * (size_t)k] - w.b_offset) : 0;   // 1-based row of the argmax = rows to run
   const int32_t k0 = hit ? 64 * (max(0, rows - 1 - kWindowGuard) / 64) : 0;
   w.nb = rows;
   w.k0 = k0;
   w.ckpt = k0 > 0 ? w.ckpt + (size_t)(k0 / 64 - 1) * 16 * (size_t)(a.R + 1) : nullptr;
   w.dirs = a.dirs + (size_t)k * kWindowRows * 16 * (size_t)a.W;
-  a.probs[k] = w;
+  a.probs2[k] = w;
 }
 
 struct BatchWalkArgs {
@@ -113,7 +169,7 @@ __global__ void batch_walk_setup(const BatchWalkArgs a) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= a.count) return;
   const WaveProblem P = a.probs[k];
-  const int id = a.qsel[a.first + k];
+  const int id = a.qsel[batch_sorted_pos(a.first, a.count, k)];
   WaveWalk w;
   w.x = a.qbytes + a.qoff[id];
   w.y = a.ref;
@@ -121,13 +177,14 @@ __global__ void batch_walk_setup(const BatchWalkArgs a) {
   w.na = P.na; w.nb = P.nb; w.orient = a.orient;
   w.R = a.R; w.lanes = 16; w.skew = 1; w.row0 = P.k0;
   w.need_slope = 0.0f;
-  w.b_offset = 0;
+  w.b_offset = P.b_offset;                                         // (a piece of a long stream: its first row)
   const bool hit = a.best[k] > 0.0f;
   w.start_i = hit ? a.cell[2 * (size_t)k] : 0;                     // no positive cell: the walk emits nothing
   w.start_j = hit ? a.cell[2 * (size_t)k + 1] : 0;
   w.exact_from = 0;                                                // whole problem: every cell is exact
   w.cap = P.na + P.nb + 2;
   w.out = a.wout + 3 * (size_t)k;
+  w.zchunk = 0; w.zwarm = 0;
   a.walks[k] = w;
 }
 

@@ -35,6 +35,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "sw_score_kernel.h"
 
 namespace mi355sw {
@@ -73,6 +75,19 @@ struct LongArgs {
   long long *gcount;           // ... and the positions of it that are complete (zero at launch)
   int32_t subs_per_tile;       // chunk_len / sub_len
   int32_t *status;             // set to 1 when a pipeline wait expired
+  // Saved state for the finish (host_saved.h): the sweep passes every cell of the matrix once; what a later exact window
+  // would have to recompute behind a zero border and a warm-up margin of its own is kept instead —
+  //   colsave  the H column 64 positions in front of every sub-chunk (stream position warm + b * sub_len - 64: the column
+  //            just left of the window locate re-runs for sub-chunk b), every row of the query: lane l is at that column
+  //            at step l of the segment, and stores its R values then;
+  //   rowsave  the bottom row of every strip but the last (what already travels to the strip below), every position.
+  // A block of 64 * R rows x one sub-chunk of columns is then an independent exact problem with known left column and top
+  // row.  Values are the cells' own (H * 2^-k).  Null: nothing is saved.
+  float *colsave;              // [(range * col_subs + tile * subs_per_tile + b) * col_rows + row]
+  int64_t col_subs, col_rows;  // sub-chunks per range; nstrips * 64 * R
+  float *rowsave;              // [((range * tiles_stride + tile) * (nstrips - 1) + strip) * row_stride + position]
+  int64_t row_stride;
+  int32_t fault;               // test hook (option fault_inject = long_stall): the waits BETWEEN workgroups expire at once
 };
 
 // Dwords between the float16 profile rows of adjacent lanes.  R = 24 (twelve dwords): 16-byte reads, stride
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
       }
     };
     auto wait_global = [&](long long *counter, long long need) {          // progress of the workgroup above (device scope)
-      int spins = 0;
+      int spins = a.fault ? kLongSpinLimit : 0;
       while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
         if (__hip_atomic_load(&dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 || ++spins > kLongSpinLimit) {
           __hip_atomic_store(&dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -215,6 +230,10 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
     //   oseg    collects lane 63's bottom-row value of every step (shift down, insert at lane 63): one ring write per segment.
     uint32_t code = pad;
     uint32_t curc = stage_load(0), nextc = stage_load(1);
+    uint32_t oprev = 0u;
+    float *rsave = (has_out && a.rowsave != nullptr)
+                       ? a.rowsave + (((size_t)range * (size_t)a.tiles_stride + (size_t)tile) * (size_t)(a.nstrips - 1) + (size_t)strip) * (size_t)a.row_stride
+                       : nullptr;
     const int segs_per_sub = (int)(a.sub_len / 64);
     const int warm_segs = (int)(a.warm / 64);
     int sub = 0;
@@ -245,6 +264,20 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
       curc = nextc;
       nextc = stage_load(seg + 2);
       uint32_t oseg = 0u;
+      // The saved copy of the PREVIOUS segment's bottom row goes out here, at the start of the steps: the waits above (flat
+      // atomic loads) and the release operations at the segment's end wait for every memory operation of the wavefront that
+      // is still in flight — vmcnt counts in order — and a store issued right in front of them cost the sweep a third
+      // (202 -> 268 ms on 10 kbp x 250 Mbp: one store round trip per segment); from here it has 64 steps to complete.
+      if (rsave != nullptr && seg > 0) {
+        const int64_t t = (int64_t)(seg - 1) * 64 + l - 63;
+        if (t >= 0) rsave[t] = __uint_as_float(oprev);
+      }
+      // the segment in front of own sub-chunk bdone / segs_per_sub: lane l stands at the column to save at step l
+      const int bdone = seg + 1 - warm_segs;
+      const bool save_seg = a.colsave != nullptr && bdone >= 0 && bdone % segs_per_sub == 0 && bdone / segs_per_sub < a.subs_per_tile;
+      const size_t csave_at = save_seg ? ((size_t)range * (size_t)a.col_subs + (size_t)tile * a.subs_per_tile + (size_t)(bdone / segs_per_sub)) * (size_t)a.col_rows +
+                                             (size_t)strip * 64 * R
+                                       : 0;
 #pragma unroll UNR
       for (int k = 0; k < 64; ++k) {
         {
@@ -303,6 +336,14 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
           Hg[r] = ng;
         }
         if (has_out) oseg = shl1_insert(__float_as_uint(H[R - 1]), oseg);  // lane 63 inserts, the others pass down
+        if (save_seg) {                                                    // (uniform: a scalar branch in all other segments —
+          asm volatile("" ::: "memory");                                   //  kept apart from the per-lane test below)
+          if (k == l) {                                                    // this lane stands at stream position seg * 64
+            float *csave = a.colsave + csave_at + (size_t)l * R;
+#pragma unroll
+            for (int r = 0; r < R; r += 4) *reinterpret_cast<float4 *>(csave + r) = make_float4(H[r], H[r + 1], H[r + 2], H[r + 3]);
+          }
+        }
       }
       // lane j of oseg holds lane 63's value of step j: stream position seg*64 + j - 63
       // positions <= seg*64 are stored; this wavefront has read positions <= seg*64 + 63
@@ -318,10 +359,15 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
         if (l == 0) __hip_atomic_store(&produced[w], (long long)seg * 64 + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       if (l == 0) __hip_atomic_store(&consumed[w], (long long)(seg + 1) * 64, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      oprev = oseg;                                                        // (saved at the start of the next segment's steps, see there)
       // lane 0 has just finished a sub-chunk (and it is not the tile's last): report and restart the maximum.  Lanes lag
       // lane 0 by up to 63 columns, so the tail of a sub-chunk is reported with the next one (the host widens its windows).
       const int done = seg + 1 - warm_segs;
       if (done > 0 && done % segs_per_sub == 0 && done / segs_per_sub < a.subs_per_tile) fold_sub(sub++);
+    }
+    if (ok && rsave != nullptr && nseg > 0) {                              // the last segment's bottom row
+      const int64_t t = (int64_t)(nseg - 1) * 64 + l - 63;
+      if (t >= 0) rsave[t] = __uint_as_float(oprev);
     }
     if (ok) fold_sub(a.subs_per_tile - 1);                                 // the tile's last (or only) sub-chunk
     // whatever happened, the workgroup below must not wait for this one any more

@@ -56,8 +56,17 @@ struct StripProblem {
                          // strip, one round); the bottom row of a workgroup's last strip reaches the next workgroup
                          // through gbound + g * gstride, progress through gcount[g] (global, zero at launch)
   long long *gcount;
-  int32_t fault;         // test hook (MI355_SW_FAULT_INJECT=strip_stall): wavefront 0 never reports progress, so the
+  int32_t fault;         // test hook (option fault_inject = strip_stall): wavefront 0 never reports progress, so the
                          // strip below it runs into the bounded wait and the workgroup takes the expiry path
+  // A BLOCK of a larger problem whose left column and top row the score sweep saved (sw_long_kernel.h colsave / rowsave,
+  // host_saved.h): rows row0 + 1 .. row0 + na of the query (a = x + row0), starting right of the saved column instead of a
+  // zero border; lane registers start from init, the first strip's boundary row comes complete from top.  Null: zero border.
+  const float *init;     // init[ai] = H(row0 + ai + 1, column in front of stream position 0) * in_scale^-1, ai = -1 .. (row0 + ai >= 0)
+  const float *top;      // top[t] = H(row0, column of stream position t) * in_scale^-1 (row0 > 0)
+  float in_scale;        // the saved values are the sweep's scaled cells: H = value * in_scale
+  int32_t row0;          // rows of the query above this block (true row = row0 + local row)
+  int32_t na_full;       // |x| of the full problem (uint8 storage order)
+  int32_t lt;            // kStripDirs: lanes of a decision row (64 * strips of the FULL problem); 0: 64 * nstrips
 };
 
 enum : int { kStripDirs = 0, kStripTrack = 1, kStripMax = 2 };
@@ -96,12 +105,14 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
   }
   __syncthreads();
   const int na = P.na, nb = P.nb;
+  const int nfull = P.na_full > 0 ? P.na_full : na;                  // rows of the full problem (a block knows only its own)
   const int nstrips = P.nstrips;
   const int s_first = multi ? grp * P.spg : 0;                       // this workgroup's first strip
   const int nw = multi ? min(P.spg, nstrips - s_first) : P.nw;       // wavefronts that take part (multi: one per strip)
   if (nw <= 0) return;
-  const int LT = 64 * nstrips;
+  const int LT = P.lt > 0 ? P.lt : 64 * nstrips;
   constexpr int W = (R + 15) / 16;
+  const bool top_saved = P.top != nullptr;                           // block of a larger problem: the row above it is in HBM
   const int nseg = (nb + 64 + 63) / 64;                  // lane 63 reaches stream position nb - 1
   const long long NBP = (long long)nseg * 64;            // counter units per round
   const int rounds = multi ? 1 : (nstrips + nw - 1) / nw;
@@ -153,12 +164,13 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
     const int s = s_first + round * nw + w;              // this wavefront's strip in this round
     if (s >= nstrips) break;
     const long long base = (long long)round * NBP;
-    const bool has_in = s > 0, has_out = s + 1 < nstrips;
+    const bool has_in = s > 0 || top_saved, has_out = s + 1 < nstrips;
+    const bool in_saved = top_saved && s == 0;           // complete in HBM before the launch: nothing to wait for
     const bool in_global = has_in && w == 0;             // from the last wavefront of the previous round
     const bool out_global = has_out && w == nw - 1;      // to wavefront 0 of the next round
     const float *rin = ring[w > 0 ? w - 1 : 0];
     float *rout = ring[w];
-    const float *gin = in_global ? P.gbound + (size_t)(multi ? grp - 1 : ((round + 1) & 1)) * (size_t)P.gstride : nullptr;
+    const float *gin = in_saved ? P.top : (in_global ? P.gbound + (size_t)(multi ? grp - 1 : ((round + 1) & 1)) * (size_t)P.gstride : nullptr);
     float *gout = out_global ? P.gbound + (size_t)(multi ? grp : (round & 1)) * (size_t)P.gstride : nullptr;
 
     uint32_t ca[R];
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
 
     for (int seg = 0; seg < nseg && ok; ++seg) {
       // input: boundary positions seg*64 .. seg*64+63 (the strip above finishes them during ITS segment seg+1)
-      if (has_in) {
+      if (has_in && !in_saved) {
         const long long need = (seg + 1) * 64 < nb ? (seg + 1) * 64 : nb;
         if (in_global) {
           if (multi) wait_global(P.gcount + (grp - 1), need);
@@ -199,8 +211,21 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
       uint32_t bseg = 0u;
       {
         const int tl = seg * 64 + l;
-        if (has_in && tl < nb)
-          bseg = __float_as_uint(in_global ? __hip_atomic_load(gin + tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : rin[tl & (kStripRing - 1)]);
+        if (has_in && tl < nb) {
+          if (in_saved) bseg = __float_as_uint(gin[tl] * P.in_scale);
+          else bseg = __float_as_uint(in_global ? __hip_atomic_load(gin + tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : rin[tl & (kStripRing - 1)]);
+        }
+      }
+      // a block that starts right of a saved column: lane l reaches stream position 0 at step l of the first segment and
+      // takes its rows of that column (and the row above them, for its first diagonal term) then
+      float hinit[R];
+      float dinit = 0.0f;
+      const bool seeded = P.init != nullptr && seg == 0;
+      if (seeded) {
+        const int ai0 = (s * 64 + l) * R;
+#pragma unroll
+        for (int r = 0; r < R; ++r) hinit[r] = (ai0 + r < na) ? P.init[ai0 + r] * P.in_scale : 0.0f;
+        dinit = (P.row0 + ai0 > 0) ? P.init[ai0 - 1] * P.in_scale : 0.0f;
       }
       uint32_t cseg = curc;
       curc = nextc;
@@ -216,6 +241,11 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
           code = shr1(head, code);
         }
         const uint32_t cb = code;
+        if (seeded && k == l) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) H[r] = hinit[r];
+          up_prev = __float_as_uint(dinit);
+        }
         uint32_t up;                                                     // H(first row of the strip - 1, this column)
         if (has_in) { const uint32_t head = bseg; bseg = rot1(bseg); up = shr1(head, __float_as_uint(H[R - 1])); }
         else up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(H[R - 1]), 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
@@ -263,9 +293,9 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
             while (rows) {
               const int r = __builtin_ctz(rows);
               rows &= rows - 1;
-              const long long i = (long long)(s * 64 + l) * R + r + 1;
-              if (i <= na) {
-                const unsigned long long key = U8 ? order_key<1>(i, j, na, P.full_n) : order_key<0>(i, j, na, P.full_n);
+              const long long il = (long long)(s * 64 + l) * R + r + 1, i = il + P.row0;
+              if (il <= na) {
+                const unsigned long long key = U8 ? order_key<1>(i, j, nfull, P.full_n) : order_key<0>(i, j, nfull, P.full_n);
                 if (key < bkey) { bkey = key; bi = i; bj = j; }
               }
             }
@@ -278,9 +308,9 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void sw_strip_kernel(const Str
             const long long j = P.col_offset + t + 1;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-              const long long i = (long long)(s * 64 + l) * R + r + 1;
-              if (H[r] >= bval && H[r] > 0.0f && i <= na) {
-                const unsigned long long key = U8 ? order_key<1>(i, j, na, P.full_n) : order_key<0>(i, j, na, P.full_n);
+              const long long il = (long long)(s * 64 + l) * R + r + 1, i = il + P.row0;
+              if (H[r] >= bval && H[r] > 0.0f && il <= na) {
+                const unsigned long long key = U8 ? order_key<1>(i, j, nfull, P.full_n) : order_key<0>(i, j, nfull, P.full_n);
                 if (H[r] > bval || key < bkey) { bval = H[r]; bkey = key; bi = i; bj = j; }
               }
             }

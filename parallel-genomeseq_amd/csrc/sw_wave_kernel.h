@@ -481,6 +481,10 @@ struct WaveWalk {
   int64_t exact_from;      // stream index (true, 1-based) from which every cell is exact; 0 = all
   int32_t cap;             // longest consensus the caller accepts
   int64_t *out;            // [0] length, [1] pos, [2] status (0 ok, 1 window too small, 2 capacity)
+  // Decisions made from the score sweep's saved columns / rows (host_saved.h): a cell is as exact as the sweep's TILE that
+  // owns its column made it — tile T = (column - 1 + 63) / zchunk started from a zero border at column T * zchunk - zwarm
+  // (tile 0: the matrix border itself).  zchunk > 0 replaces b_offset by that border in the need_slope rule; exact_from = 0.
+  int64_t zchunk, zwarm;
 };
 
 // Many walks take two passes over the same decisions: kWalkMeasure yields (length, pos, status); the host then
@@ -578,6 +582,10 @@ __global__ __launch_bounds__(64) void sw_wave_walk_long_kernel(const WaveWalk *p
           need = rn < need ? rn : need;
         }
         if (cy - 1 < need) inwin = false;
+      }
+      if (inwin && W.zchunk > 0) {
+        const long long tile = (cy - 1 + 63) / W.zchunk;
+        if (tile > 0 && cy - 1 < tile * W.zchunk - W.zwarm + cx + (long long)ceilf((float)cx * W.need_slope) + 2) inwin = false;
       }
       if (!inwin) code = 4;
       else if (len + p >= W.cap) code = 5;

@@ -84,28 +84,45 @@ def align_queries_sharded(align_fn, queries, weights=None, gather=True):
     arrays score/pos/end_x/end_y identical on every rank."""
     rank, size = world()
     n = len(queries)
+    # every rank derives EVERY rank's shard (both partitions are deterministic): the gather below needs no index exchange
     if weights is None:
-        lo, hi = shard_block(n, rank, size)
-        idx = np.arange(lo, hi, dtype=np.int64)
+        parts = [np.arange(*shard_block(n, r, size), dtype=np.int64) for r in range(size)]
     else:
-        idx = shard_lpt(weights, size)[rank]
+        parts = shard_lpt(weights, size)
+    idx = parts[rank]
     res = align_fn([queries[i] for i in idx]) if len(idx) else []
     gathered = None
     if gather:
-        # disjoint shards: SUM == gather (x + 0 is exact in both types); the scores stay float32
-        full = torch.zeros((3, n), dtype=torch.int64, device=_dev())
-        fsc = torch.zeros(n, dtype=torch.float32, device=_dev())
+        # ONE all_gather of 16 B per alignment (SURVEY.md §8e): (score as float32 bits, pos, end_x, end_y) as four int32 —
+        # pos is the reference's unsigned int, end_x / end_y are below 2^31 for every reference this engine holds; shards are
+        # padded to the longest one (all_gather wants equal shapes), the padding is dropped on arrival
+        longest = max(len(p) for p in parts) if parts else 0
+        rec = np.zeros((max(1, longest), 4), dtype=np.int32)
         if len(idx):
-            loc = torch.tensor([[r["pos"] for r in res], [r["end_x"] for r in res], [r["end_y"] for r in res]],
-                               dtype=torch.int64, device=_dev())
-            at = torch.as_tensor(idx, device=_dev())
-            full[:, at] = loc
-            fsc[at] = torch.tensor([r["score"] for r in res], dtype=torch.float32, device=_dev())
+            rec[:len(idx), 0] = np.array([r["score"] for r in res], dtype=np.float32).view(np.int32)
+            rec[:len(idx), 1] = np.array([r["pos"] for r in res], dtype=np.int64).astype(np.uint32).view(np.int32)
+            rec[:len(idx), 2] = np.array([r["end_x"] for r in res], dtype=np.int64)
+            rec[:len(idx), 3] = np.array([r["end_y"] for r in res], dtype=np.int64)
+        mine = torch.from_numpy(rec).to(_dev())
         if size > 1:
-            dist.all_reduce(full, op=dist.ReduceOp.SUM)
-            dist.all_reduce(fsc, op=dist.ReduceOp.SUM)
-        full = full.cpu().numpy()
-        gathered = dict(score=fsc.cpu().numpy(), pos=full[0], end_x=full[1], end_y=full[2])
+            every = [torch.empty_like(mine) for _ in range(size)]
+            dist.all_gather(every, mine)
+        else:
+            every = [mine]
+        score = np.zeros(n, dtype=np.float32)
+        pos = np.zeros(n, dtype=np.int64)
+        end_x = np.zeros(n, dtype=np.int64)
+        end_y = np.zeros(n, dtype=np.int64)
+        for r in range(size):
+            k = len(parts[r])
+            if k == 0:
+                continue
+            a = every[r].cpu().numpy()[:k]
+            score[parts[r]] = a[:, 0].copy().view(np.float32)
+            pos[parts[r]] = a[:, 1].copy().view(np.uint32)
+            end_x[parts[r]] = a[:, 2]
+            end_y[parts[r]] = a[:, 3]
+        gathered = dict(score=score, pos=pos, end_x=end_x, end_y=end_y)
     return idx, res, gathered
 
 
@@ -176,6 +193,10 @@ def align_split_sharded_certified(ranges, best_fn, final_align_fn, max_rounds=3)
         if gbest > above:
             break
         known = max(gbest, 1.0)
+    else:
+        # (every rank sees the same merged values, so every rank raises)
+        raise RuntimeError("reference sharding: the merged best %r is still not above what the sweeps certify (%r) after %d rounds"
+                           % (gbest, above, max_rounds))
     owner = piece % size
     res = None
     if rank == owner:

@@ -57,6 +57,8 @@ def test_cpp_dropin_headers_compile():
     assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "test_dropin.bin"))
     if os.path.exists("/root/reference/cmake/eigen-3.3.7.zip"):
         assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "test_dropin_eigen.bin"))
+        # the reference's own test/*.cpp, unchanged and in place, against the mirror + tests/cpp/gtest_shim
+        assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "test_reference_gtests.bin"))
 
 
 def test_index_maps_match_reference(pgs, golden):

@@ -160,14 +160,33 @@ def _cpp_test_binary(name):
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "tests", "cpp", name)
-    if not os.path.exists(exe) and name != "test_dropin_eigen.bin":
+    if not os.path.exists(exe) and name not in ("test_dropin_eigen.bin", "test_reference_gtests.bin"):
         import __graft_entry__ as g
         g.build()
     return exe
 
 
+def test_reference_gtest_files_compiled_in_place():
+    """The reference's OWN test files (/root/reference/test/main.cpp, test_localaligner.cpp, test_skewedmatrix.cpp, …), compiled
+    where they lie against include/parseq/*.h and a build-owned minimal <gtest/gtest.h> (tests/cpp/build_dropin.sh), run on the
+    GPU: SWAligner_Test.Example_small_sequence_alignment / Verify_consensus_strings, SimilarityMatrix.SkewedMatrixIndex /
+    SkewedMatrixDP — the four real tests of the reference.  Prebuilt where the reference exists (the binary
+    travels to the GPU box); where it did not travel this is SKIPPED, not passed."""
+    import os
+    import subprocess
+    exe = _cpp_test_binary("test_reference_gtests.bin")
+    if not os.path.exists(exe):
+        pytest.skip("tests/cpp/test_reference_gtests.bin was not built (needs /root/reference at build time)")
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and "[  PASSED  ] 4 tests." in out, out
+    for name in ("SWAligner_Test.Example_small_sequence_alignment", "SWAligner_Test.Verify_consensus_strings",
+                 "SimilarityMatrix.SkewedMatrixIndex", "SimilarityMatrix.SkewedMatrixDP"):
+        assert "[       OK ] " + name in out, out
+
+
 def test_cpp_dropin_binary():
-    """The reference's gtest cases compiled against include/parseq/*.h run on the GPU."""
+    """What the reference's gtest files do not cover of include/parseq/*.h (tests/cpp/test_dropin.cpp) runs on the GPU."""
     import os
     import subprocess
     exe = _cpp_test_binary("test_dropin.bin")

@@ -77,9 +77,9 @@ def fuzz_cases(pgs, oracle):
 
 # every switch that selects another kernel instance / pipeline for the same answer
 SWITCHES = ["no_f16", "no_unsat", "no_sample", "no_satflag", "no_solo", "no_wave", "no_comb", "no_twin", "no_wide",
-            "no_strip", "no_quant", "no_f16_wide", "no_devlist", "no_strip_groups", "u8_long_twin", "long_twin", "no_long",
+            "no_strip", "no_quant", "no_devlist", "no_strip_groups", "u8_long_twin", "long_twin", "no_long",
             "no_requery", "slot=16", "strip_r=24", "few_r=5", "long_pipes=2", "no_long_p32", "long_groups=2", "force_f32", "no_opt_margin", "no_wave_prof",
-            "no_wave_window", "no_first"]
+            "no_wave_window", "no_first", "no_long_save", "assume_cus=32", "u8_sample_short", "no_wave_pieces"]
 
 
 def test_option_names_cover_the_switch_list(pgs):
@@ -385,8 +385,9 @@ def test_packed_upload_equals_pointer_upload(pgs, oracle):
 
 def test_best_range_winner_only(pgs, oracle):
     """mi355_sw_best_range (what OMPParallelLocalAligner needs from the per-piece maxima, plocalaligner.cpp:122-129): winner
-    and its maximum exact, first piece on ties; maxima of pieces that cannot win are lower bounds within 3 gaps (a lone long
-    query is swept on the sampled maximum); finishing the winner AND a loser through align_scored_range gives the piece's
+    and its maximum exact, first piece on ties, every piece that ties with the winner exact too; maxima of pieces that cannot
+    win are lower bounds of unspecified slack, never above the truth (a lone long query is swept on the sampled maximum behind
+    an optimistic warm-up margin: both only lower values); finishing the winner AND a loser through align_scored_range gives the piece's
     stand-alone alignment; short queries (exact sweep) behave like score_ranges."""
     ref = pgs.synth.dna(7401, 500_000)
     refb = bytearray(ref.tobytes())
@@ -404,14 +405,14 @@ def test_best_range_winner_only(pgs, oracle):
             best, which, mx = c.best_range(ranges, semantics=sem)
             assert best[0] == max(true) and which[0] == true.index(max(true)), (sem, best, which, true)
             for k in range(5):
-                assert true[k] - 6 <= mx[k, 0] <= true[k], (sem, k, mx[k, 0], true[k])
+                assert mx[k, 0] <= true[k], (sem, k, mx[k, 0], true[k])
                 if true[k] == max(true):
                     assert mx[k, 0] == true[k]
+            if sem == 0:
+                assert "sw_long_kernel" in c.last_kernel()["name"], c.last_kernel()["name"]
             for k in (int(which[0]), 2):
                 lo, hi = ranges[k]
                 _cmp(c.align_scored_range(k, semantics=sem), oracle.align(q, refb[lo:hi], sem), "best_range finish sem=%d piece %d" % (sem, k))
-        if True:
-            assert "sw_long_kernel" in c.last_kernel()["name"] or True
         # a short query: exact sweep, every maximum exact
         qs = bytes(refb[250_000:250_150])
         c.batch_upload([qs, q[:200]])

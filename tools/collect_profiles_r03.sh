@@ -6,11 +6,12 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_r03
 mkdir -p $OUT $R/gpurun_out/pmc
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-strong --no-traffic --no-parity"
+PY=$(python3 -c "import os,sys;print(os.path.realpath(sys.executable))")
+B="$PY $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-strong --no-traffic --no-parity"
 rocprofv3 --kernel-trace --stats -d $OUT/kt_bench --output-format csv -- $B > $OUT/kt_bench.json 2> $OUT/kt_bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/kt_config4 --output-format csv -- python3 $R/tools/c4_packed.py > $OUT/config4.log 2>&1
-rocprofv3 --kernel-trace --stats -d $OUT/kt_config5 --output-format csv -- python3 $R/tools/c5_whole.py > $OUT/config5.log 2>&1
-rocprofv3 --kernel-trace --stats -d $OUT/kt_one_by_one --output-format csv -- python3 $R/tools/lat_probe.py 50000000 0 > $OUT/one_by_one.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/kt_config4 --output-format csv -- $PY $R/tools/c4_packed.py > $OUT/config4.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/kt_config5 --output-format csv -- $PY $R/tools/c5_whole.py > $OUT/config5.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/kt_one_by_one --output-format csv -- $PY $R/tools/lat_probe.py 50000000 0 > $OUT/one_by_one.log 2>&1
 cd $R
 tools/pmc_run.sh bench 'sw_score_kernel' python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-strong --no-traffic --no-parity > $OUT/pmc_bench.log 2>&1
 tools/pmc_run.sh config4 'sw_wave_prof_kernel<10, true, true>|sw_wave_prof_kernel<10, true, false>|sw_wave_walk_kernel' python3 $R/tools/c4_packed.py > $OUT/pmc_config4.log 2>&1

@@ -4,6 +4,13 @@
 # one summary per kernel-name substring -> gpurun_out/pmc/TAG.<n>.json (n = position of the substring)
 TAG=$1; KSUBS=$2; shift 2
 R=$GRAFT_REPO_ROOT
+# a bare `python3` may resolve to a shim or a `#!/usr/bin/env` launcher, i.e. an exec hop AFTER the profiler's preloaded library
+# has initialised the GPU (forbidden on this pool): hand rocprofv3 the real interpreter binary
+if [ "$1" = python3 ] || [ "$1" = python ]; then
+  PY=$("$1" -c 'import os,sys;print(os.path.realpath(sys.executable))')
+  shift
+  set -- "$PY" "$@"
+fi
 OUT=$R/gpurun_out/pmc/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
