@@ -2,6 +2,7 @@
 library is missing, or no MI355X is visible, every compute call raises."""
 import ctypes as C
 import os
+import time
 
 import numpy as np
 
@@ -123,6 +124,7 @@ class Context:
         self.device = device
         self._view = None              # struct-of-arrays view of the last batch_run(raw=True): library memory, see consensus()
         self._nbatch = 0
+        self.last_call_s = 0.0         # wall time of the last mi355_sw_batch_run_view call itself (batch_run(raw=True))
 
     def close(self):
         self._view = None
@@ -221,7 +223,10 @@ class Context:
             # struct-of-arrays view in library-owned memory (mi355_sw_batch_run_view): no per-result objects, no
             # per-result allocations on either side; cons=True adds the strings' lengths and addresses
             v = BatchView()
-            self._chk(self._L.mi355_sw_batch_run_view(self._ctx, C.byref(p), C.c_int(flags), C.byref(v)))
+            t0 = time.perf_counter()
+            rc = self._L.mi355_sw_batch_run_view(self._ctx, C.byref(p), C.c_int(flags), C.byref(v))
+            self.last_call_s = time.perf_counter() - t0            # the C-ABI call alone (what a C / C++ caller waits for)
+            self._chk(rc)
             if n == 0:
                 return dict(score=np.zeros(0, np.float32), pos=np.zeros(0, np.int64), end_x=np.zeros(0, np.int64),
                             end_y=np.zeros(0, np.int64), cons_len=np.zeros(0, np.int64))
@@ -308,7 +313,7 @@ class Context:
         c = (C.c_uint64 * 4)()
         self._L.mi355_sw_last_counters(self._ctx, c)
         out = dict(requeried=int(c[0]), whole_batch_again=int(c[1]), candidates=int(c[2]), left_window=int(c[3]))
-        for name in ("first_settled", "saved_locates", "saved_traces", "saved_fallbacks", "wait_retries"):
+        for name in ("first_settled", "saved_locates", "saved_traces", "saved_fallbacks", "wait_retries", "early_settled"):
             v = C.c_uint64(0)
             rc = self._L.mi355_sw_last_counter(self._ctx, name.encode(), C.byref(v))
             if rc:

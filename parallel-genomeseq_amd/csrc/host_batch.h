@@ -46,7 +46,7 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   // sequences: walks of a dozen cells; a walk that leaves its window hands the problem to the host-driven path below).
   const bool prof = orient == 1 && wave_prof_ok(ref, p, R, (int)nref, true);
   const bool windows = prof && want_trace && !opt().no_wave_window;
-  // Long streams in pieces (sw_batch_kernels.h): kPieceRows own rows behind a warm-up of the L1 margin along the stream (a path
+  // Long streams in pieces (sw_batch_kernels.h; DESIGN.md §3.3 lemma L12): kPieceRows own rows behind a warm-up of the L1 margin along the stream (a path
   // that ends in row i of x spans fewer than |y| + ceil(smax |y| / g) rows) plus the reach of a decision window in front of an
   // own row (kWindowGuard + 63 + 1), so that own rows and the checkpoints their windows resume from are exact.  Only where the
   // pass keeps no whole-problem decisions (score + argmax, or checkpointed windows).

@@ -14,8 +14,8 @@ constexpr size_t kExactLdsMax = 159 * 1024;    // dynamic part; the wide instanc
 #define MI355_SW_BOOL_OPTIONS(X) \
   X(no_f16) X(no_unsat) X(no_sample) X(no_satflag) X(no_solo) X(no_wave) X(no_comb) X(no_twin) X(no_wide) X(no_strip) \
   X(no_quant) X(no_devlist) X(no_ref_cache) X(no_strip_groups) X(u8_long_twin) X(long_twin) X(no_long) \
-  X(no_requery) X(force_f32) X(no_long_p32) X(no_opt_margin) X(no_wave_prof) X(no_wave_window) X(no_first) X(no_long_save) X(u8_sample_short) X(no_wave_pieces) X(trace)
-#define MI355_SW_INT_OPTIONS(X) X(strip_r) X(slot) X(few_r) X(chunk) X(long_pipes) X(long_wgs) X(long_sub) X(long_r) X(long_groups) X(assume_cus)
+  X(no_requery) X(force_f32) X(no_long_p32) X(no_opt_margin) X(no_wave_prof) X(no_wave_window) X(no_first) X(no_long_save) X(u8_sample_short) X(no_wave_pieces) X(no_u8_early) X(trace)
+#define MI355_SW_INT_OPTIONS(X) X(strip_r) X(slot) X(few_r) X(chunk) X(long_pipes) X(long_wgs) X(long_sub) X(long_r) X(long_groups) X(assume_cus) X(long_save_what)
 struct Options {
 #define X(n) bool n = false;
   MI355_SW_BOOL_OPTIONS(X)
@@ -316,6 +316,7 @@ struct mi355_sw_ctx {
   bool long_launched = false;     // a sw_long_kernel launch since the last score_fetch (its status word is flags[1])
   std::string path;               // which kernels / pipelines the running call used (mi355_sw_last_path): space-separated tags
   DevInfo dev;                    // CU count and LDS per CU of this context's device
+  size_t early_settled = 0;       // uint8-engine queries of the running call settled by the reference's first and last sub-chunks (no sweep)
   size_t wait_retries = 0;        // launches of the running call that were repeated on a non-waiting instance (tl_no_wait)
   LongSaved lsaved;
   DevBuf colsave, rowsave, pieces;
@@ -399,7 +400,7 @@ inline int sat8(float a) { return a < 0 ? 0 : (a > 255 ? 255 : (int)(uint8_t)a);
 constexpr int64_t kColsMax = (int64_t)1 << 50;
 inline int64_t clamp_cols(double v) { return v >= (double)kColsMax ? kColsMax : (v <= 0 ? 0 : (int64_t)v); }
 
-// Exactness margins under float32 ROUNDING.  A cell value is the rounded score of a chain of cells
+// Exactness margins (lemma L1; rows(): L2) under float32 ROUNDING.  A cell value is the rounded score of a chain of cells
 // (follow the neighbour that achieved the maximum) that ends where a cell is 0.  With integer-valued scores every
 // operation is exact and a chain with positive value over `rows` rows spans fewer than rows + smax*rows/g columns.
 // With fractional scores each of the chain's operations may round by up to u = half an ulp of the largest value
@@ -521,19 +522,76 @@ Hash128 content_hash_part(const char *p, size_t n) {
   return r;
 }
 
-// Per-item host loops over a big batch (half a million small alignments per call): four-way on helper threads.
-// fn(k0, k1) must only touch items k0 <= k < k1.
+// Per-item host loops over a big batch (half a million small alignments per call) on a few PERSISTENT worker threads (one
+// process-wide pool, started on first use): creating threads per loop (std::async) cost 0.1-0.2 ms each time — more than the
+// loop itself on one rank's eighth of the UniProt-shaped batch, i.e. a per-call constant that did not shrink with the share.
+// fn(k0, k1) must only touch items k0 <= k < k1.  Not re-entrant (a context serves one host thread; concurrent contexts
+// take turns at the pool).
+class WorkerPool {
+ public:
+  static WorkerPool &get() { static WorkerPool p; return p; }
+  // runs job(t) for t = 1 .. nt - 1 on the workers and job(0) on the caller; returns when all are done
+  void run(int nt, const std::function<void(int)> &job) {
+    nt = std::min(nt, kWorkers + 1);
+    if (nt <= 1) { job(0); return; }
+    std::lock_guard<std::mutex> turn(turn_);
+    {
+      std::lock_guard<std::mutex> g(m_);
+      if (th_.empty()) for (int w = 0; w < kWorkers; ++w) th_.emplace_back([this, w] { loop(w); });
+      job_ = &job; want_ = nt - 1; pending_ = nt - 1; ++gen_;
+    }
+    cv_.notify_all();
+    job(0);
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [&] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+  ~WorkerPool() {
+    { std::lock_guard<std::mutex> g(m_); quit_ = true; }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+
+ private:
+  static constexpr int kWorkers = 7;
+  void loop(int w) {
+    unsigned seen = 0;
+    std::unique_lock<std::mutex> g(m_);
+    for (;;) {
+      cv_.wait(g, [&] { return quit_ || gen_ != seen; });
+      if (quit_) return;
+      seen = gen_;
+      if (w >= want_) continue;
+      const std::function<void(int)> *job = job_;
+      g.unlock();
+      (*job)(w + 1);
+      g.lock();
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_, turn_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)> *job_ = nullptr;
+  int want_ = 0, pending_ = 0;
+  unsigned gen_ = 0;
+  bool quit_ = false;
+};
+
 template <class F>
 void parallel_for(size_t n, F fn) {
-  if (n < 65536) { fn((size_t)0, n); return; }
-  const int nt = n >= 262144 ? 8 : 4;                              // (half a million alignments per call: eight threads)
+  if (n < 16384) { fn((size_t)0, n); return; }
+  const int nt = n >= 49152 ? 8 : 4;                               // (the pool's threads are there: a rank's eighth of the UniProt-shaped
+                                                                   //  batch — 70 k alignments — gets all eight, as the whole batch does)
   const size_t step = (n + nt - 1) / nt;
-  std::future<void> parts[7];
   const Options *caller = tl_opt;                                  // the workers see the calling context's options, not the environment's
-  auto bound = [caller, &fn](size_t k0, size_t k1) { const Options *was = tl_opt; tl_opt = caller; fn(k0, k1); tl_opt = was; };
-  for (int t = 0; t + 1 < nt; ++t) parts[t] = std::async(std::launch::async, bound, std::min(n, (size_t)(t + 1) * step), std::min(n, (size_t)(t + 2) * step));
-  fn((size_t)0, std::min(n, step));
-  for (int t = 0; t + 1 < nt; ++t) parts[t].get();
+  const DevInfo *caller_dev = tl_dev;
+  WorkerPool::get().run(nt, [&](int t) {
+    const Options *was = tl_opt; const DevInfo *was_dev = tl_dev;
+    tl_opt = caller; tl_dev = caller_dev;
+    fn(std::min(n, (size_t)t * step), std::min(n, (size_t)(t + 1) * step));
+    tl_opt = was; tl_dev = was_dev;
+  });
 }
 
 inline Hash128 combine_hash(Hash128 r, const Hash128 &o) {

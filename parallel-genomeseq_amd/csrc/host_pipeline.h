@@ -22,8 +22,8 @@ int trace_located(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, co
                   const mi355_sw_params &p, const std::vector<int64_t> &qwarm, const ScoreTable &table,
                   const std::vector<int> &qidx, const std::vector<Located> &loc, std::vector<TraceOut> &tout) {
   tout.assign(qidx.size(), TraceOut());
-  // A cell in row i is exact once it lies i + ceil(i * smax / g) columns into a window (the bound of DESIGN.md
-  // §3.3 for a path that can only use rows 1..i), so the window needs that margin at the argmax row plus room
+  // A cell in row i is exact once it lies i + ceil(i * smax / g) columns into a window (lemma L2: the bound
+  // for a path that can only use rows 1..i), so the window needs that margin at the argmax row plus room
   // for the horizontal excursions of the walk; the walk kernel checks every cell it visits against the bound.
   const Margin mg = table.margin(q.maxlen);
   const float slope = (float)mg.slope();
@@ -290,7 +290,7 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
     const int64_t chunk_len = qchunk[k];           // sub-chunk granularity of this query's bucket
     const int64_t nchunks = (n + chunk_len - 1) / chunk_len;
     // only cells equal to the known maximum compete: a path that reaches `score` within |x| diagonal steps can
-    // afford fewer gap columns than the general margin allows (DESIGN.md §3.3 with the score subtracted)
+    // afford fewer gap columns than the general margin allows (lemma L3)
     int64_t warm = qwarm[k];
     const Margin mg = table.margin(q.len[k]);
     if (mg.finite()) {
@@ -394,6 +394,7 @@ int locate_fast(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, cons
   return 0;
 }
 
+// (L5 — candidates of a sampled sweep —, L6 — flagged sub-chunks of a saturating sweep —, L3 for the margin.)
 // Queries whose saturating float16 sweep reached the cap (host_score.h make_buckets): exact maximum and first maximum
 // cell from the sub-chunks the sweep flagged — each re-evaluated on the pipelined strip kernel (kStripMax) over a window
 // with the general warm-up margin in front.  `flagged` = {query id, sub-chunk}; done[k] is set for every query resolved.
@@ -558,7 +559,59 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       path_note(ctx, "margin_again");
       return false;
     };
-    for (int attempt = 0; attempt < 4 && !pre; ++attempt) {
+    // uint8 engine, EARLY EXIT.  The maximum never exceeds 255, and the answer is the 255 that comes first in the
+    // skewed storage order: on the lowest anti-diagonal i + j — so within the first sub-chunk s1 that truly holds a 255 or its right
+    // neighbour (sub-chunks are longer than |x| + 64 columns) — unless the wrapped bottom-right triangle (the last two
+    // sub-chunks) holds one, which the layout stores in front of everything.  Reads whose random BACKGROUND reaches the cap
+    // (beyond ~300 bp at 3 / -3 / 2: the linear regime, about 0.6 per row) hold a 255 within the reference's first few hundred
+    // columns: when the exact evaluation of sub-chunks 0 and 1 and of the last two finds a 255 in sub-chunk 0, that is s1 = 0,
+    // every candidate has been evaluated, and the sweep of the remaining reference cannot change (maximum, first cell) — it is
+    // skipped.  (The reference sweeps it all the same; its answer for such reads is decided where the matrix first saturates.)
+    bool all_early = false;
+    if (!pre && p.semantics == MI355_SW_U8SAT && n >= 1024 && allow_sample && !opt().no_u8_early && nq <= 4096 && table.ok) {
+      std::vector<Bucket> bk = make_buckets(ref, q, table, p, n, false, false);
+      std::vector<int64_t> echunk(nq, 0), ewarm(nq, 0);
+      std::vector<float> elow(nq, 255.0f);
+      std::vector<char> edone(nq, 0);
+      std::vector<std::pair<uint32_t, uint32_t>> ff;
+      bool likely = !bk.empty();
+      for (Bucket &b : bk) {
+        likely = likely && bucket_fast_ok(ref, table, b, n, p) && 0.3 * (double)table.smax * (double)q.len[q.order[b.first]] >= 255.0;
+        if (!likely) break;
+        const int64_t E = score_sub_len(p.semantics, b), nsub = (n + E - 1) / E;
+        for (int k = 0; k < b.count; ++k) {
+          const int id = q.order[b.first + k];
+          echunk[id] = E; ewarm[id] = b.warm;
+          int64_t seen[4]; int ns = 0;
+          for (int64_t s : {(int64_t)0, (int64_t)1, nsub - 2, nsub - 1}) {
+            bool dup = s < 0 || s >= nsub;
+            for (int t = 0; t < ns; ++t) dup = dup || seen[t] == s;
+            if (!dup) { seen[ns++] = s; ff.push_back({(uint32_t)id, (uint32_t)s}); }
+          }
+        }
+      }
+      if (likely && !ff.empty()) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+        int rc = locate_saturated(ctx, ref, q, rg, p, echunk, ewarm, elow, table, ff, loc, edone);
+        if (rc) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+        ctx->timings[1] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
+        all_early = true;
+        for (size_t k = 0; k < nq && all_early; ++k) {
+          const bool wrapped = loc[k].ix + loc[k].iy > n && n >= (int64_t)q.len[k];
+          all_early = edone[k] && loc[k].score == 255.0f && (loc[k].iy - 1 < echunk[k] || wrapped);
+        }
+        if (all_early) {
+          for (size_t k = 0; k < nq; ++k) { qfast[k] = 1; qdone[k] = 1; qchunk[k] = echunk[k]; qwarm[k] = ewarm[k]; }
+          any_fast = true;
+          ctx->early_settled += nq;
+          path_note(ctx, "u8_early");
+        } else {
+          for (size_t k = 0; k < nq; ++k) loc[k] = Located();       // (the sweep decides for everybody)
+        }
+      }
+    }
+    for (int attempt = 0; attempt < 4 && !pre && !all_early; ++attempt) {
       buckets.clear();
       if (n >= 1024) buckets = make_buckets(ref, q, table, p, n, allow_sat, allow_sample);
       any_fast = false;
@@ -913,7 +966,7 @@ int align_range_view(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
 }
 
 // Per-range maxima of every query (value half of find_index_of_maximum per piece).
-// winner_only (mi355_sw_best_range): the caller only needs, per query, the first range with the greatest maximum — what
+// winner_only (mi355_sw_best_range; DESIGN.md §3.3 lemmas L10, L11): the caller only needs, per query, the first range with the greatest maximum — what
 // OMPParallelLocalAligner does with the per-piece maxima (plocalaligner.cpp:122-129).  A lone long query is then swept with the
 // sampled maximum (every 4th step: keys are lower bounds within three gaps), and only the ranges whose key lies within that
 // slack of the best key — the only ones that can hold the greatest maximum — have their candidate sub-chunks re-evaluated
@@ -1082,7 +1135,7 @@ void reset_timings(mi355_sw_ctx *ctx) {
   ctx->score_ev_used = 0; ctx->arenas.clear(); ctx->cons_used = 0;
   ctx->last_kernel = mi355_sw_kernel_info{};
   ctx->requeried = 0; ctx->whole_again = 0; ctx->candidates = 0; ctx->left_window = 0; ctx->first_settled = 0;
-  ctx->saved_locates = 0; ctx->saved_traces = 0; ctx->saved_fallbacks = 0; ctx->wait_retries = 0;
+  ctx->saved_locates = 0; ctx->saved_traces = 0; ctx->saved_fallbacks = 0; ctx->wait_retries = 0; ctx->early_settled = 0;
   ctx->path.clear();
 }
 

@@ -9,7 +9,7 @@
 // row: the candidate window of the locate step is ceil(|x| / (64 R)) blocks, the decision window of the traceback one block
 // per (strip, sub-chunk) it covers, all resident at once on different CUs, each as long as ONE block's sweep.
 //
-// Exactness (lemma numbers: DESIGN.md §3): a saved value is what the sweep computed, i.e. the cell of a window whose zero
+// Exactness (DESIGN.md §3.3 lemma L9, with L2-L4): a saved value is what the sweep computed, i.e. the cell of a window whose zero
 // border is the sweep tile's (column T * chunk - warm; tile 0: the matrix border).  Every margin argument therefore holds
 // with that border in place of the window's own: locate takes a candidate only when the tile's margin covers the
 // score-aware margin of locate_saturated, the walk kernel checks every cell it visits against the tile border

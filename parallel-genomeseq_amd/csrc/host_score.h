@@ -178,6 +178,11 @@ bool long_shape(int ncodes, int len, int &R, int &nstrips) {
   return best > 0;
 }
 
+// Tile shape of a lone short query on twin tiles: 16 lanes x R rows.  (Round 4 tried 8 lanes x 19 rows with the code-pair profile
+// — half the per-step work per cell, 152 instead of 160 rows: 0.646 against 0.658 ms per 150 bp x 50 Mbp sweep, and 0.157 against
+// 0.098 ms at 1 Mbp, where half as many wavefronts leave CUs idle: dropped, CHANGELOG.md.)
+void twin_shape(const RefData &ref, Bucket &b) { b.SL = 16; b.R = pick_R(b.maxlen); b.comb = comb_ok(ref.ncodes, b.R); }
+
 // Length classes of the batch: one bucket per kernel instance (R), plus one strip-mined bucket.
 bool sampled_instance(int SL, int R) {
   if (SL == 8) return R == 13 || R == 16 || R == 19 || R == 26 || R == 32;
@@ -216,7 +221,7 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       // the same rule in packed float16 cells scaled by 1/256 (4.25 instead of 5.5 ops per cell); values never leave
       // 0..255, so this holds for every query length
       if (b.sem == kSemU8 && !opt().no_f16) b.sem = kSemU8H;
-      // The score pass only has to deliver, per query, the maximum and the FIRST sub-chunk that reaches it.  Sweep with
+      // (DESIGN.md §3.3 lemma L7.)  The score pass only has to deliver, per query, the maximum and the FIRST sub-chunk that reaches it.  Sweep with
       // the FLOAT engine's packed float16 cell (kSemF16: max(0, NW + s, W - G, N - G) on the integer scores M, -X, G,
       // whose clamped add saturates the diagonal term at 2048 instead of 255) and clamp what is published at 255: left of
       // the first cell that reaches 255 neither rule has saturated, so both recurrences agree there and that cell holds
@@ -242,7 +247,7 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
                       (!opt().u8_sample_short || 0.3 * (double)t.smax * (double)b.maxlen + 3.0 * (double)t.gap < 230.0);
         }
         else if (twin16_ok && !b.strips && b.SL != 64) {
-          b.sem = kSemF16; b.unsat = true; b.twin = true; b.SL = 16; b.R = pick_R(b.maxlen); b.comb = comb_ok(ref.ncodes, b.R);
+          b.sem = kSemF16; b.unsat = true; b.twin = true; twin_shape(ref, b);
         }
         // a lone LONG query (whole-wavefront tiles): the float engine's float32 cell (three ops per cell, one query per
         // register; exact below 2^24), unsaturated and clamped at 255 the same way, sweeps it faster than two tiles per packed
@@ -264,10 +269,10 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       if (fits && !t.htab.empty() && !b.strips && b.count >= 2 &&
           (int64_t)t.smax * b.maxlen + t.smax <= 2040 && !opt().no_f16) {
         b.sem = kSemF16;
-        // the running maximum every 4th step, the sub-chunks within 3 gaps of the key re-evaluated exactly (sw_score_kernel MK)
+        // the running maximum every 4th step, the sub-chunks within 3 gaps of the key re-evaluated exactly (sw_score_kernel MK; lemma L5)
         b.sampled = allow_sample && sampled_instance(b.SL, b.R) && !opt().no_sample;
       }
-      // Beyond float16's exact range (reads above 680 bp at match 3) the packed int16 cell costs 4.5 ops.  The float16
+      // (Lemma L6.)  Beyond float16's exact range (reads above 680 bp at match 3) the packed int16 cell costs 4.5 ops.  The float16
       // cell still sweeps them when its clamp is allowed to SATURATE the values at 2048: if the true maximum M is below
       // 2048 nothing saturated and the sweep is exact; if not, the first cell holding M has 2048 in the sweep (every
       // suffix of its best path has a positive sum — else an earlier cell would hold M too — so a walk capped at 2048
@@ -287,7 +292,7 @@ std::vector<Bucket> make_buckets(const RefData &ref, const QueryBatch &q, const 
       // ... except a short one with small scores: two of its TILES per packed float16 register on 16-lane tiles
       if (b.count == 1 && b.sem == kSemI16 && twin16_ok && !t.htab.empty() && !b.strips && b.SL != 64 &&
           (int64_t)t.smax * b.maxlen + t.smax <= 2040 && !opt().no_f16) {
-        b.sem = kSemF16; b.twin = true; b.SL = 16; b.R = pick_R(b.maxlen); b.comb = comb_ok(ref.ncodes, b.R);
+        b.sem = kSemF16; b.twin = true; twin_shape(ref, b);
       }
       else if (b.count == 1 && b.sem == kSemI16 && twin_ok && opt().long_twin) b.twin = true;   // A/B switch
       else if (b.count == 1 && b.sem == kSemI16 && (double)t.smax * b.maxlen < 1.6e7) b.sem = kSemF32;
@@ -518,6 +523,9 @@ int64_t score_sub_len(int semantics, const Bucket &b) {
   if (semantics == MI355_SW_F32 && b.count == 1 && !b.strips && b.SL != 64) return kSeg;
   int64_t s = 256;
   while (s < b.maxlen) s *= 2;
+  // uint8 engine: strictly more than |x| + 64 columns, so that the first 255 in skewed order lies in the first sub-chunk that truly
+  // holds one or its right neighbour (what settles a sampled query whose key sits at the cap)
+  if (semantics == MI355_SW_U8SAT) while (s <= (int64_t)b.maxlen + 64) s *= 2;
   return s;
 }
 
@@ -538,7 +546,8 @@ int64_t pick_chunk_len(int64_t max_range_len, size_t npairs, int64_t warm, int S
   // mostly idle, so tiles shrink until every CU has a workgroup (down to one sub-chunk: >= 256 columns, >= |x|)
   int64_t floor_cl = 256;
   while (floor_cl < maxlen) floor_cl *= 2;
-  if (sub_len > 0 && sub_len < floor_cl) floor_cl = std::max<int64_t>(128, sub_len);   // finer sub-chunks allow shorter tiles (measured:
+  if (sub_len > floor_cl) floor_cl = sub_len;                                          // (a tile is at least one sub-chunk: the uint8 engine's is > |x| + 64)
+  else if (sub_len > 0 && sub_len < floor_cl) floor_cl = std::max<int64_t>(128, sub_len);   // finer sub-chunks allow shorter tiles (measured:
                                                                                        // 0.30 ms per 150 bp x 1 Mbp call at 128 columns, 0.33 at 256)
   const double per_wg = 256.0 / SL * (twin ? 2.0 : 1.0);
   while (cl / 2 >= floor_cl && (double)npairs * (double)((max_range_len + cl - 1) / cl) / per_wg < cus) cl /= 2;
@@ -722,7 +731,7 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   a.range_hi = ctx->ranges.as<int64_t>() + nr;
   a.chunk_len = chunk; a.sub_len = sub_len;
   a.warm = (cpr == 1) ? 0 : b.warm;              // a single tile per range starts at the range's own border
-  // Optimistic warm-up margin.  The full margin m + ceil(smax m / g) makes EVERY cell exact; a cell of value v is already
+  // Optimistic warm-up margin (DESIGN.md §3.3 lemma L11, from L3).  The full margin m + ceil(smax m / g) makes EVERY cell exact; a cell of value v is already
   // exact behind m + ceil((smax m - v) / g) + 2 columns (a path that reaches v within m diagonal steps affords that many gap
   // columns).  The sweep therefore starts with the margin that is enough for maxima above 11/12 of the best possible score —
   // what a read with a real hit has — and reports the value above which it was exact (long_cert); the callers check their
@@ -783,11 +792,14 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     if (col_bytes + row_bytes <= ((size_t)64 << 30) && !ctx->colsave.ensure(col_bytes + 64) && !ctx->rowsave.ensure(row_bytes + 64)) {
       a.colsave = ctx->colsave.as<float>();
       a.rowsave = b.nstrips > 1 ? ctx->rowsave.as<float>() : nullptr;
+      const long what = opt().long_save_what;                           // tuning aid (timing only: the finish needs both): 1 columns, 2 rows
+      if (what == 1) a.rowsave = nullptr;
+      if (what == 2) a.colsave = nullptr;
       LongSaved &ls = ctx->lsaved;
       ls.ref = &ref; ls.batch = &q; ls.ref_version = ref.version; ls.batch_version = q.version; ls.params = p; ls.qid = qid;
       ls.ranges = ranges; ls.chunk = chunk; ls.sub_len = sub_len; ls.warm = a.warm; ls.nstrips = b.nstrips; ls.R = b.R; ls.spt = subs_per_tile;
       ls.tiles_stride = a.tiles_stride; ls.col_subs = nsub; ls.col_rows = a.col_rows; ls.row_stride = a.row_stride; ls.fshift = ctx->fshift;
-      ls.valid = true;                                                  // (the launch below fills the buffers; every call ends synchronised)
+      ls.valid = what != 1 && what != 2;                                // (the launch below fills the buffers; every call ends synchronised)
     }
   }
   const size_t shmem = long_lds_bytes(ref.ncodes, spg, pipes, b.R, subs_per_tile, p32);

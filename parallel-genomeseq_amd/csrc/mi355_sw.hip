@@ -480,6 +480,7 @@ int mi355_sw_last_counter(const mi355_sw_ctx *ctx, const char *name, uint64_t *o
   else if (k == "left_window") *out = ctx->left_window;
   else if (k == "first_settled") *out = ctx->first_settled;
   else if (k == "wait_retries") *out = ctx->wait_retries;
+  else if (k == "early_settled") *out = ctx->early_settled;
   else if (k == "saved_locates") *out = ctx->saved_locates;
   else if (k == "saved_traces") *out = ctx->saved_traces;
   else if (k == "saved_fallbacks") *out = ctx->saved_fallbacks;

@@ -264,13 +264,14 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
       curc = nextc;
       nextc = stage_load(seg + 2);
       uint32_t oseg = 0u;
-      // The saved copy of the PREVIOUS segment's bottom row goes out here, at the start of the steps: the waits above (flat
-      // atomic loads) and the release operations at the segment's end wait for every memory operation of the wavefront that
-      // is still in flight — vmcnt counts in order — and a store issued right in front of them cost the sweep a third
-      // (202 -> 268 ms on 10 kbp x 250 Mbp: one store round trip per segment); from here it has 64 steps to complete.
+      // The saved copy of the PREVIOUS segment's bottom row goes out here, at the start of the steps (the waits above and the
+      // release operations at the segment's end wait for every memory operation of the wavefront still in flight), and as a
+      // WRITE-THROUGH store (system scope: sc0 sc1): the chip has one L2 per XCD, so every agent-scope release between the
+      // workgroups of a tile writes the L2's dirty lines back (buffer_wbl2) — with 12 GB of saved state passing through as
+      // ordinary stores those write-backs cost the sweep a third (202 -> 268 ms on 10 kbp x 250 Mbp).
       if (rsave != nullptr && seg > 0) {
         const int64_t t = (int64_t)(seg - 1) * 64 + l - 63;
-        if (t >= 0) rsave[t] = __uint_as_float(oprev);
+        if (t >= 0) __hip_atomic_store(rsave + t, __uint_as_float(oprev), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
       // the segment in front of own sub-chunk bdone / segs_per_sub: lane l stands at the column to save at step l
       const int bdone = seg + 1 - warm_segs;
@@ -339,9 +340,13 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
         if (save_seg) {                                                    // (uniform: a scalar branch in all other segments —
           asm volatile("" ::: "memory");                                   //  kept apart from the per-lane test below)
           if (k == l) {                                                    // this lane stands at stream position seg * 64
-            float *csave = a.colsave + csave_at + (size_t)l * R;
-#pragma unroll
-            for (int r = 0; r < R; r += 4) *reinterpret_cast<float4 *>(csave + r) = make_float4(H[r], H[r + 1], H[r + 2], H[r + 3]);
+            float *csave = a.colsave + csave_at + (size_t)l * R;             // (write-through stores, see the row save above:
+#pragma unroll                                                             //  16 bytes each — as single dwords they cost 2.6 % of the sweep)
+            for (int r = 0; r < R; r += 4) {
+              typedef float f32x4 __attribute__((ext_vector_type(4)));
+              const f32x4 v = {H[r], H[r + 1], H[r + 2], H[r + 3]};
+              asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(csave + r), "v"(v) : "memory");
+            }
           }
         }
       }
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(64 * long_max_waves(R)) void sw_long_kernel(const L
     }
     if (ok && rsave != nullptr && nseg > 0) {                              // the last segment's bottom row
       const int64_t t = (int64_t)(nseg - 1) * 64 + l - 63;
-      if (t >= 0) rsave[t] = __uint_as_float(oprev);
+      if (t >= 0) __hip_atomic_store(rsave + t, __uint_as_float(oprev), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (ok) fold_sub(a.subs_per_tile - 1);                                 // the tile's last (or only) sub-chunk
     // whatever happened, the workgroup below must not wait for this one any more

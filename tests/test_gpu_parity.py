@@ -901,15 +901,22 @@ def test_u8_unsaturated_sweep_edges(ctx, oracle, pgs):
         degraded[i] = ord("ACGT"[("ACGT".index(chr(degraded[i])) + 1) % 4])
     reads += [long_read, bytes(degraded), pgs.synth.dna(92, 150).tobytes()]
     refb = bytes(refb)
-    for sc in (dict(), dict(match=5.0, mismatch=-4.0, gap=3.0), dict(match=2.0, mismatch=0.0, gap=1.0),
-               dict(match=255.0, mismatch=-255.0, gap=200.0), dict(match=7.9, mismatch=-1.2, gap=1.99)):
-        exp = _pmap(lambda q: oracle.align(q, refb, 1, **sc), reads)
-        got = ctx.align_batch(reads, refb, semantics=1, **sc)
-        for k, (g, e) in enumerate(zip(got, exp)):
-            _cmp(g, e, ("u8 batch", sc, k))
-        for k in (0, 1, 2, 7, 8):
-            _cmp(ctx.align(reads[k], refb, 1, **sc), exp[k], ("u8 lone", sc, k))
-    assert "unsaturated" in ctx.last_kernel()["name"]
+    for early in (False, True):
+        # (the SWEEP is what this test is about: once with the early exit of DESIGN.md L8a switched off, once as the library runs)
+        ctx.set_option("no_u8_early", None if early else True)
+        try:
+            for sc in (dict(), dict(match=5.0, mismatch=-4.0, gap=3.0), dict(match=2.0, mismatch=0.0, gap=1.0),
+                       dict(match=255.0, mismatch=-255.0, gap=200.0), dict(match=7.9, mismatch=-1.2, gap=1.99)):
+                exp = _pmap(lambda q: oracle.align(q, refb, 1, **sc), reads)
+                got = ctx.align_batch(reads, refb, semantics=1, **sc)
+                for k, (g, e) in enumerate(zip(got, exp)):
+                    _cmp(g, e, ("u8 batch", sc, k, early))
+                for k in (0, 1, 2, 7, 8):
+                    _cmp(ctx.align(reads[k], refb, 1, **sc), exp[k], ("u8 lone", sc, k, early))
+            if not early:
+                assert "unsaturated" in ctx.last_kernel()["name"]
+        finally:
+            ctx.set_option("no_u8_early", None)
 
 
 def test_split_calls_on_the_single_alignment_chain(ctx, oracle, pgs):

@@ -30,7 +30,8 @@ ENGAGE = {
     "no_f16": ("batch150_f32", "", r"score\[cell=i16", r"score\[cell=f16"),
     "no_unsat": ("batch150_u8", "", r"score\[cell=u8f16[^\]]*unsat=0", r"score\[cell=f16[^\]]*unsat=1"),
     "no_sample": ("batch150_f32", "", r"score\[[^\]]*sampled=0", r"score\[[^\]]*sampled=1"),
-    "u8_sample_short": ("batch1000_u8", "", r"score\[[^\]]*sampled=0", r"score\[[^\]]*sampled=1"),
+    "u8_sample_short": ("batch1000_u8", "no_u8_early", r"score\[[^\]]*sampled=0", r"score\[[^\]]*sampled=1"),
+    "no_u8_early": ("batch1000_u8", "", r"score\[", r"^(?!.*score\[).*u8_early"),
     "no_satflag": ("batch1000_f32", "", r"score\[cell=i16[^\]]*satflag=0", r"score\[cell=f16[^\]]*satflag=1"),
     "no_solo": ("single150_f32", "", r"strip\[|wave\[", r"solo\["),
     "no_wave": ("uniprot_shape", "", r"^exact\[[^ ]*$", r"wave\["),
@@ -41,7 +42,7 @@ ENGAGE = {
     "no_quant": ("single400_long_ref", "", r"score\[[^\]]*pow2=1", r"score\[[^\]]*pow2=0"),
     "no_devlist": ("uniprot_shape", "", r"^(?!.*devlist)", r"devlist\["),
     "no_strip_groups": ("single1000_f32", "", r"mode=dirs,grouped=0", r"mode=dirs,grouped=1"),
-    "u8_long_twin": ("single1000_u8", "", r"score\[cell=f16[^\]]*twin=1", r"score\[cell=f32[^\]]*twin=0"),
+    "u8_long_twin": ("single1000_u8", "no_u8_early", r"score\[cell=f16[^\]]*twin=1", r"score\[cell=f32[^\]]*twin=0"),
     "long_twin": ("single1000_f32", "", r"score\[cell=i16[^\]]*twin=1", r"score\[cell=f32[^\]]*twin=0"),
     "no_long": ("single3000_f32", "", r"score\[cell=f32[^\]]*strips=1", r"long\["),
     "strip_r=24": ("single5000_f32", "no_long", r"score\[[^\]]*R=24,strips=1", r"score\[[^\]]*R=20,strips=1"),
@@ -119,16 +120,16 @@ def test_assumed_cu_count_resizes_the_launches(pgs, oracle):
     c = pgs.Context(0)
     try:
         _cmp(c.align(qs[0], ref, sem), exp, "default sizing")
-        k_default = c.last_kernel()
         c.set_option("assume_cus", 32)
         _cmp(c.align(qs[0], ref, sem), exp, "assume_cus=32")
-        k_small = c.last_kernel()
-        assert k_small["chunk_len"] > k_default["chunk_len"], (k_default["chunk_len"], k_small["chunk_len"])   # fewer, longer tiles
         c.set_option("assume_cus", None)
         kind, qs, ref, sem = build(pgs, "batch150_f32")
         a = c.align_batch(qs, ref, semantics=sem)
+        k_default = c.last_kernel()
         c.set_option("assume_cus", 8)
         b = c.align_batch(qs, ref, semantics=sem)
+        k_small = c.last_kernel()
+        assert k_small["chunk_len"] > k_default["chunk_len"], (k_default["chunk_len"], k_small["chunk_len"])   # fewer, longer tiles
         for k, (x, y) in enumerate(zip(a, b)):
             _cmp(y, x, "assume_cus=8, read %d" % k)
     finally:

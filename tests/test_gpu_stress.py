@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
-BUDGET_S = float(os.environ.get("MI355_SW_STRESS_SECONDS", "38"))
+BUDGET_S = float(os.environ.get("MI355_SW_STRESS_SECONDS", "32"))
 
 
 @pytest.mark.parametrize("seed", [2026, 777, 424242])

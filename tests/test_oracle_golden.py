@@ -187,3 +187,29 @@ def test_stress_fixture_is_what_its_script_makes(tmp_path):
     q = kept["qs"].tobytes()[offs[6]:offs[7]]
     r = ob.align(q, kept["ref"].tobytes(), 0, *[float(v) for v in kept["sc"]])
     assert (len(q), r["score"], r["pos"], r["end_y"]) == (2300, 10362.0, 11966, 17929), r
+
+
+def test_fullsize_fixture_is_complete_and_pins_the_oracle(pgs):
+    """tests/golden/fullsize.json (made by the REAL reference at 150 bp x 50 Mbp and over all 561 356 UniProt-shaped alignments,
+    tests/golden/make_fullsize_golden.py) holds what tests/test_gpu_fullsize.py needs, and the C restatement agrees with it at
+    full size: the lean rolling-column locate + the window traceback of one float-engine and one uint8-engine alignment give
+    the reference's score, argmax cell, pos and consensus strings."""
+    import json
+    import os
+    from oracle import binding as ob
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize.json")
+    fix = json.load(open(path))
+    c3, c4 = fix["config3"], fix["config4"]
+    assert len(c3["f32_plain"]) + len(c3["f32_repeats"]) >= 16 and len(c3["u8_plain"]) + len(c3["u8_repeats"]) >= 64
+    assert len(c3["repeat_reads"]) >= 8 and c4["sequences"] == 561356 and len(c4["sha256"]) == 64
+    ref = pgs.synth.dna(c3["plain"]["seed"], c3["ref_len"])
+    reads, _ = pgs.synth.reads_from_ref(ref, c3["read_seed"], 3, c3["read_len"])
+    assert [r.tobytes().decode() for r in reads] == c3["plain_reads"][:3]          # the fixture's reads are what the seeds make
+    refb = ref.tobytes()
+    for sem, key in ((ob.F32, "f32_plain"), (ob.U8SAT, "u8_plain")):
+        q, e = c3["plain_reads"][2].encode(), c3[key][2]
+        mx, ix, iy = ob.locate(q, refb, sem)
+        assert (mx, ix, iy) == (e["score"], e["end_x"], e["end_y"]), (key, mx, ix, iy, e["score"], e["end_x"], e["end_y"])
+        lo = max(0, iy - 20_000)
+        w = ob.trace_from(q, refb[lo:iy], sem, ix, iy - lo)
+        assert (w["cons_x"], w["cons_y"], w["pos"] + lo) == (e["cons_x"], e["cons_y"], e["pos"]), key
