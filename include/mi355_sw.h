@@ -213,7 +213,9 @@ int mi355_sw_last_counters(const mi355_sw_ctx *ctx, uint64_t out[4]);
  * "first_settled" — uint8 engine: queries over their candidate cap whose first candidates, evaluated in order, settled them
  * without a second sweep; "saved_locates" / "saved_traces" — finish steps of a lone long query that started from the columns and
  * strip rows its sweep saved, "saved_fallbacks" — those that took the zero-border windows instead; "wait_retries" — launches
- * repeated on a non-waiting instance after a wait between workgroups expired.  MI355_SW_EINVAL for an unknown name. */
+ * repeated on a non-waiting instance after a wait between workgroups expired; "early_settled" — uint8 engine: queries settled
+ * from the first and last sub-chunks without a sweep; "beyond_f16" — sequences of a many-small-alignments batch whose maximum lay
+ * beyond the packed float16 pass's key range and were redone on float32 cells.  MI355_SW_EINVAL for an unknown name. */
 int mi355_sw_last_counter(const mi355_sw_ctx *ctx, const char *name, uint64_t *out);
 
 /* Which kernels and pipeline decisions the last call used: space-separated tags, each at most once, e.g.

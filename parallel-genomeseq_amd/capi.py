@@ -313,7 +313,7 @@ class Context:
         c = (C.c_uint64 * 4)()
         self._L.mi355_sw_last_counters(self._ctx, c)
         out = dict(requeried=int(c[0]), whole_batch_again=int(c[1]), candidates=int(c[2]), left_window=int(c[3]))
-        for name in ("first_settled", "saved_locates", "saved_traces", "saved_fallbacks", "wait_retries", "early_settled"):
+        for name in ("first_settled", "saved_locates", "saved_traces", "saved_fallbacks", "wait_retries", "early_settled", "beyond_f16"):
             v = C.c_uint64(0)
             rc = self._L.mi355_sw_last_counter(self._ctx, name.encode(), C.byref(v))
             if rc:

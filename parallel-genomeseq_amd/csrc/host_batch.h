@@ -37,7 +37,8 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   if (count == 0) return 0;
   const int64_t nref = rg.hi - rg.lo;
   const int maxna = orient == 0 ? q.len[q.order[first + count - 1]] : (int)nref;
-  const int R = wave_R(maxna);
+  int R = wave_R(maxna);
+  if (orient == 1 && wave_prof_ok(ref, p, wave_prof_R((int)nref), (int)nref, true)) R = wave_prof_R((int)nref);
   const int W = (R + 15) / 16;
   const int64_t stream_total = orient == 0 ? (int64_t)count * nref : q.cumlen[first + count] - q.cumlen[first];
   // lanes = columns of the shared second sequence: the profile kernel (three-op cell, first maximum per lane).  With traceback,
@@ -141,8 +142,17 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   const unsigned blocks = (unsigned)((n + 15) / 16), pblocks = (unsigned)((nprob + 15) / 16);
   const WaveProblem *dp = ctx->wprobs.as<WaveProblem>();
   const WaveProblem *dp_walk = dp;                                   // the problems the walks read their decisions from
+  // the first pass without decisions: two problems per slot on packed float16 cells where every value fits (sw_wave_kernel.h)
+  int64_t max_stream = 0;
+  for (size_t e = 0; e < npieces; ++e) max_stream = std::max<int64_t>(max_stream, pc_rows[e]);
+  if (nprob > npieces) max_stream = std::max<int64_t>(max_stream, q.len[q.order[first + count - 1 - (size_t)nlong]]);
+  int f16 = 0;
   if (windows) {
-    int rc = launch_wave_prof(ctx, ref, p, R, (int)nref, true, false, pblocks, dp, (int)nprob);
+    int rc = launch_wave_prof16(ctx, ref, p, R, (int)nref, max_stream, dp, (int)nprob);
+    if (rc < 0) return rc;
+    f16 = rc == 0;
+    if (!f16) rc = launch_wave_prof(ctx, ref, p, R, (int)nref, true, false, pblocks, dp, (int)nprob);
+    else rc = 0;
     if (rc) return rc < 0 ? rc : fail(ctx, MI355_SW_ENODEV, "internal: the profile kernel refused a launch it had accepted");
     hipLaunchKernelGGL(batch_seq_results, dim3(sblocks), dim3(256), 0, ctx->stream, a);   // (always: it also names every sequence's problem)
     hipLaunchKernelGGL(batch_window_setup, dim3(sblocks), dim3(256), 0, ctx->stream, a);
@@ -150,7 +160,10 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     if (rc) return rc < 0 ? rc : fail(ctx, MI355_SW_ENODEV, "internal: the profile kernel refused a launch it had accepted");
     dp_walk = a.probs2;
   } else {
-    const int prof_rc = prof ? launch_wave_prof(ctx, ref, p, R, (int)nref, true, want_trace, pblocks, dp, (int)nprob) : 1;
+    int prof_rc = prof && !want_trace ? launch_wave_prof16(ctx, ref, p, R, (int)nref, max_stream, dp, (int)nprob) : 1;
+    if (prof_rc < 0) return prof_rc;
+    f16 = prof_rc == 0;
+    if (!f16) prof_rc = prof ? launch_wave_prof(ctx, ref, p, R, (int)nref, true, want_trace, pblocks, dp, (int)nprob) : 1;
     if (prof_rc < 0) return prof_rc;
     if (prof_rc == 0 && npieces) hipLaunchKernelGGL(batch_seq_results, dim3(sblocks), dim3(256), 0, ctx->stream, a);
 #define BATCH_WAVE(r)                                                                                                   \
@@ -161,7 +174,7 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
 #undef BATCH_WAVE
   }
   HIPCHK(ctx, hipGetLastError());
-  path_note(ctx, "devlist[orient=%d,R=%d,prof=%d,windows=%d,trace=%d,pieces=%d]", orient, R, (int)prof, (int)windows, (int)want_trace, (int)(npieces != 0));
+  path_note(ctx, "devlist[orient=%d,R=%d,prof=%d,f16=%d,windows=%d,trace=%d,pieces=%d]", orient, R, (int)prof, f16, (int)windows, (int)want_trace, (int)(npieces != 0));
 
   // results land in pinned staging: [best n x 4][cell n x 16][wout n x 24][offs (n + 1) x 8]
   const size_t o_best = 0, o_cell = (n * 4 + 15) & ~(size_t)15, o_wout = o_cell + n * 16, o_offs = o_wout + n * 24;
@@ -192,6 +205,7 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(h_offs, offs, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h_wout, wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->while_device_works) { ctx->while_device_works(); ctx->while_device_works = nullptr; }
     { HostTrace t_("  batch: passes + walk measure");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }            // the one mid-call round trip: how many bytes to expect
     const size_t ctot = (size_t)h_offs[n];
@@ -205,15 +219,17 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     ctx->cons_used++;
     cons_base = cons.as<char>();
   }
+  if (ctx->while_device_works) { ctx->while_device_works(); ctx->while_device_works = nullptr; }
   { HostTrace t_("  batch: to the last download");
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
   HostTrace t_results("  batch: results on the host");
   std::atomic<bool> bad{false};
-  std::atomic<size_t> left{0};
+  std::atomic<size_t> left{0}, beyond{0};
   parallel_for(n, [&](size_t k0, size_t k1) {
     for (size_t k = k0; k < k1; ++k) {
       const int id = q.order[batch_sorted_pos((int)first, (int)n, (int)k)];
       const bool hit = h_best[k] > 0;
+      if (h_best[k] < 0) { beyond.fetch_add(1, std::memory_order_relaxed); continue; }   // the float16 pass left it undecided (handled stays 0)
       if (want_trace && hit && h_wout[3 * k + 2] != 0) {
         // a walk that left its window: the problem goes to the host-driven path (handled stays 0); on whole problems: a bug
         if (!windows || h_wout[3 * k + 2] != 1) bad.store(true, std::memory_order_relaxed);
@@ -234,6 +250,7 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   });
   if (bad.load()) return fail(ctx, MI355_SW_ENODEV, "internal: a walk over a whole-problem window failed");
   ctx->left_window += left.load();
+  ctx->beyond_f16 += beyond.load();
   return 0;
 }
 

@@ -14,7 +14,7 @@ constexpr size_t kExactLdsMax = 159 * 1024;    // dynamic part; the wide instanc
 #define MI355_SW_BOOL_OPTIONS(X) \
   X(no_f16) X(no_unsat) X(no_sample) X(no_satflag) X(no_solo) X(no_wave) X(no_comb) X(no_twin) X(no_wide) X(no_strip) \
   X(no_quant) X(no_devlist) X(no_ref_cache) X(no_strip_groups) X(u8_long_twin) X(long_twin) X(no_long) \
-  X(no_requery) X(force_f32) X(no_long_p32) X(no_opt_margin) X(no_wave_prof) X(no_wave_window) X(no_first) X(no_long_save) X(u8_sample_short) X(no_wave_pieces) X(no_u8_early) X(trace)
+  X(no_requery) X(force_f32) X(no_long_p32) X(no_opt_margin) X(no_wave_prof) X(no_wave_window) X(no_first) X(no_long_save) X(u8_sample_short) X(no_wave_pieces) X(no_u8_early) X(no_wave_f16) X(trace)
 #define MI355_SW_INT_OPTIONS(X) X(strip_r) X(slot) X(few_r) X(chunk) X(long_pipes) X(long_wgs) X(long_sub) X(long_r) X(long_groups) X(assume_cus) X(long_save_what)
 struct Options {
 #define X(n) bool n = false;
@@ -303,6 +303,8 @@ struct mi355_sw_ctx {
   // 30 MB of fresh pages every time)
   std::vector<Located> loc_store;
   std::vector<TraceOut> tout_store;
+  std::function<void()> while_device_works;   // host work of the running call that does not depend on the launches in flight: run in front of the next wait
+  size_t beyond_f16 = 0;          // sequences of the running call whose maximum was beyond the packed float16 pass's key range (host_batch.h)
   size_t left_window = 0;         // walks of the running call that left their decision window (host_batch.h) and were redone whole
   size_t requeried = 0;           // queries of the running call that were swept a second time on the exact instances
   size_t whole_again = 0;         // ... times the whole batch was (most of it exceeded its candidate cap)

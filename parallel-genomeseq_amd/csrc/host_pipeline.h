@@ -512,13 +512,25 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
   const int64_t n = rg.hi - rg.lo;
   HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
   // (half a million small alignments per call: the per-query host arrays are sized only where a path reads them)
-  { HostTrace t_("  per-query arrays");
   loc.resize(nq);
   tout.resize(want_trace ? nq : 0);
-  parallel_for(nq, [&](size_t k0, size_t k1) {
-    std::fill(loc.begin() + k0, loc.begin() + k1, Located());
-    if (want_trace) std::fill(tout.begin() + k0, tout.begin() + k1, TraceOut());
-  }); }
+  auto fill_defaults = [&loc, &tout, nq, want_trace]() {
+    HostTrace t_("  per-query arrays");
+    parallel_for(nq, [&](size_t k0, size_t k1) {
+      std::fill(loc.begin() + k0, loc.begin() + k1, Located());
+      if (want_trace) std::fill(tout.begin() + k0, tout.begin() + k1, TraceOut());
+    });
+  };
+  // The many-small-alignments batch (below: nothing takes the score kernel) touches these arrays only once its results are down:
+  // the defaults are then written while the device works (exact_full_device runs ctx->while_device_works in front of its first
+  // wait) — 31 MB of host stores for config 4's 561 356 alignments
+  const bool devlist_first = !pre && n < 1024 && p.semantics == MI355_SW_F32 && wave_scoring_ok(p) && !opt().no_wave && !opt().no_devlist;
+  if (devlist_first) ctx->while_device_works = fill_defaults;
+  else fill_defaults();
+  struct RunPending {                                              // (every exit: the deferred work is done or dropped, never left behind)
+    mi355_sw_ctx *c;
+    ~RunPending() { c->while_device_works = nullptr; }
+  } run_pending_{ctx};
   // No score can be positive (uint8 engine whose match score saturates to 0; float engine whose best substitution
   // score is <= 0 with a positive gap): every cell of the matrix is 0 and the defined no-match result stands.
   bool all_zero = false;
@@ -851,6 +863,7 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
       ctx->timings[2] += elapsed_us(ctx, ctx->ev[2], ctx->ev[3]);
     }
+    if (ctx->while_device_works) { ctx->while_device_works(); ctx->while_device_works = nullptr; }   // (no launch took it)
     std::vector<int> slow;
     for (size_t k = 0; k < nq; ++k) if (!qfast[k] && !handled[k]) slow.push_back((int)k);
     // Problems the score kernel does not take (no finite warm-up margin: a gap penalty that is, or truncates to, 0 ...) and whose
@@ -1134,7 +1147,7 @@ void reset_timings(mi355_sw_ctx *ctx) {
   for (double &t : ctx->timings) t = 0;
   ctx->score_ev_used = 0; ctx->arenas.clear(); ctx->cons_used = 0;
   ctx->last_kernel = mi355_sw_kernel_info{};
-  ctx->requeried = 0; ctx->whole_again = 0; ctx->candidates = 0; ctx->left_window = 0; ctx->first_settled = 0;
+  ctx->requeried = 0; ctx->whole_again = 0; ctx->candidates = 0; ctx->left_window = 0; ctx->beyond_f16 = 0; ctx->first_settled = 0;
   ctx->saved_locates = 0; ctx->saved_traces = 0; ctx->saved_fallbacks = 0; ctx->wait_retries = 0; ctx->early_settled = 0;
   ctx->path.clear();
 }

@@ -15,6 +15,9 @@ bool wave_scoring_ok(const mi355_sw_params &p) {
 
 // rows per lane of the wave kernel instance that covers `na` cells on the lane side, and its decision bytes
 int wave_R(int na) { return na <= 160 ? 10 : (na <= 320 ? 20 : 32); }
+// ... of the profile kernels (lanes = columns of the shared second sequence): nine where they cover it — |y| = 144 = 16 x 9 is the
+// UniProt driver's query P02232 — and no column is padding
+int wave_prof_R(int na) { return na <= 144 ? 9 : wave_R(na); }
 size_t wave_dirs_bytes(int64_t nb, int R) { return (size_t)(nb + 16) * 16 * (size_t)((R + 15) / 16) * 4; }   // (+ the skew's rows)
 
 struct WaveJob {
@@ -71,10 +74,8 @@ bool wave_prof_ok(const RefData &ref, const mi355_sw_params &p, int R, int na, b
   return true;
 }
 
-int launch_wave_prof(mi355_sw_ctx *ctx, const RefData &ref, const mi355_sw_params &p, int R, int na, bool track, bool dirs,
-                     unsigned blocks, const WaveProblem *dp, int n) {
-  if (!wave_prof_ok(ref, p, R, na, track)) return 1;
-  const size_t lds = (size_t)ref.ncodes * 16 * lane_stride(R) * 4;
+// byte -> code and code -> byte tables of the resident reference, for the profile kernels
+int wave_tables(mi355_sw_ctx *ctx, const RefData &ref) {
   if (ctx->wlut_ref != (const void *)&ref || ctx->wlut_version != ref.version) {
     ctx->h_wlut.assign(512, 0);
     for (int b = 0; b < 256; ++b) ctx->h_wlut[b] = (uint8_t)(ref.code_of[b] >= 0 ? ref.code_of[b] : ref.ncodes - 1);
@@ -84,6 +85,14 @@ int launch_wave_prof(mi355_sw_ctx *ctx, const RefData &ref, const mi355_sw_param
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                // (the staging vector may change with the next reference)
     ctx->wlut_ref = (const void *)&ref; ctx->wlut_version = ref.version;
   }
+  return 0;
+}
+
+int launch_wave_prof(mi355_sw_ctx *ctx, const RefData &ref, const mi355_sw_params &p, int R, int na, bool track, bool dirs,
+                     unsigned blocks, const WaveProblem *dp, int n) {
+  if (!wave_prof_ok(ref, p, R, na, track)) return 1;
+  const size_t lds = (size_t)ref.ncodes * 16 * lane_stride(R) * 4;
+  { int rc_t = wave_tables(ctx, ref); if (rc_t) return rc_t; }
   WaveProfArgs sa;
   sa.lut = ctx->wlut.as<uint8_t>();
   sa.byte_of = ctx->wlut.as<uint8_t>() + 256;
@@ -103,8 +112,52 @@ int launch_wave_prof(mi355_sw_ctx *ctx, const RefData &ref, const mi355_sw_param
     else if (track) hipLaunchKernelGGL((sw_wave_prof_kernel<r, true, false>), dim3(blocks), dim3(256), lds, ctx->stream, dp, n, sa);   \
     else hipLaunchKernelGGL((sw_wave_prof_kernel<r, false, true>), dim3(blocks), dim3(256), lds, ctx->stream, dp, n, sa);              \
   }
-  if (R == 10) WAVE_PROF(10) else if (R == 20) WAVE_PROF(20) else WAVE_PROF(32)
+  if (R == 9) WAVE_PROF(9) else if (R == 10) WAVE_PROF(10) else if (R == 20) WAVE_PROF(20) else WAVE_PROF(32)
 #undef WAVE_PROF
+  return 0;
+}
+
+// sw_wave_prof16_kernel (two problems per slot on packed float16 cells) for the TRACK pass of a device-built batch: returns 1 when
+// it does not apply (the caller launches the float32 kernel), 0 when launched, < 0 on error.  DESIGN.md §3.3 lemma L13: every
+// score is a multiple of q = 2^e and smaller than 2048 q in magnitude, match * (|y| + 1) < 2048 q (every cell value is then an
+// integer multiple of q below 2048 q: exact in float16), ten columns per lane (the key's four bits), streams of at most 65 000
+// rows (16-bit step counters).  A sequence whose maximum reaches 128 q comes back with best = -1: the caller leaves it to the
+// float32 path.
+int launch_wave_prof16(mi355_sw_ctx *ctx, const RefData &ref, const mi355_sw_params &p, int R, int na, int64_t max_stream,
+                       const WaveProblem *dp, int n) {
+  if (opt().no_wave_f16 || (R != 9 && R != 10) || max_stream > 65000 || !wave_prof_ok(ref, p, R, na, true)) return 1;
+  float q = 0.0f;
+  int e = 10;
+  for (; e >= -10 && q == 0.0f; --e) {
+    const float c = std::ldexp(1.0f, e);
+    if (std::floor(p.match / c) == p.match / c && std::floor(p.mismatch / c) == p.mismatch / c && std::floor(p.gap / c) == p.gap / c) { q = c; break; }
+  }
+  if (q == 0.0f) return 1;
+  const double lim = 2048.0 * (double)q;
+  if ((double)p.match * ((double)na + 1.0) >= lim || std::fabs((double)p.mismatch) >= lim || (double)p.gap >= lim || !(p.gap > 0.0f)) return 1;
+  const size_t lds = 2 * (size_t)ref.ncodes * 16 * lane_stride(R) * 4;
+  if (lds > 60 * 1024) return 1;
+  int rc = wave_tables(ctx, ref);
+  if (rc) return rc;
+  WaveProf16Args sa;
+  sa.lut = ctx->wlut.as<uint8_t>();
+  sa.byte_of = ctx->wlut.as<uint8_t>() + 256;
+  sa.ncodes = ref.ncodes;
+  const float unit = std::ldexp(q, 11);                              // cells hold H / (q 2048)
+  sa.match_h = half_bits(p.match / unit); sa.mismatch_h = half_bits(p.mismatch / unit);
+  sa.ngap2 = (uint32_t)half_bits(-p.gap / unit) * 0x00010001u;
+  sa.unscale = unit;
+  const int k = std::max(1, std::min(100, std::ilogb((double)p.match * ((double)na + 1.0) + 1.0) + 2));   // (as launch_wave_prof)
+  sa.ck_scale = std::ldexp(unit, -k);
+  const unsigned blocks = (unsigned)((n + 31) / 32);
+#define WAVE_PROF16(r)                                                                                                               \
+  {                                                                                                                                   \
+    if (lds > 48 * 1024)                                                                                                              \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_wave_prof16_kernel<r>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((sw_wave_prof16_kernel<r>), dim3(blocks), dim3(256), lds, ctx->stream, dp, n, sa);                             \
+  }
+  if (R == 9) WAVE_PROF16(9) else WAVE_PROF16(10)
+#undef WAVE_PROF16
   return 0;
 }
 

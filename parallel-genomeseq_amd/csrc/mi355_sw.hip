@@ -478,6 +478,7 @@ int mi355_sw_last_counter(const mi355_sw_ctx *ctx, const char *name, uint64_t *o
   else if (k == "whole_batch_again") *out = ctx->whole_again;
   else if (k == "candidates") *out = ctx->candidates;
   else if (k == "left_window") *out = ctx->left_window;
+  else if (k == "beyond_f16") *out = ctx->beyond_f16;
   else if (k == "first_settled") *out = ctx->first_settled;
   else if (k == "wait_retries") *out = ctx->wait_retries;
   else if (k == "early_settled") *out = ctx->early_settled;

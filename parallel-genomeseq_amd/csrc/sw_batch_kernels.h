@@ -123,11 +123,14 @@ __global__ void batch_seq_results(const BatchWaveArgs a) {
   float bv = 0.0f;
   int64_t bi = 0, bj = 0;
   const int e0 = a.pc_first[k], e1 = a.pc_first[k + 1];
+  bool undecided = false;                                          // a piece the float16 pass left undecided (best = -1): so is the sequence
   for (int e = e0; e < e1; ++e) {
     const float v = a.best[e];
+    undecided |= v < 0.0f;
     const int64_t i = a.cell[2 * (size_t)e], j = a.cell[2 * (size_t)e + 1];
     if (v > bv || (v == bv && v > 0.0f && (j < bj || (j == bj && i < bi)))) { bv = v; bi = i; bj = j; }
   }
+  if (undecided) bv = -1.0f;
   a.sbest[k] = bv;
   a.scell[2 * (size_t)k] = bv > 0.0f ? bi : 0;
   a.scell[2 * (size_t)k + 1] = bv > 0.0f ? bj : 0;

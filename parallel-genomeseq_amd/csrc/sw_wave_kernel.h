@@ -318,6 +318,7 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
   steps = max(steps, __shfl_xor(steps, 16));
   steps = max(steps, __shfl_xor(steps, 32));
   const int nseg = (steps + kWaveSeg - 1) / kWaveSeg;
+  const int steps4 = (steps + 3) & ~3;                             // the last segment stops at the wavefront's last step (in fours)
 
   uint32_t nextc = stage_load(0);
   {
@@ -347,8 +348,11 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
   const float *prof_lane = prof + l * LS;
 
   for (int seg = 0; seg < nseg; ++seg) {
-#pragma unroll 4
-    for (int k = 0; k < kWaveSeg; ++k) {
+    const int kq = min(kWaveSeg, steps4 - seg * kWaveSeg) >> 2;
+    for (int k4 = 0; k4 < kq; ++k4) {
+#pragma unroll
+    for (int ku = 0; ku < 4; ++ku) {
+      const int k = 4 * k4 + ku;
       const int t = k0 + seg * kWaveSeg + k - l;                   // this lane's stream position
       const uint32_t c = (uint32_t)buf_lane[k];
       const u32x4 *pp = static_cast<const u32x4 *>(__builtin_assume_aligned(prof_lane + c * (16 * LS), 16));
@@ -427,6 +431,7 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
         }
       }
     }
+    }
     if (TRACK && !DIRS) {
       // the slot's wavefront as it stands after step 64 (seg + 1) - 1: what a later launch needs to resume there
       if (P.ckpt != nullptr && (seg + 1) * kWaveSeg < nb + 16) {
@@ -459,6 +464,208 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
       *P.best = bv;
       P.cell[0] = bv > 0.0f ? bi : 0;
       P.cell[1] = bv > 0.0f ? bj : 0;
+    }
+  }
+}
+
+// sw_wave_prof16_kernel — the TRACK pass of sw_wave_prof_kernel on PACKED FLOAT16 cells: every register holds the same cell of
+// TWO database sequences (low half = problem 2s, high half = problem 2s + 1 of the launch; neighbours in a length-sorted
+// list), so a 16-lane slot runs two problems and a cell costs half the instructions.
+//   * cells hold H / (q 2048), q = the power of two all three scores are multiples of: every value below 2048 q is exact, and the
+//     host takes this kernel only when match * (|y| + 1) stays below that (DESIGN.md §3.3 lemma L13);
+//   * the two halves see different stream letters, so the profile exists twice in LDS: profLo[code][lane][r] = (score | 1.0 in
+//     the high half) and profHi[code][lane][r] = (1.0 | score in the high half).  ONE v_pk_fma_f16 with the clamp modifier,
+//     profLo[cA] * profHi[cB] + NW, is then (clamp(NW_A + score_A), clamp(NW_B + score_B)): no merge instruction, and the cell is
+//     fma, maximum3, add (H - g), or (the key), half a maximum3 (the lane's best key) = 4.5 ops for two cells;
+//   * the first maximum in storage order: key = cell bits | (15 - column within the lane) as in sw_wave_prof_kernel — the four
+//     lowest mantissa bits of a float16 are free while the value is below 128 q (cell < 2^-4).  A slot whose best key reaches
+//     2^-4 is NOT decided here: best = -1, and the host hands that sequence to the float32 path (a database of mostly unrelated
+//     sequences: a handful).  The row of the first sight of a lane's best key is kept for both halves as two 16-bit counts of
+//     the steps since (the host bounds the stream at 65 000 rows): max, sub, saturating sub, mad on packed integers per STEP.
+// Saved states (P.ckpt) are written in the float32 kernel's cell scale, so the decision windows resume from them unchanged.
+struct WaveProf16Args {
+  const uint8_t *lut;        // [256] byte -> code; ncodes - 1 = "other"
+  const uint8_t *byte_of;    // [ncodes - 1] code -> byte
+  int32_t ncodes;
+  uint32_t match_h, mismatch_h;   // float16 bits of score / (q 2048)
+  uint32_t ngap2;            // float16 bits of -gap / (q 2048) in both halves
+  float unscale;             // q * 2048
+  float ck_scale;            // float32 kernel's cell = this kernel's cell * ck_scale
+};
+constexpr uint32_t kProf16KeyLimit = 0x2C00u;                      // float16 2^-4 = 128 / 2048: keys below it are exact
+constexpr uint32_t kProf16One = 0x3C00u;                           // float16 1.0
+constexpr uint32_t kProf16Pad = 0xC800u;                           // float16 -8: padding columns clamp to 0
+
+template <int R>
+__global__ __launch_bounds__(256) void sw_wave_prof16_kernel(const WaveProblem *probs, int nprob, const WaveProf16Args sa) {
+  static_assert(R <= 16, "the key holds the column within the lane in four bits");
+  constexpr int LS = lane_stride(R);
+  constexpr int NQ4 = (R + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) uint32_t wsmem[];
+  __shared__ __attribute__((aligned(16))) uint8_t win[2 * 16 * kWaveBuf];
+  __shared__ uint8_t lut_s[256];
+  uint32_t *profLo = wsmem;                                        // [ncodes][16][LS]
+  uint32_t *profHi = wsmem + sa.ncodes * 16 * LS;
+  const int tid = threadIdx.x;
+  const int l = tid & 15;
+  const int slot = tid >> 4;
+  const int pidA = (blockIdx.x * 16 + slot) * 2, pidB = pidA + 1;
+  const bool activeA = pidA < nprob, activeB = pidB < nprob;
+  const uint8_t *bA = nullptr, *bB = nullptr;
+  int nbA = 0, nbB = 0;
+  if (activeA) { bA = probs[pidA].b; nbA = probs[pidA].nb; }
+  if (activeB) { bB = probs[pidB].b; nbB = probs[pidB].nb; }
+  // the lane side is the same for every problem of the launch (the range of the resident reference)
+  const uint8_t *ya = probs[0].a;
+  const int na = probs[0].na;
+  const uint32_t other = (uint32_t)(sa.ncodes - 1);
+  lut_s[tid] = sa.lut[tid];
+  for (int e = tid; e < sa.ncodes * 16 * R; e += 256) {
+    const int c = e / (16 * R);
+    const int rem = e - c * 16 * R;
+    const int ll = rem / R, r = rem - ll * R;
+    const int j = ll * R + r;
+    uint32_t v = kProf16Pad;
+    if (j < na) v = ((uint32_t)c < other && ya[j] == sa.byte_of[c]) ? sa.match_h : sa.mismatch_h;
+    profLo[(c * 16 + ll) * LS + r] = v | (kProf16One << 16);
+    profHi[(c * 16 + ll) * LS + r] = kProf16One | (v << 16);
+  }
+  __syncthreads();
+
+  // stream windows of CODES, one per half: 16 B history + 64 B segment, refilled every 64 steps
+  uint8_t *bufA = win + (2 * slot) * kWaveBuf, *bufB = bufA + kWaveBuf;
+  uint32_t *bufA32 = reinterpret_cast<uint32_t *>(bufA), *bufB32 = reinterpret_cast<uint32_t *>(bufB);
+  const uint8_t *bufA_lane = bufA + 16 - l, *bufB_lane = bufB + 16 - l;
+  auto stage_load = [&](const uint8_t *b, int nb, int seg) -> uint32_t {
+    const int c0 = seg * kWaveSeg + 4 * l;
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = c0 + k;
+      const uint32_t ch = (uint32_t)t < (uint32_t)nb ? (uint32_t)lut_s[b[t]] : other;     // outside the stream: matches nothing
+      w |= ch << (8 * k);
+    }
+    return w;
+  };
+  int steps = max(nbA, nbB) + 16;
+  steps = max(steps, __shfl_xor(steps, 16));
+  steps = max(steps, __shfl_xor(steps, 32));
+  const int nseg = (steps + kWaveSeg - 1) / kWaveSeg;
+  const int steps4 = (steps + 3) & ~3;
+
+  uint32_t nextA = stage_load(bA, nbA, 0), nextB = stage_load(bB, nbB, 0);
+  if (l < 4) { bufA32[l] = other * 0x01010101u; bufB32[l] = other * 0x01010101u; }
+  bufA32[4 + l] = nextA; bufB32[4 + l] = nextB;
+  nextA = stage_load(bA, nbA, 1); nextB = stage_load(bB, nbB, 1);
+
+  uint32_t gv = sa.ngap2;
+  asm volatile("" : "+v"(gv));
+  uint32_t one2 = 0x00010001u;
+  asm volatile("" : "+v"(one2));
+  uint32_t H[R], Hg[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { H[r] = 0u; Hg[r] = gv; }
+  uint32_t up_prev = 0;
+  uint32_t blk = 0;                                                // best key of this lane, both halves
+  uint32_t s2 = 0;                                                 // ... and the steps since it was first seen (16 bits each)
+  const uint32_t *profLo_lane = profLo + l * LS, *profHi_lane = profHi + l * LS;
+  float *ckA = activeA ? probs[pidA].ckpt : nullptr, *ckB = activeB ? probs[pidB].ckpt : nullptr;
+
+  for (int seg = 0; seg < nseg; ++seg) {
+    const int kq = min(kWaveSeg, steps4 - seg * kWaveSeg) >> 2;
+    for (int k4 = 0; k4 < kq; ++k4) {
+#pragma unroll
+    for (int ku = 0; ku < 4; ++ku) {
+      const int k = 4 * k4 + ku;
+      const uint32_t cA = (uint32_t)bufA_lane[k], cB = (uint32_t)bufB_lane[k];
+      const u32x4 *pa = static_cast<const u32x4 *>(__builtin_assume_aligned(profLo_lane + cA * (16 * LS), 16));
+      const u32x4 *pb = static_cast<const u32x4 *>(__builtin_assume_aligned(profHi_lane + cB * (16 * LS), 16));
+      uint32_t A[NQ4 * 4], B[NQ4 * 4];
+#pragma unroll
+      for (int q = 0; q < NQ4; ++q) {
+        const u32x4 v = pa[q];
+        A[4 * q + 0] = v.x; A[4 * q + 1] = v.y; A[4 * q + 2] = v.z; A[4 * q + 3] = v.w;
+        const u32x4 u = pb[q];
+        B[4 * q + 0] = u.x; B[4 * q + 1] = u.y; B[4 * q + 2] = u.z; B[4 * q + 3] = u.w;
+      }
+      const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H[R - 1], 0x111, 0xf, 0xf, true);
+      uint32_t diag = up_prev;
+      up_prev = up;
+      uint32_t ng;
+      asm("v_pk_add_f16 %0, %1, %2" : "=v"(ng) : "v"(up), "v"(gv));
+      uint32_t m = 0, tpend = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t w = H[r];
+        uint32_t x, h;
+        asm("v_pk_fma_f16 %0, %1, %2, %3 clamp" : "=v"(x) : "v"(A[r]), "v"(B[r]), "v"(diag));
+        asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(h) : "v"(x), "v"(Hg[r]), "v"(ng));
+        const uint32_t hk = h | ((uint32_t)(15 - r) * 0x00010001u);
+        if (r & 1) asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(tpend), "v"(hk));
+        else if (r + 1 < R) tpend = hk;
+        else asm("v_pk_max_f16 %0, %1, %2" : "=v"(m) : "v"(m), "v"(hk));
+        diag = w;
+        H[r] = h;
+        asm("v_pk_add_f16 %0, %1, %2" : "=v"(ng) : "v"(h), "v"(gv));
+        Hg[r] = ng;
+      }
+      {
+        // strict '>' per half: a key that grew restarts the count of steps since the best key was first seen, an equal key
+        // (same value, same column, a later row) does not: s2 <- (s2 + 1) * [key did not grow]
+        uint32_t nbk, d, nd1;
+        asm("v_pk_max_f16 %0, %1, %2" : "=v"(nbk) : "v"(blk), "v"(m));
+        asm("v_pk_sub_u16 %0, %1, %2" : "=v"(d) : "v"(nbk), "v"(blk));
+        asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(nd1) : "v"(one2), "v"(d));
+        asm("v_pk_mad_u16 %0, %1, %2, %2" : "=v"(s2) : "v"(s2), "v"(nd1));
+        blk = nbk;
+      }
+    }
+    }
+    // the slot's wavefront as it stands after step 64 (seg + 1) - 1, in the float32 kernel's scale and layout
+    if (ckA != nullptr && (seg + 1) * kWaveSeg < nbA + 16) {
+      float *ck = ckA + ((size_t)seg * 16 + (size_t)l) * (R + 1);
+#pragma unroll
+      for (int r = 0; r < R; ++r) ck[r] = (float)__builtin_bit_cast(_Float16, (uint16_t)(H[r] & 0xFFFFu)) * sa.ck_scale;
+      ck[R] = (float)__builtin_bit_cast(_Float16, (uint16_t)(up_prev & 0xFFFFu)) * sa.ck_scale;
+    }
+    if (ckB != nullptr && (seg + 1) * kWaveSeg < nbB + 16) {
+      float *ck = ckB + ((size_t)seg * 16 + (size_t)l) * (R + 1);
+#pragma unroll
+      for (int r = 0; r < R; ++r) ck[r] = (float)__builtin_bit_cast(_Float16, (uint16_t)(H[r] >> 16)) * sa.ck_scale;
+      ck[R] = (float)__builtin_bit_cast(_Float16, (uint16_t)(up_prev >> 16)) * sa.ck_scale;
+    }
+    const uint32_t histA = bufA32[kWaveSeg / 4 + (l & 3)], histB = bufB32[kWaveSeg / 4 + (l & 3)];
+    if (l < 4) { bufA32[l] = histA; bufB32[l] = histB; }
+    bufA32[4 + l] = nextA; bufB32[4 + l] = nextB;
+    nextA = stage_load(bA, nbA, seg + 2); nextB = stage_load(bB, nbB, seg + 2);
+  }
+
+  // per half: the lane's winner -> across the 16 lanes: value, then column of y, then row of x
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const bool active = half ? activeB : activeA;
+    const uint32_t kb = (blk >> (16 * half)) & 0xFFFFu;
+    const int tl = steps4 - 1 - l - (int)((s2 >> (16 * half)) & 0xFFFFu);   // (the lane's last stream position - steps since)
+    uint32_t kmax = kb;                                            // (keys are positive float16: ordered as integers)
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 16));
+    float bv = (float)__builtin_bit_cast(_Float16, (uint16_t)(kb & ~15u)) * sa.unscale;
+    const long long boff = active ? probs[half ? pidB : pidA].b_offset : 0;
+    long long bj = (long long)l * R + (15 - (int)(kb & 15u)) + 1, bi = boff + tl + 1;
+    if (!(bv > 0.0f)) { bv = 0.0f; bi = 0; bj = 0; }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+      const float ov = __shfl_xor(bv, off, 16);
+      const long long oi = __shfl_xor(bi, off, 16);
+      const long long oj = __shfl_xor(bj, off, 16);
+      if (ov > bv || (ov == bv && ov > 0.0f && (oj < bj || (oj == bj && oi < bi)))) { bv = ov; bi = oi; bj = oj; }
+    }
+    if (l == 0 && active) {
+      const WaveProblem *P = probs + (half ? pidB : pidA);
+      const bool undecided = kmax >= kProf16KeyLimit;
+      *P->best = undecided ? -1.0f : bv;
+      P->cell[0] = (bv > 0.0f && !undecided) ? bi : 0;
+      P->cell[1] = (bv > 0.0f && !undecided) ? bj : 0;
     }
   }
 }

@@ -79,7 +79,7 @@ def fuzz_cases(pgs, oracle):
 SWITCHES = ["no_f16", "no_unsat", "no_sample", "no_satflag", "no_solo", "no_wave", "no_comb", "no_twin", "no_wide",
             "no_strip", "no_quant", "no_devlist", "no_strip_groups", "u8_long_twin", "long_twin", "no_long",
             "no_requery", "slot=16", "strip_r=24", "few_r=5", "long_pipes=2", "no_long_p32", "long_groups=2", "force_f32", "no_opt_margin", "no_wave_prof",
-            "no_wave_window", "no_first", "no_long_save", "assume_cus=32", "u8_sample_short", "no_wave_pieces", "no_u8_early"]
+            "no_wave_window", "no_first", "no_long_save", "assume_cus=32", "u8_sample_short", "no_wave_pieces", "no_u8_early", "no_wave_f16"]
 
 
 def test_option_names_cover_the_switch_list(pgs):
@@ -520,16 +520,29 @@ def test_small_alignment_batch_windows(pgs, oracle, ylen):
     exp = [oracle.align(x, y, 0) for x in xs]
     c = pgs.Context(0)
     try:
-        for var in ({}, {"no_wave_window": 1}, {"no_wave_prof": 1}):
+        for var in ({}, {"no_wave_window": 1}, {"no_wave_prof": 1}, {"no_wave_f16": 1}):
             for k, v in var.items():
                 c.set_option(k, v)
             got = c.align_batch(xs, y, semantics=0)
             for k, (g, e) in enumerate(zip(got, exp)):
                 _cmp(g, e, "windows |y|=%d x[%d] |x|=%d %r" % (ylen, k, len(xs[k]), var))
-            left = c.last_counters()["left_window"]
-            assert (left >= 8) if not var else (left == 0), (var, left)         # the planted copies walk further than a window
+            cnt = c.last_counters()
+            left = cnt["left_window"]
+            # the planted copies walk further than a window — where they get one (beyond the float16 pass's key range they do not)
+            windows_f32 = var == {"no_wave_f16": 1} or (not var and ylen != 144)
+            assert (left >= 8) if windows_f32 else (left == 0), (var, left)
+            # ten columns per lane (|y| = 144): the first pass runs on packed float16 cells, and the planted copies (scores of
+            # 128 and more) are beyond its key range: they must come back through the float32 path with the oracle's answers
+            f16 = "f16=1" in " ".join(c.last_path())
+            assert f16 == (ylen == 144 and not var), (var, c.last_path())
+            assert (cnt["beyond_f16"] >= 8) if f16 else (cnt["beyond_f16"] == 0), (var, cnt)
             for k in var:
                 c.set_option(k, None)
+        # score + first maximum only (no decisions anywhere: the float16 pass on every |y| = 144 sequence, pieces included)
+        got = c.align_batch(xs, y, semantics=0, flags=pgs.capi.SCORE_ONLY)
+        assert ("f16=1" in " ".join(c.last_path())) == (ylen == 144), c.last_path()
+        for k, (g, e) in enumerate(zip(got, exp)):
+            assert (g["score"], g["end_x"], g["end_y"]) == (e["score"], e["end_x"], e["end_y"]), ("score only", ylen, k, len(xs[k]), g, e)
         # other dyadic scorings on the same batch (other scale; a cheap gap: long gapped walks)
         for sc in ((2.0, -1.0, 0.5), (5.0, -4.0, 3.0)):
             for g, x in zip(c.align_batch(xs, y, semantics=0, match=sc[0], mismatch=sc[1], gap=sc[2]), xs):
