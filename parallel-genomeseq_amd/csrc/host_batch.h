@@ -42,14 +42,14 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   const int W = (R + 15) / 16;
   const int64_t stream_total = orient == 0 ? (int64_t)count * nref : q.cumlen[first + count] - q.cumlen[first];
   // lanes = columns of the shared second sequence: the profile kernel (three-op cell, first maximum per lane).  With traceback,
-  // decisions are only made where the walk goes: a first pass keeps (maximum, cell) and saves the wavefront every 64 steps, a
-  // second resumes every problem kWindowGuard..+63 rows in front of its argmax and stops at it (a database of mostly unrelated
+  // decisions are only made where the walk goes: a first pass keeps (maximum, cell) and saves the wavefront every kCkptEvery steps, a
+  // second resumes every problem kWindowGuard + 1 .. + kCkptEvery rows in front of its argmax and stops at it (a database of mostly unrelated
   // sequences: walks of a dozen cells; a walk that leaves its window hands the problem to the host-driven path below).
   const bool prof = orient == 1 && wave_prof_ok(ref, p, R, (int)nref, true);
   const bool windows = prof && want_trace && !opt().no_wave_window;
   // Long streams in pieces (sw_batch_kernels.h; DESIGN.md §3.3 lemma L12): kPieceRows own rows behind a warm-up of the L1 margin along the stream (a path
   // that ends in row i of x spans fewer than |y| + ceil(smax |y| / g) rows) plus the reach of a decision window in front of an
-  // own row (kWindowGuard + 63 + 1), so that own rows and the checkpoints their windows resume from are exact.  Only where the
+  // own row (kWindowGuard + kCkptEvery), so that own rows and the checkpoints their windows resume from are exact.  Only where the
   // pass keeps no whole-problem decisions (score + argmax, or checkpointed windows).
   std::vector<int32_t> pc_seq, pc_start, pc_rows, pc_first;
   std::vector<int64_t> pc_before;
@@ -57,7 +57,7 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   int64_t piece_stream = 0, long_stream = 0;
   if (prof && (windows || !want_trace) && !opt().no_wave_pieces) {
     const Margin mg = make_margin(p.match, p.gap, true, (double)nref);   // (the profile kernel's scores are dyadic: exact arithmetic)
-    const int64_t warm = mg.finite() ? (mg.cols((double)nref) + kWindowGuard + 64 + 63) / 64 * 64 : -1;
+    const int64_t warm = mg.finite() ? (mg.cols((double)nref) + kWindowGuard + kCkptEvery + 63) / 64 * 64 : -1;
     const int64_t split_above = kPieceRows + warm;                   // (shorter sequences would not get shorter as pieces)
     if (warm > 0 && warm <= 4 * kPieceRows) {
       pc_first.push_back(0);
@@ -109,6 +109,7 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   a.best = ctx->outs_f.as<float>();
   a.cell = ctx->outs_i.as<int64_t>();
   a.ckpt = windows ? ctx->ckpt.as<float>() : nullptr;
+  a.f16 = 0;
   a.R = R;
   a.nlong = nlong; a.npieces = (int)npieces; a.piece_rows = kPieceRows; a.piece_stream = piece_stream; a.long_stream = long_stream;
   a.pc_seq = a.pc_start = a.pc_rows = a.pc_first = nullptr; a.pc_before = nullptr;
@@ -151,6 +152,7 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     int rc = launch_wave_prof16(ctx, ref, p, R, (int)nref, max_stream, dp, (int)nprob);
     if (rc < 0) return rc;
     f16 = rc == 0;
+    a.f16 = f16;
     if (!f16) rc = launch_wave_prof(ctx, ref, p, R, (int)nref, true, false, pblocks, dp, (int)nprob);
     else rc = 0;
     if (rc) return rc < 0 ? rc : fail(ctx, MI355_SW_ENODEV, "internal: the profile kernel refused a launch it had accepted");

@@ -101,6 +101,15 @@ int launch_wave_prof(mi355_sw_ctx *ctx, const RefData &ref, const mi355_sw_param
   const int k = std::max(1, std::min(100, std::ilogb((double)p.match * ((double)na + 1.0) + 1.0) + 2));
   sa.match_s = std::ldexp(p.match, -k); sa.mismatch_s = std::ldexp(p.mismatch, -k); sa.gap_s = std::ldexp(p.gap, -k);
   sa.unscale = std::ldexp(1.0f, k);
+  {
+    // states saved by sw_wave_prof16_kernel hold H / (q 2048), q = the power of two all three scores are multiples of
+    float q = 1.0f;
+    for (int e = 10; e >= -10; --e) {
+      const float c = std::ldexp(1.0f, e);
+      if (std::floor(p.match / c) == p.match / c && std::floor(p.mismatch / c) == p.mismatch / c && std::floor(p.gap / c) == p.gap / c) { q = c; break; }
+    }
+    sa.ck16_scale = std::ldexp(q, 11 - k);
+  }
 #define WAVE_PROF(r)                                                                                                                  \
   {                                                                                                                                   \
     if (lds > 48 * 1024) {                                                                                                            \
@@ -147,8 +156,6 @@ int launch_wave_prof16(mi355_sw_ctx *ctx, const RefData &ref, const mi355_sw_par
   sa.match_h = half_bits(p.match / unit); sa.mismatch_h = half_bits(p.mismatch / unit);
   sa.ngap2 = (uint32_t)half_bits(-p.gap / unit) * 0x00010001u;
   sa.unscale = unit;
-  const int k = std::max(1, std::min(100, std::ilogb((double)p.match * ((double)na + 1.0) + 1.0) + 2));   // (as launch_wave_prof)
-  sa.ck_scale = std::ldexp(unit, -k);
   const unsigned blocks = (unsigned)((n + 31) / 32);
 #define WAVE_PROF16(r)                                                                                                               \
   {                                                                                                                                   \
@@ -197,7 +204,7 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
     w.best = ctx->outs_f.as<float>() + k;
     w.cell = ctx->outs_i.as<int64_t>() + 2 * k;
     w.target = j.target; w.own_lo = j.own_lo; w.full_n = nref;
-    w.ckpt = nullptr; w.k0 = 0;
+    w.ckpt = nullptr; w.k0 = 0; w.ck_half = 0;
   }
   });
   const bool keyed = jobs[0].keyed;

@@ -8,7 +8,7 @@
 //   batch_wave_setup   WaveProblem[k] for sorted positions [first, first + count): whole problem, TRACK + DIRS
 //   (sw_wave_kernel)   one pass: first maximum in storage order AND the greedy decision of every cell
 //     or, lanes = columns of the shared second sequence with dyadic scores (sw_wave_prof_kernel, host_batch.h):
-//     (TRACK pass)       first maximum, the slot's wavefront saved every 64 steps
+//     (TRACK pass)       first maximum, the slot's wavefront saved every kCkptEvery steps
 //     batch_window_setup WaveProblem[k] <- the rows [k0, row of the argmax), resumed from the state saved at step k0
 //     (DIRS pass)        decisions for those rows only (a walk that leaves them: the problem goes to the host-driven path)
 //   batch_walk_setup   WaveWalk[k] from the argmax the pass just found
@@ -38,9 +38,10 @@ struct BatchWaveArgs {
   float *best;               // [count]
   int64_t *cell;             // [2 * count]
   // checkpointed whole problems (orient 1 on sw_wave_prof_kernel, host_batch.h): the first pass keeps (best, cell) and saves
-  // the wavefront's state every 64 steps; batch_window_setup then turns every problem into its last kWindowGuard .. + 63 rows in
+  // the wavefront's state every kCkptEvery steps; batch_window_setup then turns every problem into its last kWindowGuard + 1 .. + kCkptEvery rows in
   // front of the argmax, resumed from the saved state, and only those rows get decisions
   float *ckpt;               // null: whole problems in one pass
+  int f16;                   // the first pass ran on sw_wave_prof16_kernel (two problems per slot, one set of saved states per pair)
   int R;
   // Long streams cut into PIECES (orient 1 on sw_wave_prof_kernel, host_batch.h): a launch is at least as long as its longest
   // stream, and a 7 k-residue sequence is 20 average ones — a fixed cost that does not shrink with a rank's share of the
@@ -60,13 +61,15 @@ struct BatchWaveArgs {
 };
 
 constexpr int kPieceRows = 1024;                                   // own rows of a piece of a long stream (BatchWaveArgs)
-constexpr int kWindowGuard = 48;                                   // rows in front of the argmax a window holds at least
-constexpr int kWindowRows = kWindowGuard + 64 + 16;                // decision rows per window: guard .. guard + 63 rows, + the skew
+// rows in front of the argmax a window holds at least.  Config 4's walks (unrelated sequences): median 4 rows, 18 at the 99.9th
+// percentile, 23 the longest of 20 000; a walk that leaves its window takes the host-driven path (left_window)
+constexpr int kWindowGuard = 32;
+constexpr int kWindowRows = kWindowGuard + kCkptEvery + 16;        // decision rows per window: guard + 1 .. guard + kCkptEvery rows, + the skew
 
-// saved states in front of problem k: one row of 16 x (R + 1) floats per 64 steps (as batch_dirs_offset: monotone in k, room for
-// (steps_k + 16) / 64 + 1 rows)
+// saved states in front of problem k: one row of 16 x (R + 1) floats per kCkptEvery steps (as batch_dirs_offset: monotone in k,
+// room for (steps_k + 16) / kCkptEvery + 1 rows)
 __device__ __host__ inline int64_t batch_ckpt_row(int64_t stream_positions_before, int64_t k) {
-  return (stream_positions_before + 16 * k) / 64 + k;
+  return (stream_positions_before + 16 * k) / kCkptEvery + k;
 }
 
 // decision bytes in front of problem k of the launch (k = 0 .. count): (stream positions so far + 16 rows of skew per
@@ -99,7 +102,7 @@ __global__ void batch_wave_setup(const BatchWaveArgs a) {
   w.dirs = a.ckpt != nullptr ? nullptr
                              : reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(a.dirs) + batch_dirs_offset(before, kk, a.W));
   w.ckpt = a.ckpt != nullptr ? a.ckpt + (size_t)batch_ckpt_row(before, kk) * 16 * (size_t)(a.R + 1) : nullptr;
-  w.k0 = 0;
+  w.k0 = 0; w.ck_half = 0;
   w.best = a.best + kk;
   w.cell = a.cell + 2 * (size_t)kk;
   w.target = 0.0f; w.own_lo = 0; w.full_n = a.nref;
@@ -147,10 +150,13 @@ __global__ void batch_window_setup(const BatchWaveArgs a) {
   WaveProblem w = a.probs[a.sprob[k]];                             // (a piece: rows count from its first row, b_offset)
   const bool hit = a.sbest[k] > 0.0f;
   const int32_t rows = hit ? (int32_t)(a.scell[2 * (size_t)k] - w.b_offset) : 0;   // 1-based row of the argmax = rows to run
-  const int32_t k0 = hit ? 64 * (max(0, rows - 1 - kWindowGuard) / 64) : 0;
+  const int32_t k0 = hit ? kCkptEvery * (max(0, rows - 1 - kWindowGuard) / kCkptEvery) : 0;
   w.nb = rows;
   w.k0 = k0;
-  w.ckpt = k0 > 0 ? w.ckpt + (size_t)(k0 / 64 - 1) * 16 * (size_t)(a.R + 1) : nullptr;
+  // (states of the packed float16 pass: one set per PAIR of problems, at the first one's place)
+  float *states = a.f16 ? a.probs[a.sprob[k] & ~1].ckpt : w.ckpt;
+  w.ckpt = k0 > 0 ? states + (size_t)(k0 / kCkptEvery - 1) * 16 * (size_t)(a.R + 1) : nullptr;
+  w.ck_half = a.f16 ? 1 + (a.sprob[k] & 1) : 0;
   w.dirs = a.dirs + (size_t)k * kWindowRows * 16 * (size_t)a.W;
   a.probs2[k] = w;
 }

@@ -38,10 +38,14 @@ struct WaveProblem {
   int32_t own_lo;
   int64_t full_n;        // |y| of the full problem (uint8 storage order)
   // sw_wave_prof_kernel only (checkpointed whole problems, host_batch.h).  TRACK without DIRS: where the state of the slot's
-  // wavefront is saved after every 64th step (null: nowhere).  DIRS without TRACK: k0 > 0 resumes the problem at step k0 (a
-  // multiple of 64) from the state saved there; nb is then the END of the rows to run, dirs rows count from step k0.
+  // wavefront is saved after every kCkptEvery-th step (null: nowhere).  DIRS without TRACK: k0 > 0 resumes the problem at step k0
+  // (a multiple of kCkptEvery) from the state saved there; nb is then the END of the rows to run, dirs rows count from step k0.
   float *ckpt;
   int32_t k0;
+  // DIRS resumed from a state sw_wave_prof16_kernel saved: that kernel stores its packed registers as they are, one row of
+  // 16 x (R + 1) dwords per saved state for the PAIR of problems a slot runs (ckpt of the pair's first problem); 1 / 2 = this
+  // problem was the low / high half (0: float32 states of its own, sw_wave_prof_kernel<TRACK>)
+  int32_t ck_half;
 };
 
 struct WaveScoring {
@@ -51,6 +55,8 @@ struct WaveScoring {
 
 constexpr int kWaveSeg = 64;
 constexpr int kWaveBuf = 16 + kWaveSeg;
+constexpr int kCkptEvery = 32;           // steps between two saved states of a checkpointed pass (sw_wave_prof_kernel / sw_wave_prof16_kernel)
+static_assert(kWaveSeg == 2 * kCkptEvery, "a state is saved in the middle and at the end of every 64-step segment");
 
 template <int R, int ORIENT, bool U8, bool TRACK, bool DIRS, bool KEYED = false>
 __global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, int nprob, const WaveScoring sc) {
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, 
   WaveProblem P;
   if (active) P = probs[pid];
   else { P.a = nullptr; P.b = nullptr; P.na = 0; P.nb = 0; P.b_offset = 0; P.dirs = nullptr; P.best = nullptr; P.cell = nullptr;
-         P.target = -1.0f; P.own_lo = 0; P.full_n = 0; P.ckpt = nullptr; P.k0 = 0; }
+         P.target = -1.0f; P.own_lo = 0; P.full_n = 0; P.ckpt = nullptr; P.k0 = 0; P.ck_half = 0; }
   const int na = P.na, nb = P.nb;
 
   // this lane's R characters of the short side (0xFFFF = padding, never equal to a byte)
@@ -262,6 +268,7 @@ struct WaveProfArgs {
   int32_t ncodes;
   float match_s, mismatch_s, gap_s;   // scores * 2^-k
   float unscale;             // 2^k
+  float ck16_scale;          // a state saved by sw_wave_prof16_kernel: this kernel's cell = that float16 value * ck16_scale
 };
 
 template <int R, bool TRACK, bool DIRS>
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
   WaveProblem P;
   if (active) P = probs[pid];
   else { P.a = nullptr; P.b = nullptr; P.na = 0; P.nb = 0; P.b_offset = 0; P.dirs = nullptr; P.best = nullptr; P.cell = nullptr;
-         P.target = -1.0f; P.own_lo = 0; P.full_n = 0; P.ckpt = nullptr; P.k0 = 0; }
+         P.target = -1.0f; P.own_lo = 0; P.full_n = 0; P.ckpt = nullptr; P.k0 = 0; P.ck_half = 0; }
   const int nb = P.nb;
   // the lane side is the same for every problem of the launch (the range of the resident reference)
   const uint8_t *ya = probs[blockIdx.x * 16].a;
@@ -336,9 +343,20 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
   uint32_t up_prev = 0;
   if (DIRS && !TRACK && k0 > 0 && P.ckpt != nullptr) {
     const float *ck = P.ckpt + (size_t)l * (R + 1);
+    if (P.ck_half == 0) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) { H[r] = ck[r]; Hg[r] = H[r] - gv; }
-    up_prev = __float_as_uint(ck[R]);
+      for (int r = 0; r < R; ++r) { H[r] = ck[r]; Hg[r] = H[r] - gv; }
+      up_prev = __float_as_uint(ck[R]);
+    } else {
+      const uint32_t *ck2 = reinterpret_cast<const uint32_t *>(ck);
+      const int sh = P.ck_half == 2 ? 16 : 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        H[r] = (float)__builtin_bit_cast(_Float16, (uint16_t)(ck2[r] >> sh)) * sa.ck16_scale;
+        Hg[r] = H[r] - gv;
+      }
+      up_prev = __float_as_uint((float)__builtin_bit_cast(_Float16, (uint16_t)(ck2[R] >> sh)) * sa.ck16_scale);
+    }
   } else {
 #pragma unroll
     for (int r = 0; r < R; ++r) { H[r] = 0.0f; Hg[r] = -gv; }
@@ -347,9 +365,20 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
   int tl = 0;                                                      // ... and the stream position it was first seen at
   const float *prof_lane = prof + l * LS;
 
+  // TRACK without DIRS: the slot's wavefront as it stands after step kCkptEvery (c + 1) - 1 — what a later launch needs to
+  // resume there
+  auto save_state = [&](int c) {
+    if (P.ckpt != nullptr && (c + 1) * kCkptEvery < nb + 16) {
+      float *ck = P.ckpt + ((size_t)c * 16 + (size_t)l) * (R + 1);
+#pragma unroll
+      for (int r = 0; r < R; ++r) ck[r] = H[r];
+      ck[R] = __uint_as_float(up_prev);
+    }
+  };
   for (int seg = 0; seg < nseg; ++seg) {
     const int kq = min(kWaveSeg, steps4 - seg * kWaveSeg) >> 2;
     for (int k4 = 0; k4 < kq; ++k4) {
+    if (TRACK && !DIRS && k4 == kCkptEvery / 4) save_state(2 * seg);
 #pragma unroll
     for (int ku = 0; ku < 4; ++ku) {
       const int k = 4 * k4 + ku;
@@ -432,15 +461,7 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
       }
     }
     }
-    if (TRACK && !DIRS) {
-      // the slot's wavefront as it stands after step 64 (seg + 1) - 1: what a later launch needs to resume there
-      if (P.ckpt != nullptr && (seg + 1) * kWaveSeg < nb + 16) {
-        float *ck = P.ckpt + ((size_t)seg * 16 + (size_t)l) * (R + 1);
-#pragma unroll
-        for (int r = 0; r < R; ++r) ck[r] = H[r];
-        ck[R] = __uint_as_float(up_prev);
-      }
-    }
+    if (TRACK && !DIRS && kq == kWaveSeg / 4) save_state(2 * seg + 1);
     const uint32_t hist = buf32[kWaveSeg / 4 + (l & 3)];
     if (l < 4) buf32[l] = hist;
     buf32[4 + l] = nextc;
@@ -482,7 +503,9 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
 //     2^-4 is NOT decided here: best = -1, and the host hands that sequence to the float32 path (a database of mostly unrelated
 //     sequences: a handful).  The row of the first sight of a lane's best key is kept for both halves as two 16-bit counts of
 //     the steps since (the host bounds the stream at 65 000 rows): max, sub, saturating sub, mad on packed integers per STEP.
-// Saved states (P.ckpt) are written in the float32 kernel's cell scale, so the decision windows resume from them unchanged.
+// Saved states: the packed registers as they are, one row per state for the slot's PAIR of problems, at the first problem's
+// ckpt (rows for both problems were laid out back to back: room for the longer of the two); the decision pass converts the half
+// it resumes (WaveProblem::ck_half).
 struct WaveProf16Args {
   const uint8_t *lut;        // [256] byte -> code; ncodes - 1 = "other"
   const uint8_t *byte_of;    // [ncodes - 1] code -> byte
@@ -490,7 +513,6 @@ struct WaveProf16Args {
   uint32_t match_h, mismatch_h;   // float16 bits of score / (q 2048)
   uint32_t ngap2;            // float16 bits of -gap / (q 2048) in both halves
   float unscale;             // q * 2048
-  float ck_scale;            // float32 kernel's cell = this kernel's cell * ck_scale
 };
 constexpr uint32_t kProf16KeyLimit = 0x2C00u;                      // float16 2^-4 = 128 / 2048: keys below it are exact
 constexpr uint32_t kProf16One = 0x3C00u;                           // float16 1.0
@@ -569,11 +591,22 @@ __global__ __launch_bounds__(256) void sw_wave_prof16_kernel(const WaveProblem *
   uint32_t blk = 0;                                                // best key of this lane, both halves
   uint32_t s2 = 0;                                                 // ... and the steps since it was first seen (16 bits each)
   const uint32_t *profLo_lane = profLo + l * LS, *profHi_lane = profHi + l * LS;
-  float *ckA = activeA ? probs[pidA].ckpt : nullptr, *ckB = activeB ? probs[pidB].ckpt : nullptr;
+  float *ckA = activeA ? probs[pidA].ckpt : nullptr;              // (the pair's states go where its first problem's would)
 
+  // the slot's wavefront as it stands after step kCkptEvery (c + 1) - 1: the packed registers as they are, for the pair
+  const int nbmax = max(nbA, nbB);
+  auto save_state = [&](int c) {
+    if (ckA != nullptr && (c + 1) * kCkptEvery < nbmax + 16) {
+      uint32_t *ck = reinterpret_cast<uint32_t *>(ckA) + ((size_t)c * 16 + (size_t)l) * (R + 1);
+#pragma unroll
+      for (int r = 0; r < R; ++r) ck[r] = H[r];
+      ck[R] = up_prev;
+    }
+  };
   for (int seg = 0; seg < nseg; ++seg) {
     const int kq = min(kWaveSeg, steps4 - seg * kWaveSeg) >> 2;
     for (int k4 = 0; k4 < kq; ++k4) {
+    if (k4 == kCkptEvery / 4) save_state(2 * seg);
 #pragma unroll
     for (int ku = 0; ku < 4; ++ku) {
       const int k = 4 * k4 + ku;
@@ -621,19 +654,7 @@ __global__ __launch_bounds__(256) void sw_wave_prof16_kernel(const WaveProblem *
       }
     }
     }
-    // the slot's wavefront as it stands after step 64 (seg + 1) - 1, in the float32 kernel's scale and layout
-    if (ckA != nullptr && (seg + 1) * kWaveSeg < nbA + 16) {
-      float *ck = ckA + ((size_t)seg * 16 + (size_t)l) * (R + 1);
-#pragma unroll
-      for (int r = 0; r < R; ++r) ck[r] = (float)__builtin_bit_cast(_Float16, (uint16_t)(H[r] & 0xFFFFu)) * sa.ck_scale;
-      ck[R] = (float)__builtin_bit_cast(_Float16, (uint16_t)(up_prev & 0xFFFFu)) * sa.ck_scale;
-    }
-    if (ckB != nullptr && (seg + 1) * kWaveSeg < nbB + 16) {
-      float *ck = ckB + ((size_t)seg * 16 + (size_t)l) * (R + 1);
-#pragma unroll
-      for (int r = 0; r < R; ++r) ck[r] = (float)__builtin_bit_cast(_Float16, (uint16_t)(H[r] >> 16)) * sa.ck_scale;
-      ck[R] = (float)__builtin_bit_cast(_Float16, (uint16_t)(up_prev >> 16)) * sa.ck_scale;
-    }
+    if (kq == kWaveSeg / 4) save_state(2 * seg + 1);
     const uint32_t histA = bufA32[kWaveSeg / 4 + (l & 3)], histB = bufB32[kWaveSeg / 4 + (l & 3)];
     if (l < 4) { bufA32[l] = histA; bufB32[l] = histB; }
     bufA32[4 + l] = nextA; bufB32[4 + l] = nextB;
