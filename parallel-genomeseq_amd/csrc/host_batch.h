@@ -226,8 +226,9 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
   HostTrace t_results("  batch: results on the host");
   std::atomic<bool> bad{false};
-  std::atomic<size_t> left{0}, beyond{0};
+  std::atomic<size_t> left{0}, beyond{0}, done{0};
   parallel_for(n, [&](size_t k0, size_t k1) {
+    size_t mine = 0;
     for (size_t k = k0; k < k1; ++k) {
       const int id = q.order[batch_sorted_pos((int)first, (int)n, (int)k)];
       const bool hit = h_best[k] > 0;
@@ -239,6 +240,7 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
         continue;
       }
       handled[id] = 1;
+      ++mine;
       Located &L = loc[id];
       L.score = hit ? h_best[k] : 0;
       L.ix = h_cell[2 * k]; L.iy = h_cell[2 * k + 1];
@@ -249,8 +251,10 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
       t.cy = t.cx + t.len;
       t.pos = (uint32_t)h_wout[3 * k + 1];
     }
+    done.fetch_add(mine, std::memory_order_relaxed);
   });
   if (bad.load()) return fail(ctx, MI355_SW_ENODEV, "internal: a walk over a whole-problem window failed");
+  ctx->devlist_done += done.load();
   ctx->left_window += left.load();
   ctx->beyond_f16 += beyond.load();
   return 0;

@@ -304,6 +304,7 @@ struct mi355_sw_ctx {
   std::vector<Located> loc_store;
   std::vector<TraceOut> tout_store;
   std::function<void()> while_device_works;   // host work of the running call that does not depend on the launches in flight: run in front of the next wait
+  size_t devlist_done = 0;        // alignments of the running range the device-built lists finished (host_batch.h)
   size_t beyond_f16 = 0;          // sequences of the running call whose maximum was beyond the packed float16 pass's key range (host_batch.h)
   size_t left_window = 0;         // walks of the running call that left their decision window (host_batch.h) and were redone whole
   size_t requeried = 0;           // queries of the running call that were swept a second time on the exact instances

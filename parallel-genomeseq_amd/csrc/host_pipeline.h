@@ -841,6 +841,8 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
     // Many small whole problems (short reference or short queries: nothing took the score kernel): float engine with
     // identity scoring runs them on device-built job lists, one sorted range per orientation (host_batch.h)
     std::vector<char> handled(nq, 0);
+    bool all_handled = false;
+    size_t z_handled = 0;
     if (!any_fast && p.semantics == MI355_SW_F32 && wave_scoring_ok(p) && !opt().no_wave &&
         !opt().no_devlist) {
       auto len_at = [&](size_t pos) { return (int64_t)q.len[q.order[pos]]; };
@@ -856,6 +858,8 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
       const size_t e0 = all_stream ? z : first_above(std::min<int64_t>(kWaveMaxLanesSide, n));
       const size_t e1 = n <= kWaveMaxLanesSide ? nq : e0;          // lanes = columns of y (|y| <= 512), x streams
       for (size_t pos = 0; pos < z; ++pos) handled[q.order[pos]] = 1;
+      all_handled = true; z_handled = z;
+      ctx->devlist_done = 0;
       HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
       int rc = exact_full_device(ctx, ref, q, rg, p, z, e0 - z, 0, want_trace, loc, tout, handled);
       if (!rc) rc = exact_full_device(ctx, ref, q, rg, p, e0, e1 - e0, 1, want_trace, loc, tout, handled);
@@ -865,7 +869,9 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
     }
     if (ctx->while_device_works) { ctx->while_device_works(); ctx->while_device_works = nullptr; }   // (no launch took it)
     std::vector<int> slow;
-    for (size_t k = 0; k < nq; ++k) if (!qfast[k] && !handled[k]) slow.push_back((int)k);
+    all_handled = all_handled && z_handled + ctx->devlist_done == nq;   // (half a million alignments: no scan when the lists took them all)
+    if (!all_handled)
+      for (size_t k = 0; k < nq; ++k) if (!qfast[k] && !handled[k]) slow.push_back((int)k);
     // Problems the score kernel does not take (no finite warm-up margin: a gap penalty that is, or truncates to, 0 ...) and whose
     // anti-diagonal does not fit the LDS kernel either: the strip kernel over the WHOLE range as one window — a window that starts
     // at column 0 needs no margin — for the first maximum (locate_saturated with one sub-chunk = the range) and for the decisions

@@ -216,3 +216,54 @@ def test_finish_from_saved_state(pgs, oracle):
         assert cnt["saved_traces"] + cnt["saved_fallbacks"] >= 1, cnt
     finally:
         c.close()
+
+
+def test_float16_first_pass_boundaries(pgs, oracle):
+    """The many-small-alignments batch on packed float16 cells (sw_wave_prof16_kernel, DESIGN.md lemma L13) at the edges of what
+    it may decide: scores just below / at / above 128 units (the key's four free mantissa bits), equal maxima in neighbouring
+    columns of one lane and in different lanes (first column wins, then first row), problems paired with a much longer / an
+    empty neighbour, an odd number of problems, scorings whose unit is not 1, and the scorings / stream lengths the kernel
+    must refuse (match * (|y| + 1) >= 2048 units; streams beyond 65 000 rows when pieces are off)."""
+    y = pgs.synth.P02232.encode()                                               # 144 letters: nine columns per lane
+    rnd = lambda seed, n: pgs.synth.protein(seed, n).tobytes()
+    xs = []
+    for k, run in enumerate((41, 42, 43, 44, 60, 143)):                         # 3 * run: 123, 126, 129, 132, 180, 429
+        xs.append(rnd(100 + k, 200)[:77] + y[50:50 + run if 50 + run <= 144 else 144][:run] + rnd(200 + k, 90))
+    xs.append(rnd(300, 30) + y[10:30] + rnd(301, 45) + y[10:30] + rnd(302, 20))           # the same 20 letters twice: equal maxima, first row wins
+    xs.append(rnd(303, 25) + y[12:30] + rnd(304, 31) + y[72:90] + rnd(305, 20))           # equal maxima in different lanes: first column wins
+    xs.append(y[100:120] + rnd(306, 300) + y[20:40])                                      # ... the later row holds the earlier column
+    xs += [b"", y[:1], rnd(307, 5000), b"", rnd(308, 33), y, y[::-1], rnd(309, 1601), rnd(310, 1599)]
+    xs += [rnd(400 + k, 64 * (k % 7) + k) for k in range(41)]                             # odd count, lengths around the segments
+    c = pgs.Context(0)
+    try:
+        for sc, f16 in (((3.0, -3.0, 2.0), True), ((0.5, -0.25, 0.25), True), ((64.0, -48.0, 32.0), True),
+                        ((14.0, -3.0, 2.0), True),       # 14 * 145 = 2030 < 2048 units: the last scoring the cells hold exactly
+                        ((15.0, -3.0, 2.0), False),      # 15 * 145 = 2175: refused
+                        ((3.0, -2049.0, 2.0), False)):   # a mismatch score beyond the cell's range: refused
+            exp = [oracle.align(x, y, 0, *sc) for x in xs]
+            for flags in (0, pgs.capi.SCORE_ONLY):
+                got = c.align_batch(xs, y, semantics=0, match=sc[0], mismatch=sc[1], gap=sc[2], flags=flags)
+                path = " ".join(c.last_path())
+                assert ("f16=1" in path) == f16, (sc, flags, path)
+                for k, (g, e) in enumerate(zip(got, exp)):
+                    if flags:
+                        assert (g["score"], g["end_x"], g["end_y"]) == (e["score"], e["end_x"], e["end_y"]), (sc, k, len(xs[k]), g, e)
+                    else:
+                        _cmp(g, e, "float16 pass, scoring %r, x[%d] |x|=%d" % (sc, k, len(xs[k])))
+                beyond = c.last_counters()["beyond_f16"]
+                if sc == (3.0, -3.0, 2.0):
+                    # 129, 132, 180, 429 and the whole y (432); 123 and 126 are decided on float16 cells
+                    assert beyond == 5, (flags, beyond)
+                if not f16:
+                    assert beyond == 0
+        # a stream beyond the 16-bit step counters (pieces off): the float32 pass takes the launch
+        c.set_option("no_wave_pieces", 1)
+        long_x = [rnd(500, 70_000)[:30_000] + y[5:60] + rnd(501, 40_000), rnd(502, 200)]
+        got = c.align_batch(long_x, y, semantics=0, flags=pgs.capi.SCORE_ONLY)
+        assert "f16=0" in " ".join(c.last_path()) and "prof=1" in " ".join(c.last_path()), c.last_path()
+        for g, x in zip(got, long_x):
+            e = oracle.align(x, y, 0)
+            assert (g["score"], g["end_x"], g["end_y"]) == (e["score"], e["end_x"], e["end_y"])
+        c.set_option("no_wave_pieces", None)
+    finally:
+        c.close()
