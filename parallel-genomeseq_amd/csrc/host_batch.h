@@ -178,17 +178,28 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   HIPCHK(ctx, hipGetLastError());
   path_note(ctx, "devlist[orient=%d,R=%d,prof=%d,f16=%d,windows=%d,trace=%d,pieces=%d]", orient, R, (int)prof, f16, (int)windows, (int)want_trace, (int)(npieces != 0));
 
-  // results land in pinned staging: [best n x 4][cell n x 16][wout n x 24][offs (n + 1) x 8]
+  // Results.  When this launch holds every non-empty query of the batch (the UniProt shape: one launch), a last kernel writes one
+  // 40-byte record per alignment AT ITS QUERY ID and the host's loop over them reads and writes in order; else the per-launch-
+  // position arrays come down and the loop scatters: [best n x 4][cell n x 16][wout n x 24][offs (n + 1) x 8].
+  const size_t nq = q.nq;
+  const bool by_id = !opt().no_devlist_by_id && first + n == nq && (first == 0 || q.len[q.order[first - 1]] == 0);
+  path_note(ctx, "devlist_results[by_id=%d]", (int)by_id);
   const size_t o_best = 0, o_cell = (n * 4 + 15) & ~(size_t)15, o_wout = o_cell + n * 16, o_offs = o_wout + n * 24;
-  if (ctx->pin_out.ensure(o_offs + (n + 1) * 8 + 64)) return fail(ctx, MI355_SW_ENOMEM, "hipHostMalloc(batch results) failed");
+  if (ctx->pin_out.ensure(std::max(o_offs + (n + 1) * 8, nq * sizeof(BatchRec) + 16) + 64)) return fail(ctx, MI355_SW_ENOMEM, "hipHostMalloc(batch results) failed");
+  if (by_id && ctx->recs.ensure(nq * sizeof(BatchRec))) return fail(ctx, MI355_SW_ENOMEM, "hipMalloc(batch records) failed");
   uint8_t *pin = ctx->pin_out.as<uint8_t>();
   float *h_best = reinterpret_cast<float *>(pin + o_best);
   int64_t *h_cell = reinterpret_cast<int64_t *>(pin + o_cell);
   int64_t *h_wout = reinterpret_cast<int64_t *>(pin + o_wout);
   int64_t *h_offs = reinterpret_cast<int64_t *>(pin + o_offs);
-  HIPCHK(ctx, hipMemcpyAsync(h_best, a.sbest, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(h_cell, a.scell, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  int64_t *h_total = reinterpret_cast<int64_t *>(pin + nq * sizeof(BatchRec));   // by_id: behind the records
+  const BatchRec *h_rec = reinterpret_cast<const BatchRec *>(pin);
+  if (!by_id) {
+    HIPCHK(ctx, hipMemcpyAsync(h_best, a.sbest, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_cell, a.scell, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  }
   const char *cons_base = nullptr;
+  bool passes_done = false;
   if (want_trace) {
     WaveWalk *walks = ctx->walkp.as<WaveWalk>();
     int64_t *wout = reinterpret_cast<int64_t *>(ctx->walkp.as<uint8_t>() + n * sizeof(WaveWalk));
@@ -205,12 +216,19 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     HIPCHK(ctx, hipGetLastError());
     int rc = device_scan(ctx, offs, (int64_t)n, offs + n);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(h_offs, offs, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(h_wout, wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (by_id) {
+      hipLaunchKernelGGL(batch_records_by_id, dim3(sblocks), dim3(256), 0, ctx->stream, a, (const int64_t *)wout, (const int64_t *)offs, ctx->recs.as<BatchRec>());
+      HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipMemcpyAsync(h_total, offs + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(pin, ctx->recs.p, nq * sizeof(BatchRec), hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+      HIPCHK(ctx, hipMemcpyAsync(h_offs, offs, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(h_wout, wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (ctx->while_device_works) { ctx->while_device_works(); ctx->while_device_works = nullptr; }
     { HostTrace t_("  batch: passes + walk measure");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }            // the one mid-call round trip: how many bytes to expect
-    const size_t ctot = (size_t)h_offs[n];
+    const size_t ctot = (size_t)(by_id ? *h_total : h_offs[n]);
     if (ctx->pin_cons.size() <= ctx->cons_used) ctx->pin_cons.resize(ctx->cons_used + 1);
     PinBuf &cons = ctx->pin_cons[ctx->cons_used];
     if (ctx->cons.ensure(ctot + 16) || cons.ensure(ctot + 16)) return fail(ctx, MI355_SW_ENOMEM, "consensus buffers: allocation failed");
@@ -220,39 +238,83 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     if (ctot) HIPCHK(ctx, hipMemcpyAsync(cons.p, ctx->cons.p, ctot, hipMemcpyDeviceToHost, ctx->stream));
     ctx->cons_used++;
     cons_base = cons.as<char>();
+  } else if (by_id) {
+    hipLaunchKernelGGL(batch_records_by_id, dim3(sblocks), dim3(256), 0, ctx->stream, a, (const int64_t *)nullptr, (const int64_t *)nullptr, ctx->recs.as<BatchRec>());
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));          // (the pass is done; the records are still to come down)
+    passes_done = true;
+    HIPCHK(ctx, hipMemcpyAsync(pin, ctx->recs.p, nq * sizeof(BatchRec), hipMemcpyDeviceToHost, ctx->stream));
   }
   if (ctx->while_device_works) { ctx->while_device_works(); ctx->while_device_works = nullptr; }
   { HostTrace t_("  batch: to the last download");
+  // the result loop below takes the pool: its workers are woken (they then spin for a millisecond) as close in front of it as a
+  // wait allows — behind the pass when only the download of the records is left, else in front of the last wait
+  if (passes_done) HIPCHK(ctx, hipEventSynchronize(ctx->ev[6]));
+  if (n >= tl_pool_from) WorkerPool::get().nudge();
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
   HostTrace t_results("  batch: results on the host");
   std::atomic<bool> bad{false};
   std::atomic<size_t> left{0}, beyond{0}, done{0};
-  parallel_for(n, [&](size_t k0, size_t k1) {
-    size_t mine = 0;
-    for (size_t k = k0; k < k1; ++k) {
-      const int id = q.order[batch_sorted_pos((int)first, (int)n, (int)k)];
-      const bool hit = h_best[k] > 0;
-      if (h_best[k] < 0) { beyond.fetch_add(1, std::memory_order_relaxed); continue; }   // the float16 pass left it undecided (handled stays 0)
-      if (want_trace && hit && h_wout[3 * k + 2] != 0) {
-        // a walk that left its window: the problem goes to the host-driven path (handled stays 0); on whole problems: a bug
-        if (!windows || h_wout[3 * k + 2] != 1) bad.store(true, std::memory_order_relaxed);
-        else left.fetch_add(1, std::memory_order_relaxed);
-        continue;
-      }
-      handled[id] = 1;
-      ++mine;
-      Located &L = loc[id];
-      L.score = hit ? h_best[k] : 0;
-      L.ix = h_cell[2 * k]; L.iy = h_cell[2 * k + 1];
-      if (!want_trace || !hit) continue;
-      TraceOut &t = tout[id];
-      t.len = (size_t)h_wout[3 * k];
-      t.cx = cons_base + h_offs[k];
-      t.cy = t.cx + t.len;
-      t.pos = (uint32_t)h_wout[3 * k + 1];
+  ViewStore *dv = by_id ? ctx->direct_view : nullptr;              // (mi355_sw_batch_run_view: finished alignments go straight into the view)
+  // one alignment: the launch's (score, cell, walk) -> handled / loc / tout of query `id`, or its entries of the caller's view
+  auto take = [&](int id, float best, int64_t ix, int64_t iy, size_t len, uint32_t pos, int64_t status, int64_t off) -> bool {
+    const bool hit = best > 0;
+    if (best < 0) { beyond.fetch_add(1, std::memory_order_relaxed); return false; }      // the float16 pass left it undecided (handled stays 0)
+    if (want_trace && hit && status != 0) {
+      // a walk that left its window: the problem goes to the host-driven path (handled stays 0); on whole problems: a bug
+      if (!windows || status != 1) bad.store(true, std::memory_order_relaxed);
+      else left.fetch_add(1, std::memory_order_relaxed);
+      return false;
     }
-    done.fetch_add(mine, std::memory_order_relaxed);
-  });
+    if (dv) {
+      // (as align_range_view makes them from loc / tout)
+      handled[id] = 2;
+      const bool tr = want_trace && hit;
+      const size_t l = tr ? len : 0;
+      dv->score[id] = hit ? best : 0;
+      dv->end_x[id] = hit ? ix : 0;
+      dv->end_y[id] = hit ? iy : 0;
+      dv->pos[id] = tr ? pos : 0;
+      dv->cons_len[id] = (uint32_t)l;
+      dv->cx[id] = l ? cons_base + off : nullptr;
+      dv->cy[id] = l ? cons_base + off + l : nullptr;
+      return true;
+    }
+    handled[id] = 1;
+    Located &L = loc[id];
+    L.score = hit ? best : 0;
+    L.ix = ix; L.iy = iy;
+    if (!want_trace || !hit) return true;
+    TraceOut &t = tout[id];
+    t.len = len;
+    t.cx = cons_base + off;
+    t.cy = t.cx + t.len;
+    t.pos = pos;
+    return true;
+  };
+  if (by_id) {
+    parallel_for(nq, [&](size_t k0, size_t k1) {
+      size_t mine = 0;
+      for (size_t id = k0; id < k1; ++id) {
+        if (q.len[id] == 0) continue;                              // (an empty query: not in the launch, its defaults stand)
+        const BatchRec &r = h_rec[id];
+        mine += take((int)id, r.score, r.ix, r.iy, (size_t)r.len, r.pos, r.status, r.off) ? 1 : 0;
+      }
+      done.fetch_add(mine, std::memory_order_relaxed);
+    });
+  } else {
+    parallel_for(n, [&](size_t k0, size_t k1) {
+      size_t mine = 0;
+      for (size_t k = k0; k < k1; ++k) {
+        const int id = q.order[batch_sorted_pos((int)first, (int)n, (int)k)];
+        const bool tr = want_trace && h_best[k] > 0;
+        mine += take(id, h_best[k], h_cell[2 * k], h_cell[2 * k + 1], tr ? (size_t)h_wout[3 * k] : 0, tr ? (uint32_t)h_wout[3 * k + 1] : 0,
+                     tr ? h_wout[3 * k + 2] : 0, tr ? h_offs[k] : 0) ? 1 : 0;
+      }
+      done.fetch_add(mine, std::memory_order_relaxed);
+    });
+  }
+  if (dv) ctx->devlist_direct += done.load();
   if (bad.load()) return fail(ctx, MI355_SW_ENODEV, "internal: a walk over a whole-problem window failed");
   ctx->devlist_done += done.load();
   ctx->left_window += left.load();

@@ -14,7 +14,7 @@ constexpr size_t kExactLdsMax = 159 * 1024;    // dynamic part; the wide instanc
 #define MI355_SW_BOOL_OPTIONS(X) \
   X(no_f16) X(no_unsat) X(no_sample) X(no_satflag) X(no_solo) X(no_wave) X(no_comb) X(no_twin) X(no_wide) X(no_strip) \
   X(no_quant) X(no_devlist) X(no_ref_cache) X(no_strip_groups) X(u8_long_twin) X(long_twin) X(no_long) \
-  X(no_requery) X(force_f32) X(no_long_p32) X(no_opt_margin) X(no_wave_prof) X(no_wave_window) X(no_first) X(no_long_save) X(u8_sample_short) X(no_wave_pieces) X(no_u8_early) X(no_wave_f16) X(trace)
+  X(no_requery) X(force_f32) X(no_long_p32) X(no_opt_margin) X(no_wave_prof) X(no_wave_window) X(no_first) X(no_long_save) X(u8_sample_short) X(no_wave_pieces) X(no_u8_early) X(no_wave_f16) X(no_devlist_by_id) X(trace)
 #define MI355_SW_INT_OPTIONS(X) X(strip_r) X(slot) X(few_r) X(chunk) X(long_pipes) X(long_wgs) X(long_sub) X(long_r) X(long_groups) X(assume_cus) X(long_save_what)
 struct Options {
 #define X(n) bool n = false;
@@ -304,6 +304,9 @@ struct mi355_sw_ctx {
   std::vector<Located> loc_store;
   std::vector<TraceOut> tout_store;
   std::function<void()> while_device_works;   // host work of the running call that does not depend on the launches in flight: run in front of the next wait
+  ViewStore *direct_view = nullptr;  // mi355_sw_batch_run_view: where exact_full_device may write finished alignments directly
+  size_t devlist_direct = 0;         // ... and how many it wrote there
+  std::vector<char> handled_store;   // per query of the running range: finished by the device-built lists (2: and written into direct_view)
   size_t devlist_done = 0;        // alignments of the running range the device-built lists finished (host_batch.h)
   size_t beyond_f16 = 0;          // sequences of the running call whose maximum was beyond the packed float16 pass's key range (host_batch.h)
   size_t left_window = 0;         // walks of the running call that left their decision window (host_batch.h) and were redone whole
@@ -322,7 +325,7 @@ struct mi355_sw_ctx {
   size_t early_settled = 0;       // uint8-engine queries of the running call settled by the reference's first and last sub-chunks (no sweep)
   size_t wait_retries = 0;        // launches of the running call that were repeated on a non-waiting instance (tl_no_wait)
   LongSaved lsaved;
-  DevBuf colsave, rowsave, pieces;
+  DevBuf colsave, rowsave, pieces, recs;
   std::vector<uint8_t> h_pieces;  // host side of the piece table of the running call (host_batch.h)
   size_t saved_locates = 0, saved_traces = 0, saved_fallbacks = 0;   // finish steps of the running call that started from saved state / fell back
   DevBuf qcnt, sel2, gcnt, wlut, ckpt, first, keys, ranges, stab, ftab, ftab_s, htab, htab8, soloblk, flags, submax, lut, probs, dirs, outs_f, outs_i, cons, walkp, hmat, brow, wprobs, scan;
@@ -533,7 +536,11 @@ Hash128 content_hash_part(const char *p, size_t n) {
 class WorkerPool {
  public:
   static WorkerPool &get() { static WorkerPool p; return p; }
-  // runs job(t) for t = 1 .. nt - 1 on the workers and job(0) on the caller; returns when all are done
+  // runs job(t) for t = 1 .. nt - 1 on the workers and job(0) on the caller; returns when all are done.
+  // The loops of one C-ABI call follow each other within a millisecond or so (defaults while the device works, results, view):
+  // a worker that has finished SPINS on the generation counter for kSpinUs before it goes to sleep on the condition variable,
+  // and the caller spins on the count of pending parts — waking seven sleepers through one mutex cost 0.05-0.1 ms per loop,
+  // a third of a world-8 rank's whole call on the UniProt-shaped batch.
   void run(int nt, const std::function<void(int)> &job) {
     nt = std::min(nt, kWorkers + 1);
     if (nt <= 1) { job(0); return; }
@@ -541,51 +548,108 @@ class WorkerPool {
     {
       std::lock_guard<std::mutex> g(m_);
       if (th_.empty()) for (int w = 0; w < kWorkers; ++w) th_.emplace_back([this, w] { loop(w); });
-      job_ = &job; want_ = nt - 1; pending_ = nt - 1; ++gen_;
     }
-    cv_.notify_all();
+    job_ = &job;
+    pending_.store(nt - 1, std::memory_order_relaxed);
+    // generation and the number of workers it wants travel in ONE word: a worker that sits this generation out may still be
+    // looking at it when the next one is posted
+    state_.store(((state_.load(std::memory_order_relaxed) >> 8) + 1) << 8 | (uint64_t)(nt - 1), std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> g(m_);                           // (a worker between its last look at gen_ and its wait holds m_)
+      if (sleepers_ > 0) cv_.notify_all();
+    }
     job(0);
-    std::unique_lock<std::mutex> g(m_);
-    done_.wait(g, [&] { return pending_ == 0; });
+    for (unsigned spins = 0; pending_.load(std::memory_order_acquire) != 0; ++spins) {
+      if (spins < 4096) cpu_relax(); else std::this_thread::yield();
+    }
     job_ = nullptr;
   }
+  // wakes sleeping workers without giving them work: they spin for kSpinUs again.  Called in front of a wait for the device that
+  // a pooled loop follows (host_batch.h), so that the loop does not start with the wake-up of seven sleepers.
+  void nudge() {
+    std::lock_guard<std::mutex> turn(turn_);
+    std::lock_guard<std::mutex> g(m_);
+    if (th_.empty() || sleepers_ == 0) return;
+    state_.store(((state_.load(std::memory_order_relaxed) >> 8) + 1) << 8, std::memory_order_release);
+    cv_.notify_all();
+  }
   ~WorkerPool() {
-    { std::lock_guard<std::mutex> g(m_); quit_ = true; }
+    { std::lock_guard<std::mutex> g(m_); quit_.store(true, std::memory_order_release); }
     cv_.notify_all();
     for (auto &t : th_) t.join();
   }
 
  private:
   static constexpr int kWorkers = 7;
+  // (MI355_SW_POOL_SPIN_US in the environment, read once: 0 = sleep at once)
+  const int kSpinUs = [] { const char *e = std::getenv("MI355_SW_POOL_SPIN_US"); return e && *e ? std::max(0, atoi(e)) : 1000; }();
+  static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+  }
   void loop(int w) {
-    unsigned seen = 0;
-    std::unique_lock<std::mutex> g(m_);
+    uint64_t seen = 0;
     for (;;) {
-      cv_.wait(g, [&] { return quit_ || gen_ != seen; });
-      if (quit_) return;
-      seen = gen_;
-      if (w >= want_) continue;
+      // spin for a while, then sleep
+      bool fresh = false;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned spins = 0;; ++spins) {
+        if (quit_.load(std::memory_order_acquire)) return;
+        if (state_.load(std::memory_order_acquire) >> 8 != seen) { fresh = true; break; }
+        cpu_relax();
+        if ((spins & 255u) == 255u &&
+            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > kSpinUs) break;
+      }
+      if (!fresh) {
+        std::unique_lock<std::mutex> g(m_);
+        ++sleepers_;
+        cv_.wait(g, [&] { return quit_.load(std::memory_order_acquire) || state_.load(std::memory_order_acquire) >> 8 != seen; });
+        --sleepers_;
+        if (quit_.load(std::memory_order_acquire)) return;
+      }
+      const uint64_t st = state_.load(std::memory_order_acquire);
+      seen = st >> 8;
+      if (w >= (int)(st & 0xFF)) continue;
+      // (this worker is one of the generation's parts: run() cannot return, let alone post the next one, before it is done)
       const std::function<void(int)> *job = job_;
-      g.unlock();
       (*job)(w + 1);
-      g.lock();
-      if (--pending_ == 0) done_.notify_all();
+      pending_.fetch_sub(1, std::memory_order_release);
     }
   }
   std::vector<std::thread> th_;
   std::mutex m_, turn_;
-  std::condition_variable cv_, done_;
+  std::condition_variable cv_;
   const std::function<void(int)> *job_ = nullptr;
-  int want_ = 0, pending_ = 0;
-  unsigned gen_ = 0;
-  bool quit_ = false;
+  int sleepers_ = 0;
+  std::atomic<int> pending_{0};
+  std::atomic<uint64_t> state_{0};                                 // generation << 8 | workers wanted
+  std::atomic<bool> quit_{false};
+};
+
+// items from which a per-item host loop of the running call goes to the pool (set per call by align_range_core)
+thread_local size_t tl_pool_from = 131072;
+struct PoolFromScope {                                             // (all loops of a call or none, see parallel_for)
+  size_t was = tl_pool_from;
+  explicit PoolFromScope(bool) { tl_pool_from = 49152; }
+  ~PoolFromScope() { tl_pool_from = was; }
 };
 
 template <class F>
 void parallel_for(size_t n, F fn) {
-  if (n < 16384) { fn((size_t)0, n); return; }
-  const int nt = n >= 49152 ? 8 : 4;                               // (the pool's threads are there: a rank's eighth of the UniProt-shaped
-                                                                   //  batch — 70 k alignments — gets all eight, as the whole batch does)
+  const size_t pool_from = tl_pool_from;
+  // Measured on one rank's eighth of the UniProt-shaped batch (70 k alignments, tools/c4_w8_time.py under MI355_SW_POOL_THREADS,
+  // C-ABI call).  While the result loops scattered by query id (three loops per call): score + argmax 0.76 ms with every loop on
+  // the calling thread, 1.03 ms on the pool; with traceback 1.40 against 1.31 ms — and 1.50 ms when only SOME loops of the call
+  // took the pool: a call pools all of its loops or none.  With the records in id order (host_batch.h: one sequential loop + the
+  // defaults written while the device works, which also wakes the workers): 0.64-0.69 against 0.76-0.81 ms, 1.00-1.08 against
+  // 1.03-1.04 ms: calls pool from 49 152 items (PoolFromScope), anything else from 131 072.
+  static const int nt_env = [] { const char *e = std::getenv("MI355_SW_POOL_THREADS"); return e && *e ? std::max(1, atoi(e)) : 0; }();
+  if (n < pool_from && !nt_env) { fn((size_t)0, n); return; }
+  const int nt = nt_env ? nt_env : 8;
+  if (nt <= 1 || n < 1024) { fn((size_t)0, n); return; }
   const size_t step = (n + nt - 1) / nt;
   const Options *caller = tl_opt;                                  // the workers see the calling context's options, not the environment's
   const DevInfo *caller_dev = tl_dev;

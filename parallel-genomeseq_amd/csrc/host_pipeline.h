@@ -512,6 +512,7 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
   const int64_t n = rg.hi - rg.lo;
   HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
   // (half a million small alignments per call: the per-query host arrays are sized only where a path reads them)
+  PoolFromScope pool_from_(want_trace);
   loc.resize(nq);
   tout.resize(want_trace ? nq : 0);
   auto fill_defaults = [&loc, &tout, nq, want_trace]() {
@@ -840,7 +841,8 @@ int align_range_core(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
     }
     // Many small whole problems (short reference or short queries: nothing took the score kernel): float engine with
     // identity scoring runs them on device-built job lists, one sorted range per orientation (host_batch.h)
-    std::vector<char> handled(nq, 0);
+    std::vector<char> &handled = ctx->handled_store;               // (2: written straight into the caller's view, host_batch.h)
+    handled.assign(nq, 0);
     bool all_handled = false;
     size_t z_handled = 0;
     if (!any_fast && p.semantics == MI355_SW_F32 && wave_scoring_ok(p) && !opt().no_wave &&
@@ -957,14 +959,25 @@ int align_range_view(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q,
   const size_t nq = q.nq;
   std::vector<Located> &loc = ctx->loc_store;
   std::vector<TraceOut> &tout = ctx->tout_store;
-  int rc = align_range_core(ctx, ref, q, rg, p, flags, loc, tout);
-  if (rc) return rc;
-  HostTrace trace_results("view_results");
+  PoolFromScope pool_from_(want_trace);
   ViewStore &v = ctx->view;
   v.score.resize(nq); v.pos.resize(nq); v.cons_len.resize(nq); v.end_x.resize(nq); v.end_y.resize(nq);
   v.cx.resize(nq); v.cy.resize(nq);
+  // the many-small-alignments batch writes the alignments its device list finishes straight into the view when it has them in
+  // id order (exact_full_device, handled = 2): one pass over half a million results instead of two
+  ctx->handled_store.clear();
+  ctx->devlist_direct = 0;
+  ctx->direct_view = &v;
+  int rc = align_range_core(ctx, ref, q, rg, p, flags, loc, tout);
+  ctx->direct_view = nullptr;
+  if (rc) return rc;
+  HostTrace trace_results("view_results");
+  const std::vector<char> &direct = ctx->handled_store;
+  const bool some_direct = direct.size() == nq && ctx->devlist_direct > 0;
+  if (!(some_direct && ctx->devlist_direct == nq))
   parallel_for(nq, [&](size_t k0, size_t k1) {
     for (size_t k = k0; k < k1; ++k) {
+      if (some_direct && direct[k] == 2) continue;
       const bool hit = loc[k].score > 0;
       const TraceOut *t = (want_trace && hit) ? &tout[k] : nullptr;
       v.score[k] = loc[k].score;

@@ -197,6 +197,32 @@ __global__ void batch_walk_setup(const BatchWalkArgs a) {
   a.walks[k] = w;
 }
 
+// One record per alignment, stored AT ITS QUERY ID (the launch runs longest first; the caller's arrays are in id order): what the
+// host needs of a finished alignment in one 40-byte line, so that its result loop reads and writes sequentially.
+struct BatchRec {
+  float score;               // maximum (0: no positive cell; < 0: left undecided by the packed float16 pass)
+  uint32_t pos;              // walk: first column of the alignment
+  uint32_t len;              // walk: consensus length
+  int32_t status;            // walk: 0 ok, 1 left its window, 2 capacity
+  int64_t ix, iy;            // argmax cell
+  int64_t off;               // walk: offset of its two strings in the consensus buffer
+};
+static_assert(sizeof(BatchRec) == 40, "one record per alignment");
+
+__global__ void batch_records_by_id(const BatchWaveArgs a, const int64_t *wout, const int64_t *offs, BatchRec *rec) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.count) return;
+  BatchRec r;
+  r.score = a.sbest[k];
+  r.ix = a.scell[2 * (size_t)k]; r.iy = a.scell[2 * (size_t)k + 1];
+  r.pos = 0; r.len = 0; r.status = 0; r.off = 0;
+  if (wout != nullptr) {
+    r.len = (uint32_t)wout[3 * (size_t)k]; r.pos = (uint32_t)wout[3 * (size_t)k + 1]; r.status = (int32_t)wout[3 * (size_t)k + 2];
+    r.off = offs[k];
+  }
+  rec[a.qsel[batch_sorted_pos(a.first, a.count, k)]] = r;
+}
+
 // bytes of consensus the write pass will emit per walk (x and y back to back), 0 for a failed walk
 __global__ void batch_walk_sizes(const int64_t *wout, int n, int64_t *sizes) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;

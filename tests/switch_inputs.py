@@ -5,7 +5,7 @@ import numpy as np
 SWITCHES = ["no_f16", "no_unsat", "no_sample", "no_satflag", "no_solo", "no_wave", "no_comb", "no_twin", "no_wide",
             "no_strip", "no_quant", "no_devlist", "no_strip_groups", "u8_long_twin", "long_twin", "no_long",
             "no_requery", "slot=16", "no_long+strip_r=24", "u8_sample_short", "few_r=5", "long_pipes=2", "no_long_p32", "long_groups=2", "force_f32", "no_opt_margin",
-            "no_wave_prof", "no_wave_window", "no_first", "no_long_save", "assume_cus=32", "no_wave_pieces", "no_u8_early", "no_wave_f16"]
+            "no_wave_prof", "no_wave_window", "no_first", "no_long_save", "assume_cus=32", "no_wave_pieces", "no_u8_early", "no_wave_f16", "no_devlist_by_id"]
 
 _cache = {}
 

@@ -93,3 +93,20 @@ def test_dataset_tools(tmp_path):
     out = tmp_path / "out.csv"
     out.write_text("index,QNAME,SEQ,POS,pos_pred,score\n0,a,ACGT,10, 10, 12\n1,b,ACGT,20, 17, 12\n")
     assert eval_pos.count_mismatches(str(out)) == (2, 1)
+
+
+def test_worker_pool_under_thread_sanitizer(tmp_path):
+    """csrc/host_common.h's WorkerPool (spin-then-sleep workers behind parallel_for: the per-item host loops of a big batch) built
+    on its own with g++ -fsanitize=thread and stressed by tests/cpp/worker_pool_stress.cpp: every part of every run exactly once,
+    no data race reported."""
+    import subprocess
+    src = open(os.path.join(ROOT, "parallel-genomeseq_amd", "csrc", "host_common.h")).read()
+    a = src.index("class WorkerPool {")
+    b = src.index("template <class F>\nvoid parallel_for(size_t n, F fn")
+    head = "\n".join("#include <%s>" % h for h in ("algorithm", "atomic", "chrono", "condition_variable", "cstdint", "functional", "mutex", "thread", "vector"))
+    cpp = tmp_path / "pool.cpp"
+    cpp.write_text(head + "\n" + src[a:b] + open(os.path.join(ROOT, "tests", "cpp", "worker_pool_stress.cpp")).read())
+    exe = tmp_path / "pool"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", str(cpp), "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok") and "ThreadSanitizer" not in r.stderr, (r.stdout[-500:], r.stderr[-2000:])

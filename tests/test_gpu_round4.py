@@ -59,6 +59,7 @@ ENGAGE = {
     "no_first": ("polya_u8", "", r"requery", r"first_settled"),
     "no_wave_pieces": ("uniprot_shape", "", r"devlist\[[^\]]*pieces=0", r"devlist\[[^\]]*pieces=1"),
     "no_wave_f16": ("uniprot_shape", "", r"devlist\[[^\]]*f16=0", r"devlist\[[^\]]*f16=1"),
+    "no_devlist_by_id": ("uniprot_shape", "", r"devlist_results\[by_id=0", r"devlist_results\[by_id=1"),
     "no_long_save": ("single3000_f32", "", r"long\[[^\]]*saved=0[^ ]* strip\[[^\]]*mode=max", r"long\[[^\]]*saved=1[^ ]* saved_locate"),
 }
 
