@@ -194,6 +194,7 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   int64_t *h_offs = reinterpret_cast<int64_t *>(pin + o_offs);
   int64_t *h_total = reinterpret_cast<int64_t *>(pin + nq * sizeof(BatchRec));   // by_id: behind the records
   const BatchRec *h_rec = reinterpret_cast<const BatchRec *>(pin);
+  const BatchRecScore *h_rec_s = reinterpret_cast<const BatchRecScore *>(pin);
   if (!by_id) {
     HIPCHK(ctx, hipMemcpyAsync(h_best, a.sbest, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h_cell, a.scell, n * 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -239,11 +240,11 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     ctx->cons_used++;
     cons_base = cons.as<char>();
   } else if (by_id) {
-    hipLaunchKernelGGL(batch_records_by_id, dim3(sblocks), dim3(256), 0, ctx->stream, a, (const int64_t *)nullptr, (const int64_t *)nullptr, ctx->recs.as<BatchRec>());
+    hipLaunchKernelGGL(batch_score_records_by_id, dim3(sblocks), dim3(256), 0, ctx->stream, a, ctx->recs.as<BatchRecScore>());
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));          // (the pass is done; the records are still to come down)
     passes_done = true;
-    HIPCHK(ctx, hipMemcpyAsync(pin, ctx->recs.p, nq * sizeof(BatchRec), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(pin, ctx->recs.p, nq * sizeof(BatchRecScore), hipMemcpyDeviceToHost, ctx->stream));
   }
   if (ctx->while_device_works) { ctx->while_device_works(); ctx->while_device_works = nullptr; }
   { HostTrace t_("  batch: to the last download");
@@ -297,6 +298,11 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
       size_t mine = 0;
       for (size_t id = k0; id < k1; ++id) {
         if (q.len[id] == 0) continue;                              // (an empty query: not in the launch, its defaults stand)
+        if (!want_trace) {
+          const BatchRecScore &r = h_rec_s[id];
+          mine += take((int)id, r.score, r.ix, r.iy, 0, 0, 0, 0) ? 1 : 0;
+          continue;
+        }
         const BatchRec &r = h_rec[id];
         mine += take((int)id, r.score, r.ix, r.iy, (size_t)r.len, r.pos, r.status, r.off) ? 1 : 0;
       }

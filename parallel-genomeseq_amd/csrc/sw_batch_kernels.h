@@ -209,6 +209,22 @@ struct BatchRec {
 };
 static_assert(sizeof(BatchRec) == 40, "one record per alignment");
 
+// ... without walks (score + argmax only): 12 bytes per alignment come down instead of 40
+struct BatchRecScore {
+  float score;
+  int32_t ix, iy;            // (a row of a resident query, a column of a range shorter than 1024: both fit)
+};
+static_assert(sizeof(BatchRecScore) == 12, "one record per alignment");
+
+__global__ void batch_score_records_by_id(const BatchWaveArgs a, BatchRecScore *rec) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.count) return;
+  BatchRecScore r;
+  r.score = a.sbest[k];
+  r.ix = (int32_t)a.scell[2 * (size_t)k]; r.iy = (int32_t)a.scell[2 * (size_t)k + 1];
+  rec[a.qsel[batch_sorted_pos(a.first, a.count, k)]] = r;
+}
+
 __global__ void batch_records_by_id(const BatchWaveArgs a, const int64_t *wout, const int64_t *offs, BatchRec *rec) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= a.count) return;
