@@ -83,7 +83,23 @@ def run(budget=120.0, seed=4321):
             xs.append(x)
         with ThreadPoolExecutor(8) as ex:
             exp = list(ex.map(lambda x: ob.align(x, y, 0, *sc), xs))
-        got = ctx.align_batch(xs, y, semantics=0, match=sc[0], mismatch=sc[1], gap=sc[2])
+        # three ways to the same answers: result objects (mi355_sw_batch_run), the struct-of-arrays view with consensus strings
+        # (mi355_sw_batch_run_view: the device list's id-ordered records fill it directly), the view without traceback
+        mode = rounds % 3
+        if mode == 0:
+            got = ctx.align_batch(xs, y, semantics=0, match=sc[0], mismatch=sc[1], gap=sc[2])
+        else:
+            ctx.set_reference(y)
+            ctx.batch_upload(xs)
+            raw = ctx.batch_run(semantics=0, match=sc[0], mismatch=sc[1], gap=sc[2], raw=True, flags=pgs.capi.SCORE_ONLY if mode == 2 else 0)
+            got = []
+            for k in range(len(xs)):
+                g1 = dict(score=float(raw["score"][k]), pos=int(raw["pos"][k]), end_x=int(raw["end_x"][k]), end_y=int(raw["end_y"][k]))
+                if mode == 1:
+                    g1["cons_x"], g1["cons_y"] = ctx.consensus(k)
+                else:                                                  # (no traceback: pos and the strings are not made)
+                    g1["pos"], g1["cons_x"], g1["cons_y"] = exp[k]["pos"], exp[k]["cons_x"], exp[k]["cons_y"]
+                got.append(g1)
         nleft += ctx.last_counters()["left_window"]
         for k, (ge, e) in enumerate(zip(got, exp)):
             ncase += 1
@@ -91,7 +107,7 @@ def run(budget=120.0, seed=4321):
                 if ge[key] != e[key]:
                     nbad += 1
                     if nbad <= 5:
-                        _found("MISMATCH |y|=%d |x|=%d scoring %r alphabet %d: %s got %r expected %r" % (ylen, len(xs[k]), sc, len(alpha), key, ge[key], e[key]),
+                        _found("MISMATCH (mode %d) |y|=%d |x|=%d scoring %r alphabet %d: %s got %r expected %r" % (mode, ylen, len(xs[k]), sc, len(alpha), key, ge[key], e[key]),
                               flush=True)
                     break
         rounds += 1
