@@ -204,7 +204,7 @@ int run_wave(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q, const R
     w.best = ctx->outs_f.as<float>() + k;
     w.cell = ctx->outs_i.as<int64_t>() + 2 * k;
     w.target = j.target; w.own_lo = j.own_lo; w.full_n = nref;
-    w.ckpt = nullptr; w.k0 = 0; w.ck_half = 0;
+    w.ckpt = nullptr; w.k0 = 0; w.ck_half = 0; w.lanes_used = 0;
   }
   });
   const bool keyed = jobs[0].keyed;

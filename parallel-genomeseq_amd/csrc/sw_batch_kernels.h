@@ -102,7 +102,7 @@ __global__ void batch_wave_setup(const BatchWaveArgs a) {
   w.dirs = a.ckpt != nullptr ? nullptr
                              : reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(a.dirs) + batch_dirs_offset(before, kk, a.W));
   w.ckpt = a.ckpt != nullptr ? a.ckpt + (size_t)batch_ckpt_row(before, kk) * 16 * (size_t)(a.R + 1) : nullptr;
-  w.k0 = 0; w.ck_half = 0;
+  w.k0 = 0; w.ck_half = 0; w.lanes_used = 0;
   w.best = a.best + kk;
   w.cell = a.cell + 2 * (size_t)kk;
   w.target = 0.0f; w.own_lo = 0; w.full_n = a.nref;
@@ -157,6 +157,8 @@ __global__ void batch_window_setup(const BatchWaveArgs a) {
   float *states = a.f16 ? a.probs[a.sprob[k] & ~1].ckpt : w.ckpt;
   w.ckpt = k0 > 0 ? states + (size_t)(k0 / kCkptEvery - 1) * 16 * (size_t)(a.R + 1) : nullptr;
   w.ck_half = a.f16 ? 1 + (a.sprob[k] & 1) : 0;
+  // (lanes hold columns of y: the walk starts in the argmax column's lane and never moves right)
+  w.lanes_used = hit ? (int32_t)((a.scell[2 * (size_t)k + 1] - 1) / a.R) + 1 : 1;
   w.dirs = a.dirs + (size_t)k * kWindowRows * 16 * (size_t)a.W;
   a.probs2[k] = w;
 }

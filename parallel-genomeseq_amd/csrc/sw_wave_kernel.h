@@ -46,6 +46,9 @@ struct WaveProblem {
   // 16 x (R + 1) dwords per saved state for the PAIR of problems a slot runs (ckpt of the pair's first problem); 1 / 2 = this
   // problem was the low / high half (0: float32 states of its own, sw_wave_prof_kernel<TRACK>)
   int32_t ck_half;
+  // DIRS of a window that ENDS at the argmax (host_batch.h): the walk only moves up and to the left, so decisions are wanted of
+  // the lanes up to the argmax column's; the launch then runs nb - k0 + lanes_used steps instead of nb - k0 + 16 (0: all lanes)
+  int32_t lanes_used;
 };
 
 struct WaveScoring {
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, 
   WaveProblem P;
   if (active) P = probs[pid];
   else { P.a = nullptr; P.b = nullptr; P.na = 0; P.nb = 0; P.b_offset = 0; P.dirs = nullptr; P.best = nullptr; P.cell = nullptr;
-         P.target = -1.0f; P.own_lo = 0; P.full_n = 0; P.ckpt = nullptr; P.k0 = 0; P.ck_half = 0; }
+         P.target = -1.0f; P.own_lo = 0; P.full_n = 0; P.ckpt = nullptr; P.k0 = 0; P.ck_half = 0; P.lanes_used = 0; }
   const int na = P.na, nb = P.nb;
 
   // this lane's R characters of the short side (0xFFFF = padding, never equal to a byte)
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
   WaveProblem P;
   if (active) P = probs[pid];
   else { P.a = nullptr; P.b = nullptr; P.na = 0; P.nb = 0; P.b_offset = 0; P.dirs = nullptr; P.best = nullptr; P.cell = nullptr;
-         P.target = -1.0f; P.own_lo = 0; P.full_n = 0; P.ckpt = nullptr; P.k0 = 0; P.ck_half = 0; }
+         P.target = -1.0f; P.own_lo = 0; P.full_n = 0; P.ckpt = nullptr; P.k0 = 0; P.ck_half = 0; P.lanes_used = 0; }
   const int nb = P.nb;
   // the lane side is the same for every problem of the launch (the range of the resident reference)
   const uint8_t *ya = probs[blockIdx.x * 16].a;
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
     }
     return w;
   };
-  int steps = nb - k0 + 16;
+  int steps = nb - k0 + ((DIRS && !TRACK && P.lanes_used > 0) ? P.lanes_used : 16);
   steps = max(steps, __shfl_xor(steps, 16));
   steps = max(steps, __shfl_xor(steps, 32));
   const int nseg = (steps + kWaveSeg - 1) / kWaveSeg;
