@@ -58,8 +58,10 @@ struct WaveScoring {
 
 constexpr int kWaveSeg = 64;
 constexpr int kWaveBuf = 16 + kWaveSeg;
-constexpr int kCkptEvery = 32;           // steps between two saved states of a checkpointed pass (sw_wave_prof_kernel / sw_wave_prof16_kernel)
-static_assert(kWaveSeg == 2 * kCkptEvery, "a state is saved in the middle and at the end of every 64-step segment");
+constexpr int kCkptEvery = 32;           // steps between two saved states of a checkpointed pass (sw_wave_prof_kernel / sw_wave_prof16_kernel);
+                                         // 16 was measured: decision pass 1.51 -> 1.32 ms, first pass 2.81 -> 2.93 ms, twice the states: not taken
+constexpr int kCkptPerSeg = kWaveSeg / kCkptEvery;
+static_assert(kWaveSeg % kCkptEvery == 0 && kCkptEvery % 4 == 0, "states are saved inside and at the end of every 64-step segment");
 
 template <int R, int ORIENT, bool U8, bool TRACK, bool DIRS, bool KEYED = false>
 __global__ __launch_bounds__(256) void sw_wave_kernel(const WaveProblem *probs, int nprob, const WaveScoring sc) {
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
   for (int seg = 0; seg < nseg; ++seg) {
     const int kq = min(kWaveSeg, steps4 - seg * kWaveSeg) >> 2;
     for (int k4 = 0; k4 < kq; ++k4) {
-    if (TRACK && !DIRS && k4 == kCkptEvery / 4) save_state(2 * seg);
+    if (TRACK && !DIRS && k4 != 0 && (4 * k4) % kCkptEvery == 0) save_state(kCkptPerSeg * seg + 4 * k4 / kCkptEvery - 1);
 #pragma unroll
     for (int ku = 0; ku < 4; ++ku) {
       const int k = 4 * k4 + ku;
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(256) void sw_wave_prof_kernel(const WaveProblem *pr
       }
     }
     }
-    if (TRACK && !DIRS && kq == kWaveSeg / 4) save_state(2 * seg + 1);
+    if (TRACK && !DIRS && kq == kWaveSeg / 4) save_state(kCkptPerSeg * seg + kCkptPerSeg - 1);
     const uint32_t hist = buf32[kWaveSeg / 4 + (l & 3)];
     if (l < 4) buf32[l] = hist;
     buf32[4 + l] = nextc;
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(256) void sw_wave_prof16_kernel(const WaveProblem *
   for (int seg = 0; seg < nseg; ++seg) {
     const int kq = min(kWaveSeg, steps4 - seg * kWaveSeg) >> 2;
     for (int k4 = 0; k4 < kq; ++k4) {
-    if (k4 == kCkptEvery / 4) save_state(2 * seg);
+    if (k4 != 0 && (4 * k4) % kCkptEvery == 0) save_state(kCkptPerSeg * seg + 4 * k4 / kCkptEvery - 1);
 #pragma unroll
     for (int ku = 0; ku < 4; ++ku) {
       const int k = 4 * k4 + ku;
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(256) void sw_wave_prof16_kernel(const WaveProblem *
       }
     }
     }
-    if (kq == kWaveSeg / 4) save_state(2 * seg + 1);
+    if (kq == kWaveSeg / 4) save_state(kCkptPerSeg * seg + kCkptPerSeg - 1);
     const uint32_t histA = bufA32[kWaveSeg / 4 + (l & 3)], histB = bufB32[kWaveSeg / 4 + (l & 3)];
     if (l < 4) { bufA32[l] = histA; bufB32[l] = histB; }
     bufA32[4 + l] = nextA; bufB32[4 + l] = nextB;
