@@ -701,7 +701,10 @@ int long_score_launch(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
                                                                         // is bound by issue slots that only other wavefronts fill
   pipes = std::max(1, std::min(pipes, long_max_waves(b.R) / spg));
   while (pipes > 1 && long_lds_bytes(ref.ncodes, spg, pipes, b.R, kLongSubsMax, p32) > long_lds_max()) --pipes;
-  int64_t sub_len = opt().long_sub >= 64 ? opt().long_sub / 64 * 64 : 2048;
+  // columns per reported (and saved) sub-chunk.  The finish recomputes blocks of sub_len columns around the winner (host_saved.h):
+  // a per-call constant of ~2.3 ms at 2048, ~1.6 at 1024, while the sweep pays 1.4 ms per 250 M columns for the finer grain
+  // (measured, tools/c5_whole.py long_sub=...): finer below ~125 M columns — a rank's share of a sharded reference
+  int64_t sub_len = opt().long_sub >= 64 ? opt().long_sub / 64 * 64 : (total_cols < 125e6 ? 1024 : 2048);
   // uint8 engine: a power of two >= |x|, so that the skewed storage order stays within two neighbouring sub-chunks (locate_fast)
   if (p.semantics == MI355_SW_U8SAT) sub_len = std::max<int64_t>(sub_len, score_sub_len(p.semantics, b));
   int64_t chunk = 0;
