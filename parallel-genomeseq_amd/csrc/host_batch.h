@@ -257,7 +257,7 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   std::atomic<bool> bad{false};
   std::atomic<size_t> left{0}, beyond{0}, done{0};
   ViewStore *dv = by_id ? ctx->direct_view : nullptr;              // (mi355_sw_batch_run_view: finished alignments go straight into the view)
-  // one alignment: the launch's (score, cell, walk) -> handled / loc / tout of query `id`, or its entries of the caller's view
+  // one alignment: the launch's (score, cell, walk) -> handled / loc / tout of query `id`
   auto take = [&](int id, float best, int64_t ix, int64_t iy, size_t len, uint32_t pos, int64_t status, int64_t off) -> bool {
     const bool hit = best > 0;
     if (best < 0) { beyond.fetch_add(1, std::memory_order_relaxed); return false; }      // the float16 pass left it undecided (handled stays 0)
@@ -266,20 +266,6 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
       if (!windows || status != 1) bad.store(true, std::memory_order_relaxed);
       else left.fetch_add(1, std::memory_order_relaxed);
       return false;
-    }
-    if (dv) {
-      // (as align_range_view makes them from loc / tout)
-      handled[id] = 2;
-      const bool tr = want_trace && hit;
-      const size_t l = tr ? len : 0;
-      dv->score[id] = hit ? best : 0;
-      dv->end_x[id] = hit ? ix : 0;
-      dv->end_y[id] = hit ? iy : 0;
-      dv->pos[id] = tr ? pos : 0;
-      dv->cons_len[id] = (uint32_t)l;
-      dv->cx[id] = l ? cons_base + off : nullptr;
-      dv->cy[id] = l ? cons_base + off + l : nullptr;
-      return true;
     }
     handled[id] = 1;
     Located &L = loc[id];
@@ -293,7 +279,53 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     t.pos = pos;
     return true;
   };
-  if (by_id) {
+  if (by_id && dv) {
+    // Straight into the caller's view (as align_range_view makes its entries from loc / tout).  The loop is bound by the host's
+    // memory traffic at half a million alignments: the seven arrays are written once, in id order, so they leave as STREAMING
+    // stores (no read-for-ownership of lines that are overwritten whole) — one array at a time out of a small tile, because
+    // seven interleaved streams per thread overflow the core's write-combining buffers (measured: 0.3 ms, but 3.5 ms in one
+    // call of three, against 0.95 ms with ordinary stores).  Entries of alignments that are NOT finished here (undecided by
+    // the float16 pass, a walk that left its window, an empty query) are written as zeros and made by align_range_view.
+    parallel_for(nq, [&](size_t k0, size_t k1) {
+      constexpr size_t T = 256;
+      float t_score[T]; int64_t t_ex[T], t_ey[T]; uint32_t t_pos[T], t_len[T]; const char *t_cx[T], *t_cy[T];
+      size_t mine = 0;
+      for (size_t id0 = k0; id0 < k1; id0 += T) {
+        const size_t cnt = std::min(T, k1 - id0);
+        for (size_t j = 0; j < cnt; ++j) {
+          const size_t id = id0 + j;
+          float best = 0; int64_t ix = 0, iy = 0, status = 0, off = 0; size_t len = 0; uint32_t pos = 0;
+          bool ok = q.len[id] != 0;
+          if (ok) {
+            if (!want_trace) { const BatchRecScore &r = h_rec_s[id]; best = r.score; ix = r.ix; iy = r.iy; }
+            else { const BatchRec &r = h_rec[id]; best = r.score; ix = r.ix; iy = r.iy; len = r.len; pos = r.pos; status = r.status; off = r.off; }
+            const bool hit = best > 0;
+            if (best < 0) { beyond.fetch_add(1, std::memory_order_relaxed); ok = false; }
+            else if (want_trace && hit && status != 0) {
+              if (!windows || status != 1) bad.store(true, std::memory_order_relaxed);
+              else left.fetch_add(1, std::memory_order_relaxed);
+              ok = false;
+            }
+          }
+          const bool hit = ok && best > 0, tr = hit && want_trace;
+          const size_t l = tr ? len : 0;
+          if (ok) { handled[id] = 2; ++mine; }
+          t_score[j] = hit ? best : 0.0f; t_ex[j] = hit ? ix : 0; t_ey[j] = hit ? iy : 0;
+          t_pos[j] = tr ? pos : 0; t_len[j] = (uint32_t)l;
+          t_cx[j] = l ? cons_base + off : nullptr; t_cy[j] = l ? cons_base + off + l : nullptr;
+        }
+        for (size_t j = 0; j < cnt; ++j) __builtin_nontemporal_store(t_score[j], &dv->score[id0 + j]);
+        for (size_t j = 0; j < cnt; ++j) __builtin_nontemporal_store(t_ex[j], &dv->end_x[id0 + j]);
+        for (size_t j = 0; j < cnt; ++j) __builtin_nontemporal_store(t_ey[j], &dv->end_y[id0 + j]);
+        for (size_t j = 0; j < cnt; ++j) __builtin_nontemporal_store(t_pos[j], &dv->pos[id0 + j]);
+        for (size_t j = 0; j < cnt; ++j) __builtin_nontemporal_store(t_len[j], &dv->cons_len[id0 + j]);
+        for (size_t j = 0; j < cnt; ++j) __builtin_nontemporal_store(t_cx[j], &dv->cx[id0 + j]);
+        for (size_t j = 0; j < cnt; ++j) __builtin_nontemporal_store(t_cy[j], &dv->cy[id0 + j]);
+      }
+      __builtin_ia32_sfence();                                     // (the streaming stores of this part, before it reports done)
+      done.fetch_add(mine, std::memory_order_relaxed);
+    });
+  } else if (by_id) {
     parallel_for(nq, [&](size_t k0, size_t k1) {
       size_t mine = 0;
       for (size_t id = k0; id < k1; ++id) {
