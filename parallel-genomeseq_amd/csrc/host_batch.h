@@ -201,6 +201,10 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   }
   const char *cons_base = nullptr;
   bool passes_done = false;
+  struct InFlight {                                                // (no exit leaves a download running into the staging buffer)
+    hipStream_t s; bool armed = false;
+    ~InFlight() { if (armed) (void)hipStreamSynchronize(s); }
+  } records_in_flight{ctx->copy_stream};
   if (want_trace) {
     WaveWalk *walks = ctx->walkp.as<WaveWalk>();
     int64_t *wout = reinterpret_cast<int64_t *>(ctx->walkp.as<uint8_t>() + n * sizeof(WaveWalk));
@@ -220,8 +224,13 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
     if (by_id) {
       hipLaunchKernelGGL(batch_records_by_id, dim3(sblocks), dim3(256), 0, ctx->stream, a, (const int64_t *)wout, (const int64_t *)offs, ctx->recs.as<BatchRec>());
       HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
       HIPCHK(ctx, hipMemcpyAsync(h_total, offs + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipMemcpyAsync(pin, ctx->recs.p, nq * sizeof(BatchRec), hipMemcpyDeviceToHost, ctx->stream));
+      // the records (40 bytes per alignment: 22 MB for config 4) come down on the copy stream, beside the write pass of the walks
+      // and the download of the strings — the wait below is only for the 8 bytes that size those
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev[6], 0));
+      records_in_flight.armed = true;
+      HIPCHK(ctx, hipMemcpyAsync(pin, ctx->recs.p, nq * sizeof(BatchRec), hipMemcpyDeviceToHost, ctx->copy_stream));
     } else {
       HIPCHK(ctx, hipMemcpyAsync(h_offs, offs, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(ctx, hipMemcpyAsync(h_wout, wout, n * 24, hipMemcpyDeviceToHost, ctx->stream));
@@ -252,7 +261,8 @@ int exact_full_device(mi355_sw_ctx *ctx, const RefData &ref, const QueryBatch &q
   // wait allows — behind the pass when only the download of the records is left, else in front of the last wait
   if (passes_done) HIPCHK(ctx, hipEventSynchronize(ctx->ev[6]));
   if (n >= tl_pool_from) WorkerPool::get().nudge();
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (records_in_flight.armed) { records_in_flight.armed = false; HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream)); } }
   HostTrace t_results("  batch: results on the host");
   std::atomic<bool> bad{false};
   std::atomic<size_t> left{0}, beyond{0}, done{0};

@@ -287,6 +287,7 @@ struct ViewStore {
 struct mi355_sw_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;   // downloads that need not hold up the kernels behind them (host_batch.h: the records of a batch)
   hipEvent_t ev[8] = {};
   std::string err;
   RefData ref;                    // resident reference (set_reference)

@@ -80,6 +80,7 @@ int mi355_sw_create(mi355_sw_ctx **out, int device) {
     }
   }
   if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return MI355_SW_ENODEV; }
+  if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return MI355_SW_ENODEV; }
   for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return MI355_SW_ENODEV; }
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_exact_kernel<0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kExactLdsMax);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_exact_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kExactLdsMax);
@@ -100,6 +101,7 @@ void mi355_sw_destroy(mi355_sw_ctx *c) {
   for (PinBuf &b : c->pin_cons) b.release();
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto &e : c->score_ev) (void)hipEventDestroy(e);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
